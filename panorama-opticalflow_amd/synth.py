@@ -1,0 +1,127 @@
+"""Deterministic synthetic overlap pairs; Test_data is absent from the reference.
+
+Analytic multi-sinusoid texture T, smooth displacement field d, L = T(x + d/2), R = 1.05 * T(x - d/2)
+(gain exercises computeIntensityRatio), alpha holes (edge bands + one ellipse), horizontal blend ramp.
+Ground truth: flow L->R ~= -d, flow R->L ~= +d inside the valid-alpha region.
+Works on any torch device (the bench generates directly in HBM).
+"""
+import math
+
+import numpy as np
+import torch
+
+_MASK = (1 << 64) - 1
+
+
+class SplitMix64:
+    def __init__(self, seed):
+        self.s = seed & _MASK
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & _MASK
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _MASK
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK
+        return z ^ (z >> 31)
+
+    def uniform(self):
+        return (self.next() >> 11) * (1.0 / (1 << 53))
+
+
+def texture_params(seed, n=24):
+    rng = SplitMix64(seed)
+    ks = []
+    for _ in range(n):
+        mag = math.exp(math.log(1 / 256.0) + rng.uniform() * (math.log(1 / 6.0) - math.log(1 / 256.0)))
+        ang = rng.uniform() * 2 * math.pi
+        amp = mag ** -0.5
+        ph = [rng.uniform() * 2 * math.pi for _ in range(3)]
+        ks.append((mag * math.cos(ang), mag * math.sin(ang), amp, ph))
+    return ks
+
+
+def displacement(x, y, cols, rows, scale=1.0):
+    dx = 6.0 * torch.sin(3 * math.pi * y / rows) + 3.0 * torch.cos(4 * math.pi * x / cols)
+    dy = 1.5 * torch.sin(6 * math.pi * x / cols) + 0.0 * y
+    return dx * scale, dy * scale
+
+
+def _texture(u, v, ks):
+    sigma = math.sqrt(sum(a * a for _, _, a, _ in ks) / 2.0)
+    out = [torch.zeros_like(u) for _ in range(3)]
+    for fx, fy, a, ph in ks:
+        th = 2 * math.pi * (fx * u + fy * v)
+        s, c = torch.sin(th), torch.cos(th)
+        for ch in range(3):
+            out[ch] += a * (s * math.cos(ph[ch]) + c * math.sin(ph[ch]))
+    return [128.0 + 112.0 * t / (3.0 * sigma) for t in out]
+
+
+def alpha_mask(x, y, cols, rows):
+    band = cols // 16
+    inside = (x >= band) & (x < cols - band)
+    ell = ((x - 0.7 * cols) / (cols / 10.0)) ** 2 + ((y - 0.3 * rows) / (rows / 12.0)) ** 2 <= 1.0
+    return inside & ~ell
+
+
+def make_pair(cols, rows, seed=1234, device="cpu", disp_scale=1.0, row_chunk=512):
+    """Returns (L, R, blend, (dx, dy)): L,R uint8 [rows, cols, 4] BGRA; blend float32 [rows, cols]."""
+    ks = texture_params(seed)
+    L = torch.empty((rows, cols, 4), dtype=torch.uint8, device=device)
+    R = torch.empty((rows, cols, 4), dtype=torch.uint8, device=device)
+    xs = torch.arange(cols, dtype=torch.float64, device=device)[None, :]
+    for y0 in range(0, rows, row_chunk):
+        y1 = min(rows, y0 + row_chunk)
+        ys = torch.arange(y0, y1, dtype=torch.float64, device=device)[:, None]
+        x = xs.expand(y1 - y0, cols); y = ys.expand(y1 - y0, cols)
+        dx, dy = displacement(x, y, cols, rows, disp_scale)
+        a = alpha_mask(x, y, cols, rows)
+        tl = _texture(x + dx / 2, y + dy / 2, ks)
+        tr = _texture(x - dx / 2, y - dy / 2, ks)
+        for ch in range(3):
+            l = torch.clamp(torch.round(torch.clamp(tl[ch], 16.0, 240.0)), 0, 255)
+            r = torch.clamp(torch.round(1.05 * torch.clamp(tr[ch], 16.0, 240.0)), 0, 255)
+            L[y0:y1, :, ch] = torch.where(a, l, torch.zeros_like(l)).to(torch.uint8)
+            R[y0:y1, :, ch] = torch.where(a, r, torch.zeros_like(r)).to(torch.uint8)
+        av = torch.where(a, 255, 0).to(torch.uint8)
+        L[y0:y1, :, 3] = av; R[y0:y1, :, 3] = av
+    blend = make_blend(cols, rows, device)
+    return L, R, blend, None
+
+
+def make_blend(cols, rows, device="cpu"):
+    """Horizontal ramp 0->1 across the valid region, box-smoothed (width cols/32)."""
+    band = cols // 16
+    x = torch.arange(cols, dtype=torch.float64, device=device)
+    ramp = torch.clamp((x - band) / max(1.0, float(cols - 2 * band - 1)), 0.0, 1.0)
+    k = max(1, cols // 32) | 1
+    pad = k // 2
+    rp = torch.cat([ramp[:1].expand(pad), ramp, ramp[-1:].expand(pad)])
+    cs = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.float64, device=device), rp]), 0)
+    sm = (cs[k:] - cs[:-k]) / k
+    return sm.to(torch.float32)[None, :].expand(rows, cols).contiguous()
+
+
+def ground_truth_flow(cols, rows, device="cpu", disp_scale=1.0):
+    xs = torch.arange(cols, dtype=torch.float64, device=device)[None, :].expand(rows, cols)
+    ys = torch.arange(rows, dtype=torch.float64, device=device)[:, None].expand(rows, cols)
+    dx, dy = displacement(xs, ys, cols, rows, disp_scale)
+    return torch.stack([dx, dy], -1).to(torch.float32)
+
+
+def make_pair_np(cols, rows, seed=1234, disp_scale=1.0):
+    L, R, blend, _ = make_pair(cols, rows, seed, "cpu", disp_scale)
+    return L.numpy(), R.numpy(), blend.numpy()
+
+
+def make_canvas_pair(cols, rows, seed=1234, device="cpu"):
+    """Full-canvas style pair for Stitchtools tests: L covers a left window, R a right window, overlapping
+    in the middle third; outside its window each image is fully transparent (all 4 channels 0)."""
+    L, R, _, _ = make_pair(cols, rows, seed, device)
+    x = torch.arange(cols, device=device)[None, :, None]
+    y = torch.arange(rows, device=device)[:, None, None]
+    wob = (8 * torch.sin(y.double() * (2 * math.pi / max(rows, 1)) * 3)).long()
+    inL = (x >= cols // 10) & (x < (cols * 6) // 10 + wob)
+    inR = (x >= (cols * 4) // 10 - wob) & (x < (cols * 9) // 10)
+    L = torch.where(inL, L, torch.zeros_like(L)); R = torch.where(inR, R, torch.zeros_like(R))
+    return L, R

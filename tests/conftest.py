@@ -1,0 +1,44 @@
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "panorama-opticalflow_amd")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def load_pkg_module(name):
+    """The package directory name has a hyphen (not importable); load its modules by path."""
+    modname = "pano_amd_" + name
+    if modname in sys.modules:
+        return sys.modules[modname]
+    spec = importlib.util.spec_from_file_location(modname, os.path.join(PKG, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import orc as _orc
+    _orc.build()
+    return _orc
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return load_pkg_module("synth")
+
+
+@pytest.fixture(scope="session")
+def pf():
+    """ctypes binding of the product C-ABI (include/panoflow.h)."""
+    return load_pkg_module("pyabi")
