@@ -1,0 +1,137 @@
+/* =============================================================================================
+ * panoflow.h -- C ABI of the MI355X-native bidirectional optical-flow blending path.
+ *
+ * Drop-in boundary for MungoMeng/Panorama-OpticalFlow (reference paths are relative to
+ * /root/reference/).  Everything here is plain pointers + sizes; no C++/torch/OpenCV types.  The
+ * C++ mirror of the reference's OpticalFlow.hpp / StitchTool.hpp / PixFlow.hpp classes
+ * (panorama-opticalflow_amd/include/) is a thin layer over these entry points; INTEGRATION.md shows
+ * the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - return 0 on success, negative pf_status on failure; pf_last_error() gives the message.
+ *     No exceptions cross this ABI (the C++ wrapper rethrows util::VrCamException).
+ *   - images: 8-bit BGRA interleaved, row-major, `step` = bytes per row  (CV_8UC4)
+ *     flow  : float (dx,dy) interleaved, pixels of the full-res image      (CV_32FC2)
+ *     blend : float in [0,1] = weight of the RIGHT image                   (CV_32FC1)
+ *     map   : uint8 region codes 0/50/100/150                              (CV_8UC1)
+ *   - every call is synchronous on return; a context is owned by one host thread and one GPU.
+ *   - there is NO CPU fallback: without a usable gfx950 device pf_create() fails.
+ * ============================================================================================= */
+#ifndef PANOFLOW_H_
+#define PANOFLOW_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pf_ctx pf_ctx;
+
+typedef enum pf_status {
+  PF_OK = 0,
+  PF_ERR_ARG = -1,      /* bad argument (null pointer, size out of range, unknown algorithm) */
+  PF_ERR_DEVICE = -2,   /* HIP runtime / launch failure */
+  PF_ERR_NOMEM = -3,    /* device allocation failed */
+  PF_ERR_TIMEOUT = -4   /* a sweep band gave up waiting for its predecessor (never expected) */
+} pf_status;
+
+/* OpticalFlowInterface::DirectionHint, CPU/PixFlow.hpp:19 */
+typedef enum pf_hint { PF_HINT_UNKNOWN = 0, PF_HINT_RIGHT = 1, PF_HINT_DOWN = 2, PF_HINT_LEFT = 3, PF_HINT_UP = 4 } pf_hint;
+
+/* ---- lifetime -------------------------------------------------------------------------------
+ * Replaces the reference's runtime device probe (GPU/OpticalFlow.cpp:132-189, GPU/StitchTool.cpp:33-60). */
+int pf_device_count(void);
+pf_ctx* pf_create(int device);                 /* NULL on failure; pf_last_error(NULL) explains */
+void pf_destroy(pf_ctx* ctx);
+const char* pf_last_error(const pf_ctx* ctx);  /* ctx may be NULL (creation errors) */
+const char* pf_version(void);
+
+/* makeOpticalFlowByName, CPU/PixFlow.hpp:459-500: "pixflow_low" -> 0, "pixflow_search_20" -> 20,
+ * anything else -> PF_ERR_ARG (the reference throws VrCamException). */
+int pf_max_percentage_by_name(const char* flow_alg_name);
+
+/* ---- host-buffer entry points (the drop-in boundary) --------------------------------------- */
+
+/* PixFlow<P>::computeOpticalFlow, CPU/PixFlow.hpp:72-135.  flow = I0 -> I1, cols x rows. */
+int pf_flow(pf_ctx* ctx, const uint8_t* i0_bgra, const uint8_t* i1_bgra, int cols, int rows, size_t step_bytes,
+            int max_percentage, int hint, float* flow_xy, size_t flow_step_bytes);
+
+/* NovelViewGeneratorAsymmetricFlow::prepare, CPU/OpticalFlow.cpp:102-145: wrap-pad by cols/20,
+ * L->R solve (hint LEFT) and R->L solve (hint RIGHT) concurrently, crop.  Either output may be NULL. */
+int pf_flow_bidir(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, int cols, int rows, size_t step_bytes,
+                  int max_percentage, float* flow_l2r, float* flow_r2l, size_t flow_step_bytes);
+
+/* NovelViewUtil::combineNovelViews, CPU/OpticalFlow.cpp:30-92 (+ generateNovelViewPoint :9-28). */
+int pf_blend(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, size_t step_bytes, const float* flow_l2r,
+             const float* flow_r2l, size_t flow_step_bytes, const float* blend, size_t blend_step_bytes, int cols, int rows,
+             uint8_t* out_bgra, size_t out_step_bytes);
+
+/* prepare() + setBlend() + generateNovelView() in one call with the flows kept in HBM
+ * (CPU/main.cpp:82-90).  flow outputs may be NULL. */
+int pf_novel_view(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, int cols, int rows, size_t step_bytes,
+                  int max_percentage, const float* blend, size_t blend_step_bytes, uint8_t* out_bgra, size_t out_step_bytes,
+                  float* flow_l2r, float* flow_r2l, size_t flow_step_bytes);
+
+/* Stitchtools::prepare, CPU/StitchTool.cpp:7-36 (MatchImages :38-50, GenerateBlend :98-146,
+ * countblend :148-191).  merged_dis may be NULL.  All planes cols x rows, packed rows of `step`. */
+int pf_stitch_prepare(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, int cols, int rows, size_t step_bytes,
+                      uint8_t* map_out, size_t map_step_bytes, uint8_t* overlapped_l, uint8_t* overlapped_r,
+                      float* blend_out, size_t blend_step_bytes, float* merged_dis /* packed, nullable */);
+
+/* Stitchtools::Gather, CPU/StitchTool.cpp:52-96. */
+int pf_stitch_gather(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, const uint8_t* merged_bgra, size_t step_bytes,
+                     const uint8_t* map, size_t map_step_bytes, int cols, int rows, uint8_t* out_bgra, size_t out_step_bytes);
+
+/* ---- device-resident entry points (packed buffers already in this context's HBM) -----------
+ * Same semantics as above; used by bench.py (inputs resident when the clock starts) and by the
+ * multi-GPU driver.  Pointers are device pointers on the context's device. */
+void* pf_dev_alloc(pf_ctx* ctx, size_t bytes);
+void pf_dev_free(pf_ctx* ctx, void* dptr);
+int pf_upload(pf_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int pf_download(pf_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int pf_sync(pf_ctx* ctx);
+
+int pf_flow_bidir_dev(pf_ctx* ctx, const uint8_t* d_l, const uint8_t* d_r, int cols, int rows, int max_percentage,
+                      float* d_flow_l2r, float* d_flow_r2l);
+int pf_blend_dev(pf_ctx* ctx, const uint8_t* d_l, const uint8_t* d_r, const float* d_flow_l2r, const float* d_flow_r2l,
+                 const float* d_blend, int cols, int rows, uint8_t* d_out);
+/* flow + blend; the per-pair unit the benchmark times.  d_flow_* may be NULL (flows stay internal). */
+int pf_novel_view_dev(pf_ctx* ctx, const uint8_t* d_l, const uint8_t* d_r, int cols, int rows, int max_percentage,
+                      const float* d_blend, uint8_t* d_out, float* d_flow_l2r, float* d_flow_r2l);
+
+/* ---- stage-level entry points (host buffers, packed) ---------------------------------------
+ * One per reference step, so that tests can check every HIP kernel family against the oracle in
+ * isolation.  They run the very kernels the entry points above chain together. */
+int pf_stage_preprocess(pf_ctx* ctx, const uint8_t* bgra, int cols, int rows, int pad,
+                        float* gray_half, float* alpha_half);                         /* PixFlow.hpp:78-103 (+ OpticalFlow.cpp:113-126 when pad>0) */
+int pf_stage_pyr_down(pf_ctx* ctx, const float* src, int sw, int sh, float* dst, int dw, int dh);   /* PixFlow.hpp:146-148 */
+int pf_stage_gradients(pf_ctx* ctx, const float* img, int w, int h, float* gxy /* (Ix,Iy) interleaved */); /* PixFlow.hpp:281-294 */
+int pf_stage_gauss(pf_ctx* ctx, const float* src, int w, int h, int cn, int ksize, double sigma, float* dst); /* GaussianBlur call sites */
+int pf_stage_median5(pf_ctx* ctx, const float* flow, int w, int h, float* out);        /* PixFlow.hpp:325,338 */
+int pf_stage_sweep(pf_ctx* ctx, const float* g0xy, const float* g1xy, const float* blurred, const float* alpha0,
+                   const float* alpha1, float* flow_inout, int w, int h, int forward);  /* PixFlow.hpp:315-324 / :328-337 */
+int pf_stage_diffusion(pf_ctx* ctx, const float* alpha0, const float* alpha1, float* flow_inout, int w, int h); /* PixFlow.hpp:388-405 */
+int pf_stage_upsample_cubic(pf_ctx* ctx, const float* flow, int sw, int sh, float* out, int dw, int dh, float scale); /* PixFlow.hpp:122-125 */
+int pf_stage_final(pf_ctx* ctx, const float* flow, int sw, int sh, int pad_cols, int rows, int pad, float scale,
+                   float* out /* (pad_cols-2*pad) x rows */);                          /* PixFlow.hpp:128-134 + OpticalFlow.cpp:143-144 */
+int pf_stage_adjust_initial_flow(pf_ctx* ctx, const float* i0, const float* i1, const float* a0, const float* a1, int w, int h,
+                                 int hint, int max_percentage, float* flow_out);       /* PixFlow.hpp:226-270 */
+int pf_stage_level(pf_ctx* ctx, const float* i0, const float* i1, const float* a0, const float* a1, int w, int h,
+                   const float* flow_in /* nullable */, int hint, int max_percentage, float* flow_out); /* PixFlow.hpp:272-340 */
+int pf_stage_blend_smooth(pf_ctx* ctx, float* blend_inout, const float* merged_dis, int cols, int rows); /* StitchTool.cpp:130-143 */
+
+/* ---- per-kernel-family timing (HIP events on the streams the kernels run on) ---------------- */
+int pf_profile_enable(pf_ctx* ctx, int on);
+int pf_profile_reset(pf_ctx* ctx);
+int pf_profile_count(pf_ctx* ctx);                                       /* number of kernel families seen */
+int pf_profile_get(pf_ctx* ctx, int idx, char* name, int name_cap, double* total_ms, int* launches);
+/* algorithmic HBM bytes of one pf_novel_view on cols x rows (SURVEY.md section 8(d) model) */
+double pf_algorithmic_bytes(int cols, int rows);
+long long pf_level_pixels(int cols, int rows, int* n_levels, long long* sweep_steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANOFLOW_H_ */

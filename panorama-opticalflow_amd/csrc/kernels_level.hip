@@ -1,0 +1,233 @@
+// Per-level kernels of PixFlow::patchMatchPropagationAndSearch (CPU/PixFlow.hpp:272-340) except the
+// sweeps, plus the inter-level and final upsampling (:122-134).  All stencil/streaming, HBM-bound.
+#include "pf_common.hpp"
+
+namespace pf {
+
+// ------------------------------------------------------------------------------------------------
+// K3 gradients: Sobel(ksize=1) central difference with BORDER_REPLICATE, then Gaussian 3x3 s0.5 with
+// BORDER_REFLECT_101 (PixFlow.hpp:281-294).  Output interleaved (Ix,Iy) so the sweep's bilinear
+// gather fetches both with one 8-byte load per texel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gradients(const float* __restrict__ img, int w, int h, float2* __restrict__ gxy, Gauss g) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const float k0 = g.k[1], k1 = g.k[2];
+  const int xm = d_reflect101(x - 1, w), xp = d_reflect101(x + 1, w);
+  const int xs[3] = {xm, x, xp};
+  float tx[3], ty[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int yy = d_reflect101(y - 1 + j, h);
+    const float* r = img + size_t(yy) * w;
+    const float* ru = img + size_t(d_replicate(yy - 1, h)) * w;
+    const float* rd = img + size_t(d_replicate(yy + 1, h)) * w;
+    float sx[3], sy[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int xx = xs[i];
+      sx[i] = r[d_replicate(xx + 1, w)] - r[d_replicate(xx - 1, w)];
+      sy[i] = rd[xx] - ru[xx];
+    }
+    tx[j] = sx[1] * k0 + (sx[0] + sx[2]) * k1;
+    ty[j] = sy[1] * k0 + (sy[0] + sy[2]) * k1;
+  }
+  float ox = k0 * tx[1] + 0.0f; ox += k1 * (tx[2] + tx[0]);
+  float oy = k0 * ty[1] + 0.0f; oy += k1 * (ty[2] + ty[0]);
+  gxy[size_t(y) * w + x] = make_float2(ox, oy);
+}
+void launch_gradients(hipStream_t st, const float* img, int w, int h, float* gxy, const Gauss& g3) {
+  dim3 grid((w + 255) / 256, h);
+  hipLaunchKernelGGL(k_gradients, grid, dim3(256), 0, st, img, w, h, reinterpret_cast<float2*>(gxy), g3);
+}
+
+// update gate of the sweeps (PixFlow.hpp:317,330): alpha0 > 0.9 && alpha1 > 0.9
+__global__ __launch_bounds__(256) void k_gate(const float* __restrict__ a0, const float* __restrict__ a1, int n, uint8_t* __restrict__ gate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) gate[i] = (a0[i] > kUpdateAlphaThreshold && a1[i] > kUpdateAlphaThreshold) ? 1 : 0;
+}
+void launch_gate(hipStream_t st, const float* a0, const float* a1, int n, uint8_t* gate) {
+  hipLaunchKernelGGL(k_gate, dim3((n + 255) / 256), dim3(256), 0, st, a0, a1, n, gate);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 Gaussian 15x15 s8 on the float2 flow, BORDER_REFLECT_101 (PixFlow.hpp:306-311, :389-394).
+// [OpenCV filter.cpp] row pass = RowFilter (plain left-to-right accumulation), column pass =
+// SymmColumnFilter (centre, then symmetric pairs outward).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gauss15_row(const float2* __restrict__ src, float2* __restrict__ tmp, int w, int h, Gauss g) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const float2* r = src + size_t(y) * w;
+  float2 v = r[d_reflect101(x - 7, w)];
+  float sx = g.k[0] * v.x, sy = g.k[0] * v.y;
+#pragma unroll
+  for (int j = 1; j < 15; ++j) {
+    v = r[d_reflect101(x - 7 + j, w)];
+    sx += g.k[j] * v.x; sy += g.k[j] * v.y;
+  }
+  tmp[size_t(y) * w + x] = make_float2(sx, sy);
+}
+__device__ __forceinline__ float2 d_gauss15_col(const float2* __restrict__ tmp, int w, int h, int x, int y, const Gauss& g) {
+  float2 c = tmp[size_t(y) * w + x];
+  float sx = g.k[7] * c.x + 0.0f, sy = g.k[7] * c.y + 0.0f;
+#pragma unroll
+  for (int j = 1; j <= 7; ++j) {
+    const float2 a = tmp[size_t(d_reflect101(y + j, h)) * w + x], b = tmp[size_t(d_reflect101(y - j, h)) * w + x];
+    sx += g.k[7 + j] * (a.x + b.x); sy += g.k[7 + j] * (a.y + b.y);
+  }
+  return make_float2(sx, sy);
+}
+__global__ __launch_bounds__(256) void k_gauss15_col(const float2* __restrict__ tmp, float2* __restrict__ dst, int w, int h, Gauss g) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  dst[size_t(y) * w + x] = d_gauss15_col(tmp, w, h, x, y, g);
+}
+void launch_gauss15(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const Gauss& g15) {
+  dim3 grid((w + 255) / 256, h);
+  hipLaunchKernelGGL(k_gauss15_row, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(tmp), w, h, g15);
+  hipLaunchKernelGGL(k_gauss15_col, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(tmp), reinterpret_cast<float2*>(dst), w, h, g15);
+}
+
+// K8 lowAlphaFlowDiffusion (PixFlow.hpp:388-405): column pass fused with the alpha mix.
+__global__ __launch_bounds__(256) void k_gauss15_col_mix(const float2* __restrict__ tmp, const float2* __restrict__ flow, const float* __restrict__ a0,
+                                                         const float* __restrict__ a1, float2* __restrict__ out, int w, int h, Gauss g) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const size_t i = size_t(y) * w + x;
+  const float2 b = d_gauss15_col(tmp, w, h, x, y, g);
+  const float2 f = flow[i];
+  const float diffusionCoef = 1.0f - a0[i] * a1[i];
+  out[i] = make_float2(diffusionCoef * b.x + (1.0f - diffusionCoef) * f.x, diffusionCoef * b.y + (1.0f - diffusionCoef) * f.y);
+}
+void launch_gauss15_mix(hipStream_t st, float* flow, float* tmp, const float* a0, const float* a1, int w, int h, const Gauss& g15, float* out) {
+  dim3 grid((w + 255) / 256, h);
+  hipLaunchKernelGGL(k_gauss15_row, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(flow), reinterpret_cast<float2*>(tmp), w, h, g15);
+  hipLaunchKernelGGL(k_gauss15_col_mix, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(tmp), reinterpret_cast<const float2*>(flow), a0, a1,
+                     reinterpret_cast<float2*>(out), w, h, g15);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7 medianBlur(5) on float2, per channel, BORDER_REPLICATE, out of place (PixFlow.hpp:325,338).
+// Exact selection by "forgetful selection": keep a pool of n/2+2 candidates, drop its min and max,
+// add the next element; the survivor of the last 3 is the median.  All in registers.
+// ------------------------------------------------------------------------------------------------
+#define PF_CE(a, b) { const float lo_ = __builtin_fminf(a, b); const float hi_ = __builtin_fmaxf(a, b); a = lo_; b = hi_; }
+template <int N>
+__device__ __forceinline__ void d_minmax(float* v) {  // afterwards v[0] = min, v[N-1] = max of v[0..N-1]
+#pragma unroll
+  for (int i = 0; i + 1 < N; i += 2) PF_CE(v[i], v[i + 1]);
+#pragma unroll
+  for (int i = 2; i < N; i += 2) PF_CE(v[0], v[i]);
+#pragma unroll
+  for (int i = 1; i < N - 1; i += 2) PF_CE(v[i], v[N - 1]);
+}
+__device__ __forceinline__ float d_median25(float* v) {
+  d_minmax<14>(v); v[0] = v[14];
+  d_minmax<13>(v); v[0] = v[15];
+  d_minmax<12>(v); v[0] = v[16];
+  d_minmax<11>(v); v[0] = v[17];
+  d_minmax<10>(v); v[0] = v[18];
+  d_minmax<9>(v); v[0] = v[19];
+  d_minmax<8>(v); v[0] = v[20];
+  d_minmax<7>(v); v[0] = v[21];
+  d_minmax<6>(v); v[0] = v[22];
+  d_minmax<5>(v); v[0] = v[23];
+  d_minmax<4>(v); v[0] = v[24];
+  d_minmax<3>(v);
+  return v[1];
+}
+__global__ __launch_bounds__(256) void k_median5(const float2* __restrict__ src, float2* __restrict__ dst, int w, int h) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  float vx[25], vy[25];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const float2* r = src + size_t(d_replicate(y + j - 2, h)) * w;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const float2 p = r[d_replicate(x + i - 2, w)];
+      vx[j * 5 + i] = p.x; vy[j * 5 + i] = p.y;
+    }
+  }
+  const float mx = d_median25(vx);
+  const float my = d_median25(vy);
+  dst[size_t(y) * w + x] = make_float2(mx, my);
+}
+void launch_median5(hipStream_t st, const float* src, float* dst, int w, int h) {
+  dim3 grid((w + 255) / 256, h);
+  hipLaunchKernelGGL(k_median5, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9 inter-level upsample: resize INTER_CUBIC on float2 then *= 1/0.9f (PixFlow.hpp:122-125).
+// [OpenCV imgwarp.cpp] HResizeCubic (taps clamped to the row) then VResizeCubic (rows clipped).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_upsample_cubic(const float2* __restrict__ src, int sw, int sh, float2* __restrict__ dst, int dw, int dh,
+                                                        double scale_x, double scale_y, float mul) {
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
+  if (dx >= dw) return;
+  int sx, sy; float fx, fy;
+  d_src_coord(dx, scale_x, sx, fx);
+  d_src_coord(dy, scale_y, sy, fy);
+  float a[4], b[4];
+  d_cubic_coeffs(fx, a);
+  d_cubic_coeffs(fy, b);
+  const int x0 = d_replicate(sx - 1, sw), x1 = d_replicate(sx, sw), x2 = d_replicate(sx + 1, sw), x3 = d_replicate(sx + 2, sw);
+  float hx[4], hy[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float2* r = src + size_t(d_replicate(sy - 1 + j, sh)) * sw;
+    const float2 p0 = r[x0], p1 = r[x1], p2 = r[x2], p3 = r[x3];
+    hx[j] = p0.x * a[0] + p1.x * a[1] + p2.x * a[2] + p3.x * a[3];
+    hy[j] = p0.y * a[0] + p1.y * a[1] + p2.y * a[2] + p3.y * a[3];
+  }
+  const float ox = hx[0] * b[0] + hx[1] * b[1] + hx[2] * b[2] + hx[3] * b[3];
+  const float oy = hy[0] * b[0] + hy[1] * b[1] + hy[2] * b[2] + hy[3] * b[3];
+  dst[size_t(dy) * dw + dx] = make_float2(ox * mul + 0.0f, oy * mul + 0.0f);
+}
+void launch_upsample_cubic(hipStream_t st, const float* src, int sw, int sh, float* dst, int dw, int dh, float mul) {
+  const double sx = 1. / ((double)dw / sw), sy = 1. / ((double)dh / sh);
+  dim3 grid((dw + 255) / 256, dh);
+  hipLaunchKernelGGL(k_upsample_cubic, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), sw, sh, reinterpret_cast<float2*>(dst), dw, dh, sx,
+                     sy, mul);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K10 final: resize INTER_LINEAR to the padded full-res size, *= 1/0.5f, GaussianBlur 3x3 s1.0
+// (PixFlow.hpp:128-134), then crop `pad` columns each side (OpticalFlow.cpp:143-144).  Fused: each
+// output evaluates the 3x3 neighbourhood of the (virtual) upsampled image.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_final_flow(const float* __restrict__ flow0, int sw, int sh, int pad_cols, int rows, int pad, double scale_x,
+                                                    double scale_y, float mul, Gauss g, float2* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  const int cols = pad_cols - 2 * pad;
+  if (x >= cols) return;
+  const float k0 = g.k[1], k1 = g.k[2];
+  float tx[3], ty[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int yy = d_reflect101(y - 1 + j, rows);
+    float ux[3], uy[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int xx = d_reflect101(x + pad - 1 + i, pad_cols);
+      float v[2];
+      d_resize_linear_px<2>(flow0, sw, sh, pad_cols, rows, scale_x, scale_y, xx, yy, v);
+      ux[i] = v[0] * mul + 0.0f; uy[i] = v[1] * mul + 0.0f;
+    }
+    tx[j] = ux[1] * k0 + (ux[0] + ux[2]) * k1;
+    ty[j] = uy[1] * k0 + (uy[0] + uy[2]) * k1;
+  }
+  float ox = k0 * tx[1] + 0.0f; ox += k1 * (tx[2] + tx[0]);
+  float oy = k0 * ty[1] + 0.0f; oy += k1 * (ty[2] + ty[0]);
+  out[size_t(y) * cols + x] = make_float2(ox, oy);
+}
+void launch_final_flow(hipStream_t st, const float* flow0, int sw, int sh, int pad_cols, int rows, int pad, float mul, const Gauss& g3, float* out) {
+  const double sx = 1. / ((double)pad_cols / sw), sy = 1. / ((double)rows / sh);
+  const int cols = pad_cols - 2 * pad;
+  dim3 grid((cols + 255) / 256, rows);
+  hipLaunchKernelGGL(k_final_flow, grid, dim3(256), 0, st, flow0, sw, sh, pad_cols, rows, pad, sx, sy, mul, g3, reinterpret_cast<float2*>(out));
+}
+
+}  // namespace pf

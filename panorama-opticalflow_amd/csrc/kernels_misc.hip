@@ -1,0 +1,352 @@
+// K4 coarsest-level search (CPU/PixFlow.hpp:153-270), K11 novel-view blend (CPU/OpticalFlow.cpp:9-92),
+// K12-K15 StitchTool kernels (CPU/StitchTool.cpp).
+#include "pf_common.hpp"
+
+namespace pf {
+
+// ------------------------------------------------------------------------------------------------
+// K4.  computeIntensityRatio (PixFlow.hpp:190-205) is a sequential fp32 accumulation in row-major
+// order; the coarsest level has <= a few thousand pixels, so one lane adds them in that order (the
+// products are staged through LDS by the whole block so the serial part only reads LDS).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_intensity_ratio(const float* __restrict__ i0, const float* __restrict__ i1, const float* __restrict__ a0,
+                                                         const float* __restrict__ a1, int n, float* __restrict__ ratio) {
+  __shared__ float pl[1024], pr[1024];
+  float sumL = 0.f, sumR = 0.f;
+  for (int base = 0; base < n; base += 1024) {
+    for (int i = threadIdx.x; i < 1024 && base + i < n; i += blockDim.x) {
+      const float alpha = a0[base + i] * a1[base + i];
+      pl[i] = alpha * i0[base + i];
+      pr[i] = alpha * i1[base + i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int m = (n - base) < 1024 ? (n - base) : 1024;
+      for (int i = 0; i < m; ++i) { sumL += pl[i]; sumR += pr[i]; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *ratio = sumL / sumR;
+}
+
+// computePatchError (PixFlow.hpp:157-188); I1 is equalised on the fly: I1eq = I1*ratio + 0 ([OpenCV] Mat*scalar)
+__device__ __forceinline__ float d_patch_error(const float* __restrict__ i0, const float* __restrict__ a0, int i0x, int i0y, const float* __restrict__ i1,
+                                               const float* __restrict__ a1, int i1x, int i1y, int w, int h, float ratio, int dist) {
+  float sad = 0.f, alpha = 0.f;
+  for (int dy = -2; dy <= 2; ++dy) {
+    const int d0y = i0y + dy;
+    if (0 <= d0y && d0y < h) {
+      const int d1y = d_replicate(i1y + dy, h);
+      for (int dx = -2; dx <= 2; ++dx) {
+        const int d0x = i0x + dx;
+        if (0 <= d0x && d0x < w) {
+          const int d1x = d_replicate(i1x + dx, w);
+          const float i1eq = i1[size_t(d1y) * w + d1x] * ratio + 0.0f;
+          const float difference = i0[size_t(d0y) * w + d0x] - i1eq;
+          sad += fabsf(difference);
+          alpha += a0[size_t(d0y) * w + d0x] * a1[size_t(d1y) * w + d1x];
+        }
+      }
+    }
+  }
+  sad /= alpha;
+  const float fx = float(i1x - i0x), fy = float(i1y - i0y);
+  const float length = (float)sqrt((double)fx * fx + (double)fy * fy);
+  sad *= 1 + length / dist;
+  return sad;
+}
+
+// adjustInitialFlow (PixFlow.hpp:226-270)
+__global__ __launch_bounds__(64) void k_adjust_initial_flow(const float* __restrict__ i0, const float* __restrict__ i1, const float* __restrict__ a0,
+                                                            const float* __restrict__ a1, int w, int h, int bx, int by, int bw, int bh, int dist,
+                                                            const float* __restrict__ ratio_p, float2* __restrict__ flow) {
+  const int i0x = blockIdx.x * blockDim.x + threadIdx.x, i0y = blockIdx.y;
+  if (i0x >= w) return;
+  if (!(a0[size_t(i0y) * w + i0x] > kUpdateAlphaThreshold)) return;
+  const float ratio = *ratio_p;
+  const float kFraction = 0.8f;
+  float errorBest = kFraction * d_patch_error(i0, a0, i0x, i0y, i1, a1, i0x, i0y, w, h, ratio, dist);
+  int i1xBest = i0x, i1yBest = i0y;
+  for (int dy = by; dy < by + bh; ++dy)
+    for (int dx = bx; dx < bx + bw; ++dx) {
+      const int i1x = i0x + dx, i1y = i0y + dy;
+      if (0 <= i1x && i1x < w && 0 <= i1y && i1y < h) {
+        const float error = d_patch_error(i0, a0, i0x, i0y, i1, a1, i1x, i1y, w, h, ratio, dist);
+        if (errorBest > error) { errorBest = error; i1xBest = i1x; i1yBest = i1y; }
+      }
+    }
+  flow[size_t(i0y) * w + i0x] = make_float2(float(i1xBest - i0x), float(i1yBest - i0y));
+}
+
+// `flow` must be zero-filled by the caller (PixFlow.hpp:298).  i1eq_tmp: >= 1 float of scratch (the ratio).
+void launch_adjust_initial_flow(hipStream_t st, const float* i0, const float* i1, const float* a0, const float* a1, int w, int h, int hint,
+                                int max_pct, float* ratio_tmp, float* flow) {
+  const int dist = (kPyrMinImageSize * max_pct + 50) / 100;  // computeSearchDistance, PixFlow.hpp:153-155
+  const int kRatio = 8, ortho = (dist + kRatio / 2) / kRatio, thickness = 2 * ortho + 1;
+  int bx, by, bw, bh;  // computeSearchBox, PixFlow.hpp:207-224
+  switch (hint) {
+    case 1: bx = 0; by = -ortho; bw = dist + 1; bh = thickness; break;       // RIGHT
+    case 2: bx = -ortho; by = 0; bw = thickness; bh = dist + 1; break;       // DOWN
+    case 3: bx = -dist; by = -ortho; bw = dist + 1; bh = thickness; break;   // LEFT
+    case 4: bx = -ortho; by = -dist; bw = thickness; bh = dist + 1; break;   // UP
+    default: return;
+  }
+  hipLaunchKernelGGL(k_intensity_ratio, dim3(1), dim3(256), 0, st, i0, i1, a0, a1, w * h, ratio_tmp);
+  dim3 grid((w + 63) / 64, h);
+  hipLaunchKernelGGL(k_adjust_initial_flow, grid, dim3(64), 0, st, i0, i1, a0, a1, w, h, bx, by, bw, bh, dist, ratio_tmp,
+                     reinterpret_cast<float2*>(flow));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K11 combineNovelViews (OpticalFlow.cpp:30-92).  Streaming: 36 B/pixel + two dependent 4-byte gathers.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uchar4 d_novel_view_point(const uchar4* __restrict__ src, float2 flowDir, double t, int x, int y, int cols, int rows) {
+  int srcx = int(x + flowDir.x * t);  // fp64, truncation toward zero (OpticalFlow.cpp:17)
+  if (srcx > cols - 1) srcx = srcx - cols;
+  if (srcx < 0) srcx = srcx + cols;
+  srcx %= cols; if (srcx < 0) srcx += cols;  // latent single-wrap hazard defined as a true modulo
+  int srcy = int(y + flowDir.y * t);
+  if (srcy > rows - 1) srcy = rows - 1;
+  if (srcy < 0) srcy = 0;
+  return src[size_t(srcy) * cols + srcx];
+}
+__device__ __forceinline__ float d_lerp(float x0, float x1, float alpha) { return x0 * (1.0f - alpha) + x1 * alpha; }  // util.hpp:93-101
+
+__global__ __launch_bounds__(256) void k_blend(const uchar4* __restrict__ L, const uchar4* __restrict__ R, const float2* __restrict__ flowLR,
+                                               const float2* __restrict__ flowRL, const float* __restrict__ blend, int cols, int rows,
+                                               uchar4* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= cols) return;
+  const size_t i = size_t(y) * cols + x;
+  const float blendR = blend[i], blendL = 1 - blendR;
+  const float2 fLR = flowLR[i], fRL = flowRL[i];
+  const uchar4 colorL = d_novel_view_point(L, fRL, (double)blendR, x, y, cols, rows);
+  const uchar4 colorR = d_novel_view_point(R, fLR, (double)blendL, x, y, cols, rows);
+  uchar4 o;
+  if (colorL.w == 0 || colorR.w == 0) {
+    o = make_uchar4(0, 0, 0, 0);
+  } else {
+    const float kColorDiffCoef = 10.0f, kSoftmaxSharpness = 10.0f, kFlowMagCoef = 100.0f;
+    const float flowMagLR = sqrtf(fLR.x * fLR.x + fLR.y * fLR.y) / float(cols);
+    const float flowMagRL = sqrtf(fRL.x * fRL.x + fRL.y * fRL.y) / float(cols);
+    const float colorDiff = (abs(int(colorL.x) - int(colorR.x)) + abs(int(colorL.y) - int(colorR.y)) + abs(int(colorL.z) - int(colorR.z))) / 255.0f;
+    const float deghostCoef = tanhf(colorDiff * kColorDiffCoef);
+    const float alphaL = colorL.w / 255.0f, alphaR = colorR.w / 255.0f;
+    const double expL = exp(kSoftmaxSharpness * blendL * alphaL * (1.0 + kFlowMagCoef * flowMagRL));
+    const double expR = exp(kSoftmaxSharpness * blendR * alphaR * (1.0 + kFlowMagCoef * flowMagLR));
+    const double sumExp = expL + expR + 0.00001;
+    const float softmaxL = float(expL / sumExp), softmaxR = float(expR / sumExp);
+    const float wL = d_lerp(blendL, softmaxL, deghostCoef), wR = d_lerp(blendR, softmaxR, deghostCoef);
+    o.x = (unsigned char)(int)(float(colorL.x) * wL + float(colorR.x) * wR);
+    o.y = (unsigned char)(int)(float(colorL.y) * wL + float(colorR.y) * wR);
+    o.z = (unsigned char)(int)(float(colorL.z) * wL + float(colorR.z) * wR);
+    o.w = 255;
+  }
+  out[i] = o;
+}
+void launch_blend(hipStream_t st, const uint8_t* L, const uint8_t* R, const float* flowLR, const float* flowRL, const float* blend, int cols,
+                  int rows, uint8_t* out) {
+  dim3 grid((cols + 255) / 256, rows);
+  hipLaunchKernelGGL(k_blend, grid, dim3(256), 0, st, reinterpret_cast<const uchar4*>(L), reinterpret_cast<const uchar4*>(R),
+                     reinterpret_cast<const float2*>(flowLR), reinterpret_cast<const float2*>(flowRL), blend, cols, rows, reinterpret_cast<uchar4*>(out));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K12 MatchImages + overlap masking (StitchTool.cpp:17-33, :38-50)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_match_images(const uchar4* __restrict__ L, const uchar4* __restrict__ R, int n, uint8_t* __restrict__ map,
+                                                      uchar4* __restrict__ ovL, uchar4* __restrict__ ovR) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uchar4 l = L[i], r = R[i];
+  const uint8_t m = (uint8_t)((l.w > 0 ? 100 : 0) + (r.w > 0 ? 50 : 0));
+  map[i] = m;
+  const bool ov = m > 140;
+  ovL[i] = ov ? l : make_uchar4(0, 0, 0, 0);
+  ovR[i] = ov ? r : make_uchar4(0, 0, 0, 0);
+}
+void launch_match_images(hipStream_t st, const uint8_t* L, const uint8_t* R, int cols, int rows, uint8_t* map, uint8_t* ovL, uint8_t* ovR) {
+  const int n = cols * rows;
+  hipLaunchKernelGGL(k_match_images, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uchar4*>(L), reinterpret_cast<const uchar4*>(R), n,
+                     map, reinterpret_cast<uchar4*>(ovL), reinterpret_cast<uchar4*>(ovR));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K13 GenerateBlend's per-pixel part + countblend (StitchTool.cpp:98-128, :148-191).  The map extended
+// by cols/5 wrapped columns each side (:102-111) is virtual.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_countblend(const uint8_t* __restrict__ map, int cols, int rows, int length, int step, float* __restrict__ blend,
+                                                    float* __restrict__ mergedDis) {
+  const int x0 = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x0 >= cols) return;
+  const int MW = cols + 2 * length, MH = rows;
+  auto M = [&](int yy, int xe) -> int {
+    int sx = xe - length;
+    if (sx < 0) sx += cols; else if (sx >= cols) sx -= cols;
+    return map[size_t(yy) * cols + sx];
+  };
+  const int x = x0 + length;
+  const int m = M(y, x);
+  float b, md = 0.f;
+  if (m == 100) b = 0;
+  else if (m == 50) b = 1;
+  else if (m == 150) {
+    float minLdis = float(10 * cols), minRdis = float(10 * cols);
+    const double sqrt2 = sqrt(2.0);
+    for (int i = 0; i < cols / 2; i = i + step) {
+      int v;
+      if (x + i < MW) { v = M(y, x + i); if (v == 100 && i < minLdis) minLdis = float(i); if (v == 50 && i < minRdis) minRdis = float(i); }
+      if (x - i > 0) { v = M(y, x - i); if (v == 100 && i < minLdis) minLdis = float(i); if (v == 50 && i < minRdis) minRdis = float(i); }
+      if (y + i < MH) { v = M(y + i, x); if (v == 100 && i < minLdis) minLdis = float(i); if (v == 50 && i < minRdis) minRdis = float(i); }
+      if (y - i > 0) { v = M(y - i, x); if (v == 100 && i < minLdis) minLdis = float(i); if (v == 50 && i < minRdis) minRdis = float(i); }
+      const double di = i * sqrt2;
+      if (x + i < MW && y + i < MH) { v = M(y + i, x + i); if (v == 100 && di < minLdis) minLdis = float(di); if (v == 50 && di < minRdis) minRdis = float(di); }
+      if (x - i > 0 && y - i > 0) { v = M(y - i, x - i); if (v == 100 && di < minLdis) minLdis = float(di); if (v == 50 && di < minRdis) minRdis = float(di); }
+      if (x + i < MW && y - i > 0) { v = M(y - i, x + i); if (v == 100 && di < minLdis) minLdis = float(di); if (v == 50 && di < minRdis) minRdis = float(di); }
+      if (x - i > 0 && y + i < MH) { v = M(y + i, x - i); if (v == 100 && di < minLdis) minLdis = float(di); if (v == 50 && di < minRdis) minRdis = float(di); }
+    }
+    b = minLdis / (minRdis + minLdis);
+    md = minLdis < minRdis ? minLdis : minRdis;
+  } else b = 0.5f;
+  blend[size_t(y) * cols + x0] = b;
+  mergedDis[size_t(y) * cols + x0] = md;
+}
+void launch_countblend(hipStream_t st, const uint8_t* map, int cols, int rows, float* blend, float* mergedDis) {
+  int step = cols <= rows ? cols / 200 : rows / 200;
+  if (step < 1) step = 1;  // reference never terminates for step==0 (inputs < 200 px); defined as 1
+  dim3 grid((cols + 255) / 256, rows);
+  hipLaunchKernelGGL(k_countblend, grid, dim3(256), 0, st, map, cols, rows, cols / 5, step, blend, mergedDis);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K14 blend-ramp smoothing (StitchTool.cpp:130-143).  [OpenCV] blur() on CV_32F = RowSum<float,double>
+// + ColumnSum<double,float>: sliding sums in double, anchor k/2, BORDER_REFLECT_101 w.r.t. the whole
+// image.  The sliding sums are order-dependent along a row/column, so one lane walks each row (row
+// pass) and each column (column pass) -- exactly the O(1)/pixel schedule one wants anyway.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_box_rows(const float* __restrict__ src, double* __restrict__ rs, int cols, int rows, int k) {
+  const int y = blockIdx.x * blockDim.x + threadIdx.x;
+  if (y >= rows) return;
+  const int a = k / 2;
+  const float* r = src + size_t(y) * cols;
+  double s = 0;
+  for (int i = 0; i < k; ++i) s += (double)r[d_reflect101(-a + i, cols)];
+  rs[size_t(y) * cols] = s;
+  for (int x = 1; x < cols; ++x) {
+    s += (double)r[d_reflect101(x - a - 1 + k, cols)] - (double)r[d_reflect101(x - a - 1, cols)];
+    rs[size_t(y) * cols + x] = s;
+  }
+}
+__global__ __launch_bounds__(64) void k_box_cols(const double* __restrict__ rs, float* __restrict__ dst, int cols, int rows, int k) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= cols) return;
+  const int a = k / 2;
+  const double scale = 1. / ((double)k * k);
+  double sum = 0;
+  for (int j = 0; j < k - 1; ++j) sum += rs[size_t(d_reflect101(-a + j, rows)) * cols + x];
+  for (int y = 0; y < rows; ++y) {
+    const double s0 = sum + rs[size_t(d_reflect101(y - a + k - 1, rows)) * cols + x];
+    dst[size_t(y) * cols + x] = (float)(s0 * scale);
+    sum = s0 - rs[size_t(d_reflect101(y - a, rows)) * cols + x];
+  }
+}
+void launch_box_blur(hipStream_t st, const float* src, float* dst, double* rowsum_tmp, int cols, int rows, int k) {
+  hipLaunchKernelGGL(k_box_rows, dim3((rows + 63) / 64), dim3(64), 0, st, src, rowsum_tmp, cols, rows, k);
+  hipLaunchKernelGGL(k_box_cols, dim3((cols + 63) / 64), dim3(64), 0, st, rowsum_tmp, dst, cols, rows, k);
+}
+
+// Conditional per-tile box blur, in place, raster order (StitchTool.cpp:134-141).  A tile reads the
+// CURRENT image in a (step+k-1)^2 window, so it depends on raster-earlier tiles within d =
+// ceil(max(a, k-1-a)/step) tiles and must precede raster-later ones in that range.  Tiles with equal
+// t = tx + (d+1)*ty are mutually independent: one launch per t (a wavefront over tiles) is exact.
+__global__ __launch_bounds__(64) void k_tile_blur(float* __restrict__ img, const float* __restrict__ mergedDis, int cols, int rows, int step, int k,
+                                                  int t, int dskew, int ntx, int nty) {
+  // tile on this diagonal: ty = blockIdx.x + ty0, tx = t - dskew*ty
+  const int ty_min = (t - (ntx - 1) + dskew - 1) / dskew > 0 ? (t - (ntx - 1) + dskew - 1) / dskew : 0;
+  const int ty = ty_min + blockIdx.x;
+  if (ty >= nty) return;
+  const int tx = t - dskew * ty;
+  if (tx < 0 || tx >= ntx) return;
+  const int x0 = tx * step, y0 = ty * step;
+  if (!(mergedDis[size_t(y0) * cols + x0] > step)) return;
+  extern __shared__ double sm[];  // row sums: (step+k-1) x step
+  const int a = k / 2, nr = step + k - 1;
+  for (int j = threadIdx.x; j < nr; j += blockDim.x) {
+    const float* r = img + size_t(d_reflect101(y0 - a + j, rows)) * cols;
+    double s = 0;
+    for (int i = 0; i < k; ++i) s += (double)r[d_reflect101(x0 - a + i, cols)];
+    sm[j * step] = s;
+    for (int x = 1; x < step; ++x) {
+      s += (double)r[d_reflect101(x0 - a + x - 1 + k, cols)] - (double)r[d_reflect101(x0 - a + x - 1, cols)];
+      sm[j * step + x] = s;
+    }
+  }
+  __syncthreads();
+  const double scale = 1. / ((double)k * k);
+  for (int x = threadIdx.x; x < step; x += blockDim.x) {
+    double sum = 0;
+    for (int j = 0; j < k - 1; ++j) sum += sm[j * step + x];
+    for (int y = 0; y < step; ++y) {
+      const double s0 = sum + sm[(y + k - 1) * step + x];
+      img[size_t(y0 + y) * cols + x0 + x] = (float)(s0 * scale);
+      sum = s0 - sm[y * step + x];
+    }
+  }
+}
+void launch_tile_blur(hipStream_t st, float* blend, const float* mergedDis, int cols, int rows, int step, int k) {
+  if (step < 1 || k < 1) return;
+  // tiles: y = 0, step, ... while y+step < rows  (StitchTool.cpp:134-135)
+  int nty = 0, ntx = 0;
+  for (int y = 0; y + step < rows; y += step) ++nty;
+  for (int x = 0; x + step < cols; x += step) ++ntx;
+  if (nty <= 0 || ntx <= 0) return;
+  const int a = k / 2, reach = a > (k - 1 - a) ? a : (k - 1 - a);
+  const int d = (reach + step - 1) / step, dskew = d + 1;
+  const size_t shmem = size_t(step + k - 1) * step * sizeof(double);
+  const int tmax = (ntx - 1) + dskew * (nty - 1);
+  for (int t = 0; t <= tmax; ++t) {
+    const int ty_min = (t - (ntx - 1) + dskew - 1) / dskew > 0 ? (t - (ntx - 1) + dskew - 1) / dskew : 0;
+    const int ty_max = t / dskew < nty - 1 ? t / dskew : nty - 1;
+    if (ty_max < ty_min) continue;
+    hipLaunchKernelGGL(k_tile_blur, dim3(ty_max - ty_min + 1), dim3(64), shmem, st, blend, mergedDis, cols, rows, step, k, t, dskew, ntx, nty);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K15 Gather (StitchTool.cpp:52-96).  Out-of-range probes (latent OOB reads) are defined as "no match".
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather(const uchar4* __restrict__ L, const uchar4* __restrict__ R, const uchar4* __restrict__ merged,
+                                                const uint8_t* __restrict__ map, int cols, int rows, uchar4* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= cols) return;
+  auto M = [&](int yy, int xx) -> int {
+    if (xx < 0 || xx >= cols || yy < 0 || yy >= rows) return -1;
+    const int v = map[size_t(yy) * cols + xx] + (merged[size_t(yy) * cols + xx].w > 0 ? 75 : 0);
+    return v > 255 ? 255 : v;
+  };
+  const size_t i = size_t(y) * cols + x;
+  const int m = M(y, x);
+  uchar4 o = make_uchar4(0, 0, 0, 0);
+  if (m == 100) o = L[i];
+  else if (m == 50) o = R[i];
+  else if (m == 225 || m == 125 || m == 175) o = merged[i];
+  else if (m == 150) {
+    for (int k = 1; k < 100; k++) {
+      const int n0 = M(y, x + k), n1 = M(y, x - k), n2 = M(y + k, x), n3 = M(y - k, x), n4 = M(y - k, x - k), n5 = M(y - k, x + k),
+                n6 = M(y + k, x - k), n7 = M(y + k, x + k);
+      const bool any100 = n0 == 100 || n1 == 100 || n2 == 100 || n3 == 100 || n4 == 100 || n5 == 100 || n6 == 100 || n7 == 100;
+      const bool any50 = n0 == 50 || n1 == 50 || n2 == 50 || n3 == 50 || n4 == 50 || n5 == 50 || n6 == 50 || n7 == 50;
+      if (any100) { o = L[i]; break; }
+      else if (any50) { o = R[i]; break; }
+      else o = make_uchar4(0, 0, 0, 255);
+    }
+  }
+  out[i] = o;
+}
+void launch_gather(hipStream_t st, const uint8_t* L, const uint8_t* R, const uint8_t* merged, const uint8_t* map, int cols, int rows, uint8_t* out) {
+  dim3 grid((cols + 255) / 256, rows);
+  hipLaunchKernelGGL(k_gather, grid, dim3(256), 0, st, reinterpret_cast<const uchar4*>(L), reinterpret_cast<const uchar4*>(R),
+                     reinterpret_cast<const uchar4*>(merged), map, cols, rows, reinterpret_cast<uchar4*>(out));
+}
+
+}  // namespace pf

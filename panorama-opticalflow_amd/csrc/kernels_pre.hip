@@ -1,0 +1,146 @@
+// Pre-processing and resampling kernels:
+//   K1  wrap-pad + 8-bit fixed-point bicubic downscale + BGRA->gray + /255   (CPU/OpticalFlow.cpp:113-126, CPU/PixFlow.hpp:78-100)
+//   K1b small symmetric Gaussian (5x5 s0.25 pre-blur, PixFlow.hpp:102-103)
+//   K2  bilinear 0.9x pyramid step for the 4 planes (PixFlow.hpp:137-151)
+// All are streaming, HBM-bound kernels: one thread per output element, coalesced along x.
+#include "pf_common.hpp"
+
+namespace pf {
+
+__device__ __forceinline__ int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+// [OpenCV imgwarp.cpp] INTER_CUBIC 8UC4: HResizeCubic<uchar,int,short> + VResizeCubic/FixedPtCast<int,uchar,22>.
+// The padded image [last `pad` cols | image | first `pad` cols] is virtual: taps are re-mapped.
+__global__ __launch_bounds__(256) void k_downscale_gray(const uint8_t* __restrict__ bgra, int cols, int rows, int pad, float* __restrict__ gray,
+                                                        float* __restrict__ alpha, int dw, int dh, double scale_x, double scale_y) {
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
+  if (dx >= dw) return;
+  const int ce = cols + 2 * pad;
+  int sx, sy; float fx, fy;
+  d_src_coord(dx, scale_x, sx, fx);
+  d_src_coord(dy, scale_y, sy, fy);
+  float cx[4], cy[4];
+  d_cubic_coeffs(fx, cx);
+  d_cubic_coeffs(fy, cy);
+  int ia[4], ib[4], xs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ia[i] = sat_short(__float2int_rn(cx[i] * 2048.f));
+    ib[i] = sat_short(__float2int_rn(cy[i] * 2048.f));
+    int xp = d_replicate(sx - 1 + i, ce) - pad;
+    if (xp < 0) xp += cols; else if (xp >= cols) xp -= cols;
+    xs[i] = xp;
+  }
+  int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int yy = d_replicate(sy - 1 + j, rows);
+    const uchar4* row = reinterpret_cast<const uchar4*>(bgra) + size_t(yy) * cols;
+    int h[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uchar4 p = row[xs[i]];
+      h[0] += int(p.x) * ia[i]; h[1] += int(p.y) * ia[i]; h[2] += int(p.z) * ia[i]; h[3] += int(p.w) * ia[i];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] += h[c] * ib[j];
+  }
+  int px[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { int v = (acc[c] + (1 << 21)) >> 22; px[c] = v < 0 ? 0 : (v > 255 ? 255 : v); }
+  const int g = (px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + (1 << 13)) >> 14;  // [OpenCV color.cpp] BGRA2GRAY, 8u
+  const float inv255 = (float)(1.0 / 255.0f);
+  gray[size_t(dy) * dw + dx] = float(g) * inv255 + 0.0f;
+  alpha[size_t(dy) * dw + dx] = float(px[3]) * inv255 + 0.0f;
+}
+
+void launch_downscale_gray(hipStream_t st, const uint8_t* bgra, int cols, int rows, int pad, float* gray, float* alpha, int dw, int dh) {
+  const int ce = cols + 2 * pad;
+  const double sx = 1. / ((double)dw / ce), sy = 1. / ((double)dh / rows);
+  dim3 grid((dw + 255) / 256, dh);
+  hipLaunchKernelGGL(k_downscale_gray, grid, dim3(256), 0, st, bgra, cols, rows, pad, gray, alpha, dw, dh, sx, sy);
+}
+
+// [OpenCV filter.cpp] separable symmetric Gaussian, ksize 3 or 5, BORDER_REFLECT_101:
+// row pass SymmRowSmallFilter (centre*k0 + (l+r)*k1 + ...), column pass SymmColumnFilter.
+template <int R, int CN>
+__global__ __launch_bounds__(256) void k_gauss_small(const float* __restrict__ src, float* __restrict__ dst, int w, int h, Gauss g) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  int xi[2 * R + 1];
+#pragma unroll
+  for (int i = -R; i <= R; ++i) xi[i + R] = d_reflect101(x + i, w);
+  const float* kc = &g.k[R];
+#pragma unroll
+  for (int c = 0; c < CN; ++c) {
+    float t[2 * R + 1];
+#pragma unroll
+    for (int j = -R; j <= R; ++j) {
+      const float* row = src + size_t(d_reflect101(y + j, h)) * w * CN;
+      float s = row[xi[R] * CN + c] * kc[0];
+#pragma unroll
+      for (int i = 1; i <= R; ++i) s = s + (row[xi[R - i] * CN + c] + row[xi[R + i] * CN + c]) * kc[i];
+      t[j + R] = s;
+    }
+    float s = kc[0] * t[R] + 0.0f;
+#pragma unroll
+    for (int j = 1; j <= R; ++j) s += kc[j] * (t[R + j] + t[R - j]);
+    dst[(size_t(y) * w + x) * CN + c] = s;
+  }
+}
+
+void launch_gauss_small(hipStream_t st, const float* src, float* dst, int w, int h, int cn, const Gauss& g) {
+  dim3 grid((w + 255) / 256, h);
+  if (g.ksize == 3 && cn == 1) hipLaunchKernelGGL((k_gauss_small<1, 1>), grid, dim3(256), 0, st, src, dst, w, h, g);
+  else if (g.ksize == 3 && cn == 2) hipLaunchKernelGGL((k_gauss_small<1, 2>), grid, dim3(256), 0, st, src, dst, w, h, g);
+  else if (g.ksize == 5 && cn == 1) hipLaunchKernelGGL((k_gauss_small<2, 1>), grid, dim3(256), 0, st, src, dst, w, h, g);
+  else hipLaunchKernelGGL((k_gauss_small<2, 2>), grid, dim3(256), 0, st, src, dst, w, h, g);
+}
+
+template <int CN>
+__global__ __launch_bounds__(256) void k_resize_linear(const float* __restrict__ src, int sw, int sh, float* __restrict__ dst, int dw, int dh,
+                                                       double scale_x, double scale_y, float mul, int do_mul) {
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
+  if (dx >= dw) return;
+  float v[CN];
+  d_resize_linear_px<CN>(src, sw, sh, dw, dh, scale_x, scale_y, dx, dy, v);
+#pragma unroll
+  for (int c = 0; c < CN; ++c) dst[(size_t(dy) * dw + dx) * CN + c] = do_mul ? v[c] * mul + 0.0f : v[c];
+}
+
+void launch_resize_linear(hipStream_t st, const float* src, int sw, int sh, float* dst, int dw, int dh, int cn, float mul, bool do_mul) {
+  const double sx = 1. / ((double)dw / sw), sy = 1. / ((double)dh / sh);
+  dim3 grid((dw + 255) / 256, dh);
+  if (cn == 1) hipLaunchKernelGGL((k_resize_linear<1>), grid, dim3(256), 0, st, src, sw, sh, dst, dw, dh, sx, sy, mul, int(do_mul));
+  else hipLaunchKernelGGL((k_resize_linear<2>), grid, dim3(256), 0, st, src, sw, sh, dst, dw, dh, sx, sy, mul, int(do_mul));
+}
+
+struct Ptr4 { const float* s[4]; float* d[4]; };
+__global__ __launch_bounds__(256) void k_pyr_down4(Ptr4 p, int sw, int sh, int dw, int dh, double scale_x, double scale_y) {
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y, pl = blockIdx.z;
+  if (dx >= dw) return;
+  float v[1];
+  d_resize_linear_px<1>(p.s[pl], sw, sh, dw, dh, scale_x, scale_y, dx, dy, v);
+  p.d[pl][size_t(dy) * dw + dx] = v[0];
+}
+
+void launch_pyr_down4(hipStream_t st, const float* s0, const float* s1, const float* s2, const float* s3, int sw, int sh, float* d0,
+                      float* d1, float* d2, float* d3, int dw, int dh) {
+  Ptr4 p{{s0, s1, s2, s3}, {d0, d1, d2, d3}};
+  const double sx = 1. / ((double)dw / sw), sy = 1. / ((double)dh / sh);
+  dim3 grid((dw + 255) / 256, dh, 4);
+  hipLaunchKernelGGL(k_pyr_down4, grid, dim3(256), 0, st, p, sw, sh, dw, dh, sx, sy);
+}
+
+__global__ void k_fill_u64(unsigned long long* p, size_t n, unsigned long long v) {
+  size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t stride = size_t(gridDim.x) * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+void launch_fill_u64(hipStream_t st, unsigned long long* p, size_t n, unsigned long long v) {
+  if (n == 0) return;
+  const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  hipLaunchKernelGGL(k_fill_u64, dim3(blocks), dim3(256), 0, st, p, n, v);
+}
+
+}  // namespace pf

@@ -1,0 +1,704 @@
+// C-ABI implementation (include/panoflow.h): context, HBM arena, orchestration of the kernel families
+// on HIP streams.  Host code only launches kernels and moves data; all pixel arithmetic is in the
+// kernels_*.hip files.  There is no CPU fallback anywhere in this library.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/panoflow.h"
+#include "pf_common.hpp"
+
+using namespace pf;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct ProfEntry { double ms = 0; int n = 0; };
+struct ProfPending { int id; hipEvent_t a, b; };
+
+}  // namespace
+
+struct pf_ctx {
+  int device = 0;
+  hipStream_t s_main = nullptr, s_dir[2] = {nullptr, nullptr};
+  hipEvent_t ev_pre = nullptr, ev_dir[2] = {nullptr, nullptr};
+  std::string err;
+  std::map<std::string, DevBuf> bufs;  // named grow-only arena: everything a solve needs stays resident
+  Gauss g5, g3_05, g3_1, g15;
+  bool prof = false;
+  std::vector<std::string> prof_names;
+  std::vector<ProfEntry> prof_tot;
+  std::vector<ProfPending> prof_pending;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+int fail(pf_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  if (c) c->err = buf;
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(c, expr)                                                                                   \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) return fail(c, PF_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// [OpenCV smooth.cpp] getGaussianKernel(n, sigma, CV_32F)
+Gauss make_gauss(int n, double sigma) {
+  Gauss g; memset(&g, 0, sizeof g); g.ksize = n;
+  const double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+  const double scale2X = -0.5 / (sigmaX * sigmaX);
+  double sum = 0;
+  for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; g.k[i] = (float)exp(scale2X * x * x); sum += g.k[i]; }
+  sum = 1. / sum;
+  for (int i = 0; i < n; ++i) g.k[i] = (float)(g.k[i] * sum);
+  return g;
+}
+
+void* ensure(pf_ctx* c, const char* name, size_t bytes) {
+  DevBuf& b = c->bufs[name];
+  if (b.cap >= bytes && b.p) return b.p;
+  if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }
+  const size_t cap = (bytes + 255) & ~size_t(255);
+  if (hipMalloc(&b.p, cap) != hipSuccess) { b.p = nullptr; fail(c, PF_ERR_NOMEM, "hipMalloc(%zu) for '%s' failed", cap, name); return nullptr; }
+  b.cap = cap;
+  return b.p;
+}
+
+// ---- profiling: HIP events on the stream each kernel family is launched on ----
+int prof_id(pf_ctx* c, const char* name) {
+  for (size_t i = 0; i < c->prof_names.size(); ++i) if (c->prof_names[i] == name) return (int)i;
+  c->prof_names.push_back(name); c->prof_tot.push_back(ProfEntry());
+  return (int)c->prof_names.size() - 1;
+}
+hipEvent_t prof_event(pf_ctx* c) {
+  if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+  hipEvent_t e; hipEventCreate(&e); return e;
+}
+struct ProfScope {
+  pf_ctx* c; hipStream_t st; ProfPending p; bool on;
+  ProfScope(pf_ctx* c_, hipStream_t st_, const char* name) : c(c_), st(st_), on(c_->prof) {
+    if (!on) return;
+    p.id = prof_id(c, name); p.a = prof_event(c); p.b = prof_event(c);
+    hipEventRecord(p.a, st);
+  }
+  ~ProfScope() { if (on) { hipEventRecord(p.b, st); c->prof_pending.push_back(p); } }
+};
+void prof_collect(pf_ctx* c) {
+  for (auto& p : c->prof_pending) {
+    float ms = 0; hipEventSynchronize(p.b); hipEventElapsedTime(&ms, p.a, p.b);
+    c->prof_tot[p.id].ms += ms; c->prof_tot[p.id].n += 1;
+    c->ev_pool.push_back(p.a); c->ev_pool.push_back(p.b);
+  }
+  c->prof_pending.clear();
+}
+#define PROF(c, st, name) ProfScope prof_scope_##__LINE__(c, st, name)
+
+// ---- pyramid geometry (PixFlow.hpp:137-151) ----
+struct Geometry {
+  int cols, rows, pad, ce, w0, h0, n;
+  std::vector<int> ws, hs;
+  std::vector<size_t> off;  // element offset of each level inside a pyramid plane
+  size_t P;                 // total level pixels (padded to 64 per level)
+  size_t Pexact;
+};
+Geometry make_geometry(int cols, int rows, int pad) {
+  Geometry g; g.cols = cols; g.rows = rows; g.pad = pad; g.ce = cols + 2 * pad;
+  g.w0 = int(g.ce * kDownscaleFactor); g.h0 = int(rows * kDownscaleFactor);
+  g.ws = {g.w0}; g.hs = {g.h0};
+  while ((int)g.ws.size() < kPyrMaxLevels) {
+    const int nw = int(g.ws.back() * kPyrScaleFactor + 0.5f), nh = int(g.hs.back() * kPyrScaleFactor + 0.5f);
+    if (nh <= kPyrMinImageSize || nw <= kPyrMinImageSize) break;
+    g.ws.push_back(nw); g.hs.push_back(nh);
+  }
+  g.n = (int)g.ws.size();
+  size_t o = 0, pe = 0;
+  for (int l = 0; l < g.n; ++l) { g.off.push_back(o); const size_t px = size_t(g.ws[l]) * g.hs[l]; pe += px; o += (px + 63) & ~size_t(63); }
+  g.P = o; g.Pexact = pe;
+  return g;
+}
+
+int check_dims(pf_ctx* c, int cols, int rows, int pad) {
+  if (cols <= 0 || rows <= 0) return fail(c, PF_ERR_ARG, "bad image size %dx%d", cols, rows);
+  const int w0 = int((cols + 2 * pad) * kDownscaleFactor), h0 = int(rows * kDownscaleFactor);
+  if (w0 < 2 || h0 < 2) return fail(c, PF_ERR_ARG, "image %dx%d too small for the half-res solver", cols, rows);
+  if ((double)cols * rows > 2.0e9) return fail(c, PF_ERR_ARG, "image too large");
+  return 0;
+}
+
+// One level of one direction (PixFlow.hpp:272-340, gradients excluded: they are precomputed for all levels).
+// flow_a holds the incoming flow and receives the level's result (flow_b, blurred, tmp are scratch).
+struct LevelBufs { float *flow_a, *flow_b, *blurred, *tmp; };
+void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, const float* a0, const float* a1, const uint8_t* gate, int w, int h,
+               const LevelBufs& b, unsigned long long* bnd_fwd, unsigned long long* bnd_bwd, int* ctrl_fwd, int* ctrl_bwd, float** result) {
+  { PROF(c, st, "gauss15_blurredFlow"); launch_gauss15(st, b.flow_a, b.tmp, b.blurred, w, h, c->g15); }
+  SweepArgs sa;
+  sa.g0 = reinterpret_cast<const float2*>(g0); sa.g1 = reinterpret_cast<const float2*>(g1);
+  sa.blurred = reinterpret_cast<const float2*>(b.blurred); sa.gate = gate; sa.W = w; sa.H = h;
+  { PROF(c, st, "sweep"); sa.flow = reinterpret_cast<float2*>(b.flow_a); sa.boundary = bnd_fwd; sa.ctrl = ctrl_fwd; sa.forward = 1; launch_sweep(st, sa); }
+  { PROF(c, st, "median5"); launch_median5(st, b.flow_a, b.flow_b, w, h); }
+  { PROF(c, st, "sweep"); sa.flow = reinterpret_cast<float2*>(b.flow_b); sa.boundary = bnd_bwd; sa.ctrl = ctrl_bwd; sa.forward = 0; launch_sweep(st, sa); }
+  { PROF(c, st, "median5"); launch_median5(st, b.flow_b, b.flow_a, w, h); }
+  { PROF(c, st, "gauss15_diffusion"); launch_gauss15_mix(st, b.flow_a, b.tmp, a0, a1, w, h, c->g15, b.flow_b); }
+  *result = b.flow_b;
+}
+
+// The whole solver for 1 or 2 directions on device-resident packed BGRA images.
+// dir 0: I0 = img0, I1 = img1, hint0;  dir 1: I0 = img1, I1 = img0, hint1.  out[d]: cols x rows float2 (pad cropped).
+int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int rows, int pad, int max_pct, int ndirs, const int* hints,
+          float* const* d_out) {
+  if (int e = check_dims(c, cols, rows, pad)) return e;
+  if (max_pct < 0 || max_pct > 100) return fail(c, PF_ERR_ARG, "max_percentage %d out of range", max_pct);
+  const Geometry g = make_geometry(cols, rows, pad);
+  const size_t n0 = size_t(g.w0) * g.h0;
+  float* pyrI[2]; float* pyrA[2]; float* grad[2];
+  const char* nI[2] = {"pyrI0", "pyrI1"}; const char* nA[2] = {"pyrA0", "pyrA1"}; const char* nG[2] = {"grad0", "grad1"};
+  for (int i = 0; i < 2; ++i) {
+    pyrI[i] = (float*)ensure(c, nI[i], g.P * 4); pyrA[i] = (float*)ensure(c, nA[i], g.P * 4); grad[i] = (float*)ensure(c, nG[i], g.P * 8);
+    if (!pyrI[i] || !pyrA[i] || !grad[i]) return PF_ERR_NOMEM;
+  }
+  uint8_t* gate = (uint8_t*)ensure(c, "gate", g.P);
+  float* half_tmp = (float*)ensure(c, "half_tmp", n0 * 4);
+  if (!gate || !half_tmp) return PF_ERR_NOMEM;
+  // hand-off rows + control words of every sweep launch of this solve
+  std::vector<size_t> bnd_off(g.n);
+  size_t bnd_total = 0;
+  for (int l = 0; l < g.n; ++l) { bnd_off[l] = bnd_total; bnd_total += size_t(sweep_num_bands(g.hs[l])) * g.ws[l]; }
+  LevelBufs lb[2]; unsigned long long* bnd[2]; int* ctrl[2]; float* ratio[2];
+  const char* nb[2][7] = {{"d0_flow_a", "d0_flow_b", "d0_blurred", "d0_tmp", "d0_bnd", "d0_ctrl", "d0_ratio"},
+                          {"d1_flow_a", "d1_flow_b", "d1_blurred", "d1_tmp", "d1_bnd", "d1_ctrl", "d1_ratio"}};
+  for (int d = 0; d < ndirs; ++d) {
+    lb[d].flow_a = (float*)ensure(c, nb[d][0], n0 * 8); lb[d].flow_b = (float*)ensure(c, nb[d][1], n0 * 8);
+    lb[d].blurred = (float*)ensure(c, nb[d][2], n0 * 8); lb[d].tmp = (float*)ensure(c, nb[d][3], n0 * 8);
+    bnd[d] = (unsigned long long*)ensure(c, nb[d][4], bnd_total * 2 * 8);
+    ctrl[d] = (int*)ensure(c, nb[d][5], size_t(g.n) * 2 * 2 * sizeof(int));
+    ratio[d] = (float*)ensure(c, nb[d][6], 256);
+    if (!lb[d].flow_a || !lb[d].flow_b || !lb[d].blurred || !lb[d].tmp || !bnd[d] || !ctrl[d] || !ratio[d]) return PF_ERR_NOMEM;
+  }
+
+  hipStream_t sm = c->s_main;
+  // --- shared front end on the main stream: half-res planes, pyramids, gradients + gate of ALL levels ---
+  const uint8_t* imgs[2] = {d_img0, d_img1};
+  for (int i = 0; i < 2; ++i) {
+    { PROF(c, sm, "downscale_gray"); launch_downscale_gray(sm, imgs[i], cols, rows, pad, half_tmp, pyrA[i], g.w0, g.h0); }
+    { PROF(c, sm, "preblur5"); launch_gauss_small(sm, half_tmp, pyrI[i], g.w0, g.h0, 1, c->g5); }
+  }
+  for (int l = 1; l < g.n; ++l) {
+    PROF(c, sm, "pyr_down");
+    launch_pyr_down4(sm, pyrI[0] + g.off[l - 1], pyrI[1] + g.off[l - 1], pyrA[0] + g.off[l - 1], pyrA[1] + g.off[l - 1], g.ws[l - 1], g.hs[l - 1],
+                     pyrI[0] + g.off[l], pyrI[1] + g.off[l], pyrA[0] + g.off[l], pyrA[1] + g.off[l], g.ws[l], g.hs[l]);
+  }
+  for (int l = 0; l < g.n; ++l) {
+    PROF(c, sm, "gradients");
+    launch_gradients(sm, pyrI[0] + g.off[l], g.ws[l], g.hs[l], grad[0] + 2 * g.off[l], c->g3_05);
+    launch_gradients(sm, pyrI[1] + g.off[l], g.ws[l], g.hs[l], grad[1] + 2 * g.off[l], c->g3_05);
+    launch_gate(sm, pyrA[0] + g.off[l], pyrA[1] + g.off[l], g.ws[l] * g.hs[l], gate + g.off[l]);
+  }
+  for (int d = 0; d < ndirs; ++d) {
+    PROF(c, sm, "init_handoff");
+    launch_fill_u64(sm, bnd[d], bnd_total * 2, kNotReady);
+    HIPCHK(c, hipMemsetAsync(ctrl[d], 0, size_t(g.n) * 2 * 2 * sizeof(int), sm));
+  }
+  HIPCHK(c, hipEventRecord(c->ev_pre, sm));
+
+  // --- the two directions are independent (OpticalFlow.cpp:130-139): one stream each ---
+  for (int d = 0; d < ndirs; ++d) {
+    hipStream_t st = c->s_dir[d];
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_pre, 0));
+    const int i0 = d, i1 = 1 - d;
+    LevelBufs b = lb[d];
+    for (int level = g.n - 1; level >= 0; --level) {
+      const int w = g.ws[level], h = g.hs[level];
+      const size_t o = g.off[level];
+      if (level == g.n - 1) {
+        HIPCHK(c, hipMemsetAsync(b.flow_a, 0, size_t(w) * h * 8, st));  // PixFlow.hpp:298
+        if (max_pct > 0 && hints[d] != PF_HINT_UNKNOWN) {
+          PROF(c, st, "adjust_initial_flow");
+          launch_adjust_initial_flow(st, pyrI[i0] + o, pyrI[i1] + o, pyrA[i0] + o, pyrA[i1] + o, w, h, hints[d], max_pct, ratio[d], b.flow_a);
+        }
+      }
+      float* res = nullptr;
+      run_level(c, st, grad[i0] + 2 * o, grad[i1] + 2 * o, pyrA[i0] + o, pyrA[i1] + o, gate + o, w, h, b, bnd[d] + bnd_off[level],
+                bnd[d] + bnd_total + bnd_off[level], ctrl[d] + level * 4, ctrl[d] + level * 4 + 2, &res);
+      if (level > 0) {
+        PROF(c, st, "upsample_cubic");
+        launch_upsample_cubic(st, res, w, h, b.flow_a, g.ws[level - 1], g.hs[level - 1], 1.0f / kPyrScaleFactor);
+      } else {
+        PROF(c, st, "final_flow");
+        launch_final_flow(st, res, w, h, g.ce, rows, pad, 1.0f / kDownscaleFactor, c->g3_1, d_out[d]);
+      }
+    }
+    HIPCHK(c, hipEventRecord(c->ev_dir[d], st));
+    HIPCHK(c, hipStreamWaitEvent(sm, c->ev_dir[d], 0));
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// after the main stream has drained: did any sweep band give up?
+int check_sweeps(pf_ctx* c, int cols, int rows, int pad, int ndirs) {
+  const Geometry g = make_geometry(cols, rows, pad);
+  std::vector<int> h(size_t(g.n) * 4);
+  const char* names[2] = {"d0_ctrl", "d1_ctrl"};
+  for (int d = 0; d < ndirs; ++d) {
+    HIPCHK(c, hipMemcpy(h.data(), c->bufs[names[d]].p, h.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int l = 0; l < g.n; ++l)
+      if (h[l * 4 + 1] || h[l * 4 + 3]) return fail(c, PF_ERR_TIMEOUT, "sweep band timed out (dir %d level %d)", d, l);
+  }
+  return 0;
+}
+
+int finish(pf_ctx* c) {
+  HIPCHK(c, hipStreamSynchronize(c->s_main));
+  HIPCHK(c, hipStreamSynchronize(c->s_dir[0]));
+  HIPCHK(c, hipStreamSynchronize(c->s_dir[1]));
+  if (c->prof) prof_collect(c);
+  return 0;
+}
+
+int use(pf_ctx* c) {
+  if (!c) return fail(nullptr, PF_ERR_ARG, "null context");
+  HIPCHK(c, hipSetDevice(c->device));
+  return 0;
+}
+
+int up2d(pf_ctx* c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, int rows) {
+  HIPCHK(c, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, hipMemcpyHostToDevice, c->s_main));
+  return 0;
+}
+int down2d(pf_ctx* c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, int rows) {
+  HIPCHK(c, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, hipMemcpyDeviceToHost, c->s_main));
+  return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int pf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* pf_version(void) { return "panoflow-mi355x r1 (gfx950)"; }
+
+pf_ctx* pf_create(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { fail(nullptr, PF_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)"); return nullptr; }
+  if (device < 0 || device >= n) { fail(nullptr, PF_ERR_ARG, "device %d out of range (0..%d)", device, n - 1); return nullptr; }
+  if (hipSetDevice(device) != hipSuccess) { fail(nullptr, PF_ERR_DEVICE, "hipSetDevice(%d) failed", device); return nullptr; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { fail(nullptr, PF_ERR_DEVICE, "hipGetDeviceProperties failed"); return nullptr; }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { fail(nullptr, PF_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName); return nullptr; }
+  pf_ctx* c = new pf_ctx();
+  c->device = device;
+  bool ok = hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking) == hipSuccess;
+  for (int d = 0; d < 2 && ok; ++d) ok = hipStreamCreateWithFlags(&c->s_dir[d], hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) == hipSuccess;
+  for (int d = 0; d < 2 && ok; ++d) ok = hipEventCreateWithFlags(&c->ev_dir[d], hipEventDisableTiming) == hipSuccess;
+  if (!ok) { fail(nullptr, PF_ERR_DEVICE, "stream/event creation failed"); delete c; return nullptr; }
+  c->g5 = make_gauss(5, 0.25); c->g3_05 = make_gauss(3, 0.5); c->g3_1 = make_gauss(3, 1.0); c->g15 = make_gauss(15, 8.0);
+  return c;
+}
+
+void pf_destroy(pf_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  for (auto& kv : c->bufs) if (kv.second.p) hipFree(kv.second.p);
+  for (auto e : c->ev_pool) hipEventDestroy(e);
+  for (auto& p : c->prof_pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  if (c->ev_pre) hipEventDestroy(c->ev_pre);
+  for (int d = 0; d < 2; ++d) { if (c->ev_dir[d]) hipEventDestroy(c->ev_dir[d]); if (c->s_dir[d]) hipStreamDestroy(c->s_dir[d]); }
+  if (c->s_main) hipStreamDestroy(c->s_main);
+  delete c;
+}
+
+const char* pf_last_error(const pf_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+int pf_max_percentage_by_name(const char* name) {
+  if (name && strcmp(name, "pixflow_low") == 0) return 0;
+  if (name && strcmp(name, "pixflow_search_20") == 0) return 20;
+  return fail(nullptr, PF_ERR_ARG, "unrecognized flow algorithm name: %s", name ? name : "(null)");
+}
+
+// ---- device memory helpers ----
+void* pf_dev_alloc(pf_ctx* c, size_t bytes) {
+  if (use(c)) return nullptr;
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { fail(c, PF_ERR_NOMEM, "hipMalloc(%zu) failed", bytes); return nullptr; }
+  return p;
+}
+void pf_dev_free(pf_ctx* c, void* p) { if (!use(c) && p) hipFree(p); }
+int pf_upload(pf_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (int e = use(c)) return e;
+  HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+int pf_download(pf_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (int e = use(c)) return e;
+  HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+int pf_sync(pf_ctx* c) { if (int e = use(c)) return e; return finish(c); }
+
+// ---- device-resident entry points ----
+int pf_flow_bidir_dev(pf_ctx* c, const uint8_t* d_l, const uint8_t* d_r, int cols, int rows, int max_pct, float* d_l2r, float* d_r2l) {
+  if (int e = use(c)) return e;
+  if (!d_l || !d_r || !d_l2r || !d_r2l) return fail(c, PF_ERR_ARG, "null device pointer");
+  const int hints[2] = {PF_HINT_LEFT, PF_HINT_RIGHT};  // OpticalFlow.cpp:134,139
+  float* outs[2] = {d_l2r, d_r2l};
+  const int pad = cols / 20;                            // OpticalFlow.cpp:113
+  if (int e = solve(c, d_l, d_r, cols, rows, pad, max_pct, 2, hints, outs)) return e;
+  if (int e = finish(c)) return e;
+  return check_sweeps(c, cols, rows, pad, 2);
+}
+
+int pf_blend_dev(pf_ctx* c, const uint8_t* d_l, const uint8_t* d_r, const float* d_l2r, const float* d_r2l, const float* d_blend, int cols,
+                 int rows, uint8_t* d_out) {
+  if (int e = use(c)) return e;
+  if (!d_l || !d_r || !d_l2r || !d_r2l || !d_blend || !d_out || cols <= 0 || rows <= 0) return fail(c, PF_ERR_ARG, "bad argument");
+  { PROF(c, c->s_main, "blend"); launch_blend(c->s_main, d_l, d_r, d_l2r, d_r2l, d_blend, cols, rows, d_out); }
+  HIPCHK(c, hipGetLastError());
+  return finish(c);
+}
+
+int pf_novel_view_dev(pf_ctx* c, const uint8_t* d_l, const uint8_t* d_r, int cols, int rows, int max_pct, const float* d_blend, uint8_t* d_out,
+                      float* d_l2r, float* d_r2l) {
+  if (int e = use(c)) return e;
+  if (!d_l || !d_r || !d_blend || !d_out) return fail(c, PF_ERR_ARG, "null device pointer");
+  if (int e = check_dims(c, cols, rows, cols / 20)) return e;
+  float* f0 = d_l2r ? d_l2r : (float*)ensure(c, "nv_flow_l2r", size_t(cols) * rows * 8);
+  float* f1 = d_r2l ? d_r2l : (float*)ensure(c, "nv_flow_r2l", size_t(cols) * rows * 8);
+  if (!f0 || !f1) return PF_ERR_NOMEM;
+  const int hints[2] = {PF_HINT_LEFT, PF_HINT_RIGHT};
+  float* outs[2] = {f0, f1};
+  const int pad = cols / 20;
+  if (int e = solve(c, d_l, d_r, cols, rows, pad, max_pct, 2, hints, outs)) return e;
+  { PROF(c, c->s_main, "blend"); launch_blend(c->s_main, d_l, d_r, f0, f1, d_blend, cols, rows, d_out); }
+  HIPCHK(c, hipGetLastError());
+  if (int e = finish(c)) return e;
+  return check_sweeps(c, cols, rows, pad, 2);
+}
+
+// ---- host-buffer entry points ----
+int pf_flow(pf_ctx* c, const uint8_t* i0, const uint8_t* i1, int cols, int rows, size_t step, int max_pct, int hint, float* flow, size_t fstep) {
+  if (int e = use(c)) return e;
+  if (!i0 || !i1 || !flow) return fail(c, PF_ERR_ARG, "null pointer");
+  if (int e = check_dims(c, cols, rows, 0)) return e;
+  if (step < size_t(cols) * 4 || fstep < size_t(cols) * 8) return fail(c, PF_ERR_ARG, "row step too small");
+  if (hint < 0 || hint > 4) return fail(c, PF_ERR_ARG, "unexpected direction %d", hint);
+  const size_t ib = size_t(cols) * rows * 4;
+  uint8_t* d0 = (uint8_t*)ensure(c, "h_img0", ib); uint8_t* d1 = (uint8_t*)ensure(c, "h_img1", ib);
+  float* df = (float*)ensure(c, "h_flow0", size_t(cols) * rows * 8);
+  if (!d0 || !d1 || !df) return PF_ERR_NOMEM;
+  if (int e = up2d(c, d0, size_t(cols) * 4, i0, step, size_t(cols) * 4, rows)) return e;
+  if (int e = up2d(c, d1, size_t(cols) * 4, i1, step, size_t(cols) * 4, rows)) return e;
+  const int hints[2] = {hint, hint}; float* outs[2] = {df, nullptr};
+  if (int e = solve(c, d0, d1, cols, rows, 0, max_pct, 1, hints, outs)) return e;
+  if (int e = down2d(c, flow, fstep, df, size_t(cols) * 8, size_t(cols) * 8, rows)) return e;
+  if (int e = finish(c)) return e;
+  return check_sweeps(c, cols, rows, 0, 1);
+}
+
+int pf_novel_view(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int rows, size_t step, int max_pct, const float* blend, size_t bstep,
+                  uint8_t* out, size_t ostep, float* f_l2r, float* f_r2l, size_t fstep) {
+  if (int e = use(c)) return e;
+  if (!l || !r) return fail(c, PF_ERR_ARG, "null pointer");
+  if (int e = check_dims(c, cols, rows, cols / 20)) return e;
+  if (step < size_t(cols) * 4) return fail(c, PF_ERR_ARG, "row step too small");
+  if (out && !blend) return fail(c, PF_ERR_ARG, "blend is required when out_bgra is given");
+  const size_t ib = size_t(cols) * rows * 4, fb = size_t(cols) * rows * 8;
+  uint8_t* dl = (uint8_t*)ensure(c, "h_img0", ib); uint8_t* dr = (uint8_t*)ensure(c, "h_img1", ib);
+  float* d0 = (float*)ensure(c, "h_flow0", fb); float* d1 = (float*)ensure(c, "h_flow1", fb);
+  if (!dl || !dr || !d0 || !d1) return PF_ERR_NOMEM;
+  if (int e = up2d(c, dl, size_t(cols) * 4, l, step, size_t(cols) * 4, rows)) return e;
+  if (int e = up2d(c, dr, size_t(cols) * 4, r, step, size_t(cols) * 4, rows)) return e;
+  const int hints[2] = {PF_HINT_LEFT, PF_HINT_RIGHT}; float* outs[2] = {d0, d1};
+  const int pad = cols / 20;
+  if (int e = solve(c, dl, dr, cols, rows, pad, max_pct, 2, hints, outs)) return e;
+  if (out) {
+    float* db = (float*)ensure(c, "h_blend", size_t(cols) * rows * 4); uint8_t* dout = (uint8_t*)ensure(c, "h_out", ib);
+    if (!db || !dout) return PF_ERR_NOMEM;
+    if (int e = up2d(c, db, size_t(cols) * 4, blend, bstep, size_t(cols) * 4, rows)) return e;
+    { PROF(c, c->s_main, "blend"); launch_blend(c->s_main, dl, dr, d0, d1, db, cols, rows, dout); }
+    if (int e = down2d(c, out, ostep, dout, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
+  }
+  if (f_l2r) if (int e = down2d(c, f_l2r, fstep, d0, size_t(cols) * 8, size_t(cols) * 8, rows)) return e;
+  if (f_r2l) if (int e = down2d(c, f_r2l, fstep, d1, size_t(cols) * 8, size_t(cols) * 8, rows)) return e;
+  if (int e = finish(c)) return e;
+  return check_sweeps(c, cols, rows, pad, 2);
+}
+
+int pf_flow_bidir(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int rows, size_t step, int max_pct, float* f_l2r, float* f_r2l,
+                  size_t fstep) {
+  return pf_novel_view(c, l, r, cols, rows, step, max_pct, nullptr, 0, nullptr, 0, f_l2r, f_r2l, fstep);
+}
+
+int pf_blend(pf_ctx* c, const uint8_t* l, const uint8_t* r, size_t step, const float* f_l2r, const float* f_r2l, size_t fstep, const float* blend,
+             size_t bstep, int cols, int rows, uint8_t* out, size_t ostep) {
+  if (int e = use(c)) return e;
+  if (!l || !r || !f_l2r || !f_r2l || !blend || !out || cols <= 0 || rows <= 0) return fail(c, PF_ERR_ARG, "bad argument");
+  const size_t ib = size_t(cols) * rows * 4, fb = size_t(cols) * rows * 8;
+  uint8_t* dl = (uint8_t*)ensure(c, "h_img0", ib); uint8_t* dr = (uint8_t*)ensure(c, "h_img1", ib); uint8_t* dout = (uint8_t*)ensure(c, "h_out", ib);
+  float* d0 = (float*)ensure(c, "h_flow0", fb); float* d1 = (float*)ensure(c, "h_flow1", fb); float* db = (float*)ensure(c, "h_blend", ib);
+  if (!dl || !dr || !dout || !d0 || !d1 || !db) return PF_ERR_NOMEM;
+  if (int e = up2d(c, dl, size_t(cols) * 4, l, step, size_t(cols) * 4, rows)) return e;
+  if (int e = up2d(c, dr, size_t(cols) * 4, r, step, size_t(cols) * 4, rows)) return e;
+  if (int e = up2d(c, d0, size_t(cols) * 8, f_l2r, fstep, size_t(cols) * 8, rows)) return e;
+  if (int e = up2d(c, d1, size_t(cols) * 8, f_r2l, fstep, size_t(cols) * 8, rows)) return e;
+  if (int e = up2d(c, db, size_t(cols) * 4, blend, bstep, size_t(cols) * 4, rows)) return e;
+  { PROF(c, c->s_main, "blend"); launch_blend(c->s_main, dl, dr, d0, d1, db, cols, rows, dout); }
+  if (int e = down2d(c, out, ostep, dout, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
+  HIPCHK(c, hipGetLastError());
+  return finish(c);
+}
+
+static int blend_smooth_dev(pf_ctx* c, float* d_blend, const float* d_md, int cols, int rows) {
+  const int step = cols <= rows ? cols / 200 : rows / 200, k1 = rows / 130, k2 = rows / 400;
+  hipStream_t sm = c->s_main;
+  if (step > 0 && k1 > 0) { PROF(c, sm, "tile_blur"); launch_tile_blur(sm, d_blend, d_md, cols, rows, step, k1); }
+  if (k2 > 0) {
+    double* rs = (double*)ensure(c, "st_rowsum", size_t(cols) * rows * 8);
+    float* tmp = (float*)ensure(c, "st_blur_tmp", size_t(cols) * rows * 4);
+    if (!rs || !tmp) return PF_ERR_NOMEM;
+    PROF(c, sm, "box_blur");
+    launch_box_blur(sm, d_blend, tmp, rs, cols, rows, k2);
+    HIPCHK(c, hipMemcpyAsync(d_blend, tmp, size_t(cols) * rows * 4, hipMemcpyDeviceToDevice, sm));
+  }
+  return 0;
+}
+
+int pf_stitch_prepare(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int rows, size_t step, uint8_t* map_out, size_t mstep, uint8_t* ovl,
+                      uint8_t* ovr, float* blend_out, size_t bstep, float* merged_dis) {
+  if (int e = use(c)) return e;
+  if (!l || !r || cols <= 0 || rows <= 0 || step < size_t(cols) * 4) return fail(c, PF_ERR_ARG, "bad argument");
+  const size_t n = size_t(cols) * rows;
+  uint8_t* dl = (uint8_t*)ensure(c, "h_img0", n * 4); uint8_t* dr = (uint8_t*)ensure(c, "h_img1", n * 4);
+  uint8_t* dm = (uint8_t*)ensure(c, "st_map", n); uint8_t* dol = (uint8_t*)ensure(c, "st_ovl", n * 4); uint8_t* dor = (uint8_t*)ensure(c, "st_ovr", n * 4);
+  float* db = (float*)ensure(c, "st_blend", n * 4); float* dmd = (float*)ensure(c, "st_md", n * 4);
+  if (!dl || !dr || !dm || !dol || !dor || !db || !dmd) return PF_ERR_NOMEM;
+  hipStream_t sm = c->s_main;
+  if (int e = up2d(c, dl, size_t(cols) * 4, l, step, size_t(cols) * 4, rows)) return e;
+  if (int e = up2d(c, dr, size_t(cols) * 4, r, step, size_t(cols) * 4, rows)) return e;
+  { PROF(c, sm, "match_images"); launch_match_images(sm, dl, dr, cols, rows, dm, dol, dor); }
+  { PROF(c, sm, "countblend"); launch_countblend(sm, dm, cols, rows, db, dmd); }
+  if (int e = blend_smooth_dev(c, db, dmd, cols, rows)) return e;
+  if (map_out) if (int e = down2d(c, map_out, mstep, dm, cols, cols, rows)) return e;
+  if (ovl) if (int e = down2d(c, ovl, step, dol, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
+  if (ovr) if (int e = down2d(c, ovr, step, dor, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
+  if (blend_out) if (int e = down2d(c, blend_out, bstep, db, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
+  if (merged_dis) if (int e = down2d(c, merged_dis, size_t(cols) * 4, dmd, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
+  HIPCHK(c, hipGetLastError());
+  return finish(c);
+}
+
+int pf_stitch_gather(pf_ctx* c, const uint8_t* l, const uint8_t* r, const uint8_t* merged, size_t step, const uint8_t* map, size_t mstep, int cols,
+                     int rows, uint8_t* out, size_t ostep) {
+  if (int e = use(c)) return e;
+  if (!l || !r || !merged || !map || !out || cols <= 0 || rows <= 0) return fail(c, PF_ERR_ARG, "bad argument");
+  const size_t n = size_t(cols) * rows;
+  uint8_t* dl = (uint8_t*)ensure(c, "h_img0", n * 4); uint8_t* dr = (uint8_t*)ensure(c, "h_img1", n * 4); uint8_t* dg = (uint8_t*)ensure(c, "st_merged", n * 4);
+  uint8_t* dm = (uint8_t*)ensure(c, "st_map", n); uint8_t* dout = (uint8_t*)ensure(c, "h_out", n * 4);
+  if (!dl || !dr || !dg || !dm || !dout) return PF_ERR_NOMEM;
+  if (int e = up2d(c, dl, size_t(cols) * 4, l, step, size_t(cols) * 4, rows)) return e;
+  if (int e = up2d(c, dr, size_t(cols) * 4, r, step, size_t(cols) * 4, rows)) return e;
+  if (int e = up2d(c, dg, size_t(cols) * 4, merged, step, size_t(cols) * 4, rows)) return e;
+  if (int e = up2d(c, dm, cols, map, mstep, cols, rows)) return e;
+  { PROF(c, c->s_main, "gather"); launch_gather(c->s_main, dl, dr, dg, dm, cols, rows, dout); }
+  if (int e = down2d(c, out, ostep, dout, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
+  HIPCHK(c, hipGetLastError());
+  return finish(c);
+}
+
+// ---- stage-level entry points (tests) ----
+#define STAGE_BEGIN(c) if (int e_ = use(c)) return e_; hipStream_t sm = c->s_main; (void)sm
+static void* stage_up(pf_ctx* c, const char* name, const void* host, size_t bytes) {
+  void* d = ensure(c, name, bytes);
+  if (d && host) hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, c->s_main);
+  return d;
+}
+static int stage_down(pf_ctx* c, void* host, const void* dev, size_t bytes) {
+  HIPCHK(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->s_main));
+  HIPCHK(c, hipGetLastError());
+  return finish(c);
+}
+
+int pf_stage_preprocess(pf_ctx* c, const uint8_t* bgra, int cols, int rows, int pad, float* gray_half, float* alpha_half) {
+  STAGE_BEGIN(c);
+  if (int e = check_dims(c, cols, rows, pad)) return e;
+  const int dw = int((cols + 2 * pad) * kDownscaleFactor), dh = int(rows * kDownscaleFactor);
+  uint8_t* d = (uint8_t*)stage_up(c, "sg_a", bgra, size_t(cols) * rows * 4);
+  float* t = (float*)ensure(c, "sg_b", size_t(dw) * dh * 4); float* g = (float*)ensure(c, "sg_c", size_t(dw) * dh * 4); float* a = (float*)ensure(c, "sg_d", size_t(dw) * dh * 4);
+  if (!d || !t || !g || !a) return PF_ERR_NOMEM;
+  launch_downscale_gray(sm, d, cols, rows, pad, t, a, dw, dh);
+  launch_gauss_small(sm, t, g, dw, dh, 1, c->g5);
+  HIPCHK(c, hipMemcpyAsync(gray_half, g, size_t(dw) * dh * 4, hipMemcpyDeviceToHost, sm));
+  return stage_down(c, alpha_half, a, size_t(dw) * dh * 4);
+}
+int pf_stage_pyr_down(pf_ctx* c, const float* src, int sw, int sh, float* dst, int dw, int dh) {
+  STAGE_BEGIN(c);
+  float* s = (float*)stage_up(c, "sg_a", src, size_t(sw) * sh * 4); float* d = (float*)ensure(c, "sg_b", size_t(dw) * dh * 4);
+  if (!s || !d) return PF_ERR_NOMEM;
+  launch_resize_linear(sm, s, sw, sh, d, dw, dh, 1, 1.f, false);
+  return stage_down(c, dst, d, size_t(dw) * dh * 4);
+}
+int pf_stage_gradients(pf_ctx* c, const float* img, int w, int h, float* gxy) {
+  STAGE_BEGIN(c);
+  float* s = (float*)stage_up(c, "sg_a", img, size_t(w) * h * 4); float* d = (float*)ensure(c, "sg_b", size_t(w) * h * 8);
+  if (!s || !d) return PF_ERR_NOMEM;
+  launch_gradients(sm, s, w, h, d, c->g3_05);
+  return stage_down(c, gxy, d, size_t(w) * h * 8);
+}
+int pf_stage_gauss(pf_ctx* c, const float* src, int w, int h, int cn, int ksize, double sigma, float* dst) {
+  STAGE_BEGIN(c);
+  if (!((ksize == 3 || ksize == 5) && (cn == 1 || cn == 2)) && !(ksize == 15 && cn == 2)) return fail(c, PF_ERR_ARG, "unsupported gaussian %d/%d", ksize, cn);
+  const size_t nb = size_t(w) * h * cn * 4;
+  float* s = (float*)stage_up(c, "sg_a", src, nb); float* d = (float*)ensure(c, "sg_b", nb); float* t = (float*)ensure(c, "sg_c", nb);
+  if (!s || !d || !t) return PF_ERR_NOMEM;
+  const Gauss g = make_gauss(ksize, sigma);
+  if (ksize == 15) launch_gauss15(sm, s, t, d, w, h, g); else launch_gauss_small(sm, s, d, w, h, cn, g);
+  return stage_down(c, dst, d, nb);
+}
+int pf_stage_median5(pf_ctx* c, const float* flow, int w, int h, float* out) {
+  STAGE_BEGIN(c);
+  float* s = (float*)stage_up(c, "sg_a", flow, size_t(w) * h * 8); float* d = (float*)ensure(c, "sg_b", size_t(w) * h * 8);
+  if (!s || !d) return PF_ERR_NOMEM;
+  launch_median5(sm, s, d, w, h);
+  return stage_down(c, out, d, size_t(w) * h * 8);
+}
+int pf_stage_sweep(pf_ctx* c, const float* g0, const float* g1, const float* blurred, const float* a0, const float* a1, float* flow, int w, int h, int forward) {
+  STAGE_BEGIN(c);
+  const size_t n = size_t(w) * h;
+  float* dg0 = (float*)stage_up(c, "sg_a", g0, n * 8); float* dg1 = (float*)stage_up(c, "sg_b", g1, n * 8); float* dbl = (float*)stage_up(c, "sg_c", blurred, n * 8);
+  float* da0 = (float*)stage_up(c, "sg_d", a0, n * 4); float* da1 = (float*)stage_up(c, "sg_e", a1, n * 4); float* df = (float*)stage_up(c, "sg_f", flow, n * 8);
+  uint8_t* gate = (uint8_t*)ensure(c, "sg_g", n);
+  const size_t nb = size_t(sweep_num_bands(h)) * w;
+  unsigned long long* bnd = (unsigned long long*)ensure(c, "sg_h", nb * 8); int* ctrl = (int*)ensure(c, "sg_i", 16);
+  if (!dg0 || !dg1 || !dbl || !da0 || !da1 || !df || !gate || !bnd || !ctrl) return PF_ERR_NOMEM;
+  launch_gate(sm, da0, da1, (int)n, gate);
+  launch_fill_u64(sm, bnd, nb, kNotReady);
+  HIPCHK(c, hipMemsetAsync(ctrl, 0, 16, sm));
+  SweepArgs sa; sa.g0 = (const float2*)dg0; sa.g1 = (const float2*)dg1; sa.blurred = (const float2*)dbl; sa.gate = gate; sa.flow = (float2*)df;
+  sa.boundary = bnd; sa.ctrl = ctrl; sa.W = w; sa.H = h; sa.forward = forward;
+  launch_sweep(sm, sa);
+  int hc[4] = {0, 0, 0, 0};
+  HIPCHK(c, hipMemcpyAsync(hc, ctrl, 16, hipMemcpyDeviceToHost, sm));
+  if (int e = stage_down(c, flow, df, n * 8)) return e;
+  if (hc[1]) return fail(c, PF_ERR_TIMEOUT, "sweep band timed out");
+  return 0;
+}
+int pf_stage_diffusion(pf_ctx* c, const float* a0, const float* a1, float* flow, int w, int h) {
+  STAGE_BEGIN(c);
+  const size_t n = size_t(w) * h;
+  float* da0 = (float*)stage_up(c, "sg_a", a0, n * 4); float* da1 = (float*)stage_up(c, "sg_b", a1, n * 4); float* df = (float*)stage_up(c, "sg_c", flow, n * 8);
+  float* t = (float*)ensure(c, "sg_d", n * 8); float* o = (float*)ensure(c, "sg_e", n * 8);
+  if (!da0 || !da1 || !df || !t || !o) return PF_ERR_NOMEM;
+  launch_gauss15_mix(sm, df, t, da0, da1, w, h, c->g15, o);
+  return stage_down(c, flow, o, n * 8);
+}
+int pf_stage_upsample_cubic(pf_ctx* c, const float* flow, int sw, int sh, float* out, int dw, int dh, float scale) {
+  STAGE_BEGIN(c);
+  float* s = (float*)stage_up(c, "sg_a", flow, size_t(sw) * sh * 8); float* d = (float*)ensure(c, "sg_b", size_t(dw) * dh * 8);
+  if (!s || !d) return PF_ERR_NOMEM;
+  launch_upsample_cubic(sm, s, sw, sh, d, dw, dh, scale);
+  return stage_down(c, out, d, size_t(dw) * dh * 8);
+}
+int pf_stage_final(pf_ctx* c, const float* flow, int sw, int sh, int pad_cols, int rows, int pad, float scale, float* out) {
+  STAGE_BEGIN(c);
+  const int cols = pad_cols - 2 * pad;
+  float* s = (float*)stage_up(c, "sg_a", flow, size_t(sw) * sh * 8); float* d = (float*)ensure(c, "sg_b", size_t(cols) * rows * 8);
+  if (!s || !d) return PF_ERR_NOMEM;
+  launch_final_flow(sm, s, sw, sh, pad_cols, rows, pad, scale, c->g3_1, d);
+  return stage_down(c, out, d, size_t(cols) * rows * 8);
+}
+int pf_stage_adjust_initial_flow(pf_ctx* c, const float* i0, const float* i1, const float* a0, const float* a1, int w, int h, int hint, int max_pct, float* flow_out) {
+  STAGE_BEGIN(c);
+  const size_t n = size_t(w) * h;
+  float* d0 = (float*)stage_up(c, "sg_a", i0, n * 4); float* d1 = (float*)stage_up(c, "sg_b", i1, n * 4); float* da0 = (float*)stage_up(c, "sg_c", a0, n * 4);
+  float* da1 = (float*)stage_up(c, "sg_d", a1, n * 4); float* df = (float*)ensure(c, "sg_e", n * 8); float* rt = (float*)ensure(c, "sg_f", 256);
+  if (!d0 || !d1 || !da0 || !da1 || !df || !rt) return PF_ERR_NOMEM;
+  HIPCHK(c, hipMemsetAsync(df, 0, n * 8, sm));
+  if (max_pct > 0) launch_adjust_initial_flow(sm, d0, d1, da0, da1, w, h, hint, max_pct, rt, df);
+  return stage_down(c, flow_out, df, n * 8);
+}
+int pf_stage_level(pf_ctx* c, const float* i0, const float* i1, const float* a0, const float* a1, int w, int h, const float* flow_in, int hint, int max_pct,
+                   float* flow_out) {
+  STAGE_BEGIN(c);
+  const size_t n = size_t(w) * h;
+  float* d0 = (float*)stage_up(c, "sg_a", i0, n * 4); float* d1 = (float*)stage_up(c, "sg_b", i1, n * 4); float* da0 = (float*)stage_up(c, "sg_c", a0, n * 4);
+  float* da1 = (float*)stage_up(c, "sg_d", a1, n * 4);
+  float* g0 = (float*)ensure(c, "sg_e", n * 8); float* g1 = (float*)ensure(c, "sg_f", n * 8); uint8_t* gate = (uint8_t*)ensure(c, "sg_g", n);
+  LevelBufs b; b.flow_a = (float*)ensure(c, "sg_h", n * 8); b.flow_b = (float*)ensure(c, "sg_i", n * 8); b.blurred = (float*)ensure(c, "sg_j", n * 8); b.tmp = (float*)ensure(c, "sg_k", n * 8);
+  const size_t nb = size_t(sweep_num_bands(h)) * w;
+  unsigned long long* bnd = (unsigned long long*)ensure(c, "sg_l", nb * 16); int* ctrl = (int*)ensure(c, "sg_m", 16); float* rt = (float*)ensure(c, "sg_n", 256);
+  if (!d0 || !d1 || !da0 || !da1 || !g0 || !g1 || !gate || !b.flow_a || !b.flow_b || !b.blurred || !b.tmp || !bnd || !ctrl || !rt) return PF_ERR_NOMEM;
+  launch_gradients(sm, d0, w, h, g0, c->g3_05);
+  launch_gradients(sm, d1, w, h, g1, c->g3_05);
+  launch_gate(sm, da0, da1, (int)n, gate);
+  launch_fill_u64(sm, bnd, nb * 2, kNotReady);
+  HIPCHK(c, hipMemsetAsync(ctrl, 0, 16, sm));
+  if (flow_in) HIPCHK(c, hipMemcpyAsync(b.flow_a, flow_in, n * 8, hipMemcpyHostToDevice, sm));
+  else {
+    HIPCHK(c, hipMemsetAsync(b.flow_a, 0, n * 8, sm));
+    if (max_pct > 0 && hint != PF_HINT_UNKNOWN) launch_adjust_initial_flow(sm, d0, d1, da0, da1, w, h, hint, max_pct, rt, b.flow_a);
+  }
+  float* res = nullptr;
+  run_level(c, sm, g0, g1, da0, da1, gate, w, h, b, bnd, bnd + nb, ctrl, ctrl + 2, &res);
+  int hc[4] = {0, 0, 0, 0};
+  HIPCHK(c, hipMemcpyAsync(hc, ctrl, 16, hipMemcpyDeviceToHost, sm));
+  if (int e = stage_down(c, flow_out, res, n * 8)) return e;
+  if (hc[1] || hc[3]) return fail(c, PF_ERR_TIMEOUT, "sweep band timed out");
+  return 0;
+}
+int pf_stage_blend_smooth(pf_ctx* c, float* blend, const float* md, int cols, int rows) {
+  STAGE_BEGIN(c);
+  const size_t n = size_t(cols) * rows;
+  float* db = (float*)stage_up(c, "st_blend", blend, n * 4); float* dmd = (float*)stage_up(c, "st_md", md, n * 4);
+  if (!db || !dmd) return PF_ERR_NOMEM;
+  if (int e = blend_smooth_dev(c, db, dmd, cols, rows)) return e;
+  return stage_down(c, blend, db, n * 4);
+}
+
+// ---- profiling ----
+int pf_profile_enable(pf_ctx* c, int on) { if (!c) return PF_ERR_ARG; c->prof = on != 0; return 0; }
+int pf_profile_reset(pf_ctx* c) { if (!c) return PF_ERR_ARG; for (auto& t : c->prof_tot) t = ProfEntry(); return 0; }
+int pf_profile_count(pf_ctx* c) { return c ? (int)c->prof_names.size() : 0; }
+int pf_profile_get(pf_ctx* c, int idx, char* name, int cap, double* ms, int* launches) {
+  if (!c || idx < 0 || idx >= (int)c->prof_names.size()) return PF_ERR_ARG;
+  if (name && cap > 0) { strncpy(name, c->prof_names[idx].c_str(), cap - 1); name[cap - 1] = 0; }
+  if (ms) *ms = c->prof_tot[idx].ms;
+  if (launches) *launches = c->prof_tot[idx].n;
+  return 0;
+}
+
+long long pf_level_pixels(int cols, int rows, int* n_levels, long long* sweep_steps) {
+  const Geometry g = make_geometry(cols, rows, cols / 20);
+  long long steps = 0;
+  for (int l = 0; l < g.n; ++l) steps += g.ws[l] + g.hs[l] - 1;
+  if (n_levels) *n_levels = g.n;
+  if (sweep_steps) *sweep_steps = 2 * steps;
+  return (long long)g.Pexact;
+}
+double pf_algorithmic_bytes(int cols, int rows) {  // B_alg = 472.75*P + 102.4*C*R
+  return 472.75 * (double)pf_level_pixels(cols, rows, nullptr, nullptr) + 102.4 * (double)cols * rows;
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+// Shared host/device declarations for the panoflow HIP library (gfx950 only).
+// All kernels are built with -ffp-contract=off: the solver makes strict '<' decisions on nearly
+// equal floats, so every expression keeps the reference's evaluation order without FMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pf {
+
+// ---- constants of the solver (reference: CPU/PixFlow.hpp:32-44 and the factory :459-497) ----
+constexpr int kPyrMinImageSize = 24;
+constexpr int kPyrMaxLevels = 1000;
+constexpr float kGradEpsilon = 0.001f;
+constexpr float kUpdateAlphaThreshold = 0.9f;
+constexpr float kPyrScaleFactor = 0.9f;
+constexpr float kSmoothnessCoef = 0.001f;
+constexpr float kVerticalRegularizationCoef = 0.01f;
+constexpr float kHorizontalRegularizationCoef = 0.01f;
+constexpr float kGradientStepSize = 0.5f;
+constexpr float kDownscaleFactor = 0.5f;
+
+// sentinel for "boundary flow not published yet" (a NaN payload arithmetic cannot produce)
+constexpr unsigned long long kNotReady = 0x7FFFDEAD7FFFDEADull;
+
+struct Gauss {  // separable kernel taps (host-computed, [OpenCV] getGaussianKernel CV_32F)
+  float k[15];
+  int ksize;
+};
+
+// ---- device helpers ----
+__device__ __forceinline__ int d_reflect101(int p, int n) {
+  if (n == 1) return 0;
+  while (p < 0 || p >= n) { if (p < 0) p = -p; else p = 2 * n - 2 - p; }
+  return p;
+}
+__device__ __forceinline__ int d_replicate(int p, int n) { return p < 0 ? 0 : (p >= n ? n - 1 : p); }
+__device__ __forceinline__ int d_floor(float v) { int i = (int)v; return i - (v < (float)i); }
+
+// [OpenCV imgwarp.cpp] interpolateCubic, A = -0.75, float arithmetic in this exact order
+__device__ __forceinline__ void d_cubic_coeffs(float x, float* c) {
+  const float A = -0.75f;
+  c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+  c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+  c[3] = 1.f - c[0] - c[1] - c[2];
+}
+// source coordinate of destination index d: (float)((d+0.5)*scale-0.5), floor and fraction
+__device__ __forceinline__ void d_src_coord(int d, double scale, int& s, float& f) {
+  f = (float)((d + 0.5) * scale - 0.5);
+  s = d_floor(f);
+  f -= s;
+}
+
+// [OpenCV imgwarp.cpp] INTER_LINEAR float: HResizeLinear (fx forced to 0 at the borders, tail pixels
+// copy S[sx]*1) then VResizeLinear (rows clipped per tap, weights untouched).
+template <int CN>
+__device__ __forceinline__ void d_resize_linear_px(const float* __restrict__ src, int sw, int sh, int dw, int dh, double scale_x,
+                                                   double scale_y, int dx, int dy, float* out) {
+  int sx, sy; float fx, fy;
+  d_src_coord(dx, scale_x, sx, fx);
+  d_src_coord(dy, scale_y, sy, fy);
+  if (sx < 0) { fx = 0; sx = 0; }
+  const bool tail = (sx + 1 >= sw);
+  if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+  const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+  const float* r0 = src + size_t(d_replicate(sy, sh)) * sw * CN;
+  const float* r1 = src + size_t(d_replicate(sy + 1, sh)) * sw * CN;
+#pragma unroll
+  for (int c = 0; c < CN; ++c) {
+    float h0, h1;
+    if (tail) { h0 = r0[sx * CN + c] * 1.0f; h1 = r1[sx * CN + c] * 1.0f; }
+    else { h0 = r0[sx * CN + c] * a0 + r0[(sx + 1) * CN + c] * a1; h1 = r1[sx * CN + c] * a0 + r1[(sx + 1) * CN + c] * a1; }
+    out[c] = h0 * b0 + h1 * b1;
+  }
+}
+
+// ---- launch wrappers (defined in the kernels_*.hip files) ----
+// preprocessing
+void launch_downscale_gray(hipStream_t st, const uint8_t* bgra, int cols, int rows, int pad, float* gray, float* alpha, int dw, int dh);
+void launch_gauss_small(hipStream_t st, const float* src, float* dst, int w, int h, int cn, const Gauss& g);
+void launch_resize_linear(hipStream_t st, const float* src, int sw, int sh, float* dst, int dw, int dh, int cn, float mul, bool do_mul);
+void launch_pyr_down4(hipStream_t st, const float* s0, const float* s1, const float* s2, const float* s3, int sw, int sh, float* d0,
+                      float* d1, float* d2, float* d3, int dw, int dh);
+// per level
+void launch_gradients(hipStream_t st, const float* img, int w, int h, float* gxy, const Gauss& g3);
+void launch_gate(hipStream_t st, const float* a0, const float* a1, int n, uint8_t* gate);
+void launch_gauss15(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const Gauss& g15);
+void launch_gauss15_mix(hipStream_t st, float* flow, float* tmp, const float* a0, const float* a1, int w, int h, const Gauss& g15,
+                        float* out);
+void launch_median5(hipStream_t st, const float* src, float* dst, int w, int h);
+void launch_upsample_cubic(hipStream_t st, const float* src, int sw, int sh, float* dst, int dw, int dh, float mul);
+void launch_final_flow(hipStream_t st, const float* flow0, int sw, int sh, int pad_cols, int rows, int pad, float mul, const Gauss& g3,
+                       float* out);
+// sweep
+struct SweepArgs {
+  const float2* g0;       // (I0x,I0y) at the pixel
+  const float2* g1;       // (I1x,I1y) gathered bilinearly
+  const float2* blurred;  // frozen blurred flow
+  const uint8_t* gate;    // alpha0>thr && alpha1>thr
+  float2* flow;           // in/out
+  unsigned long long* boundary;  // [nbands][W] hand-off rows, pre-filled with kNotReady
+  int* ctrl;              // [0] ticket, [1] abort/timeout flag
+  int W, H, forward;
+};
+int sweep_num_bands(int H);
+void launch_sweep(hipStream_t st, const SweepArgs& a);
+// coarsest-level search
+void launch_adjust_initial_flow(hipStream_t st, const float* i0, const float* i1, const float* a0, const float* a1, int w, int h, int hint,
+                                int max_pct, float* i1eq_tmp, float* flow);
+// blend
+void launch_blend(hipStream_t st, const uint8_t* L, const uint8_t* R, const float* flowLR, const float* flowRL, const float* blend, int cols,
+                  int rows, uint8_t* out);
+// stitch
+void launch_match_images(hipStream_t st, const uint8_t* L, const uint8_t* R, int cols, int rows, uint8_t* map, uint8_t* ovL, uint8_t* ovR);
+void launch_countblend(hipStream_t st, const uint8_t* map, int cols, int rows, float* blend, float* mergedDis);
+void launch_box_blur(hipStream_t st, const float* src, float* dst, double* rowsum_tmp, int cols, int rows, int k);
+void launch_tile_blur(hipStream_t st, float* blend, const float* mergedDis, int cols, int rows, int step, int k);
+void launch_gather(hipStream_t st, const uint8_t* L, const uint8_t* R, const uint8_t* merged, const uint8_t* map, int cols, int rows,
+                   uint8_t* out);
+void launch_fill_u64(hipStream_t st, unsigned long long* p, size_t n, unsigned long long v);
+
+}  // namespace pf

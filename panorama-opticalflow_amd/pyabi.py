@@ -1,0 +1,275 @@
+"""ctypes binding of the product's C ABI (include/panoflow.h -> libpanoflow.so).
+
+Used by tests/, bench.py and __graft_entry__.py.  It is plumbing only: every function forwards to the
+HIP library and raises if the library or the device is missing -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libpanoflow.so")
+
+HINT_UNKNOWN, HINT_RIGHT, HINT_DOWN, HINT_LEFT, HINT_UP = 0, 1, 2, 3, 4
+
+
+class PanoflowError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", _HERE, "-j8"] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise PanoflowError("libpanoflow.so is not built (run __graft_entry__.build()); there is no fallback path")
+        _lib = C.CDLL(SO_PATH)
+        _lib.pf_create.restype = C.c_void_p
+        _lib.pf_create.argtypes = [C.c_int]
+        _lib.pf_destroy.argtypes = [C.c_void_p]
+        _lib.pf_last_error.restype = C.c_char_p
+        _lib.pf_last_error.argtypes = [C.c_void_p]
+        _lib.pf_version.restype = C.c_char_p
+        _lib.pf_dev_alloc.restype = C.c_void_p
+        _lib.pf_dev_alloc.argtypes = [C.c_void_p, C.c_size_t]
+        _lib.pf_dev_free.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.pf_algorithmic_bytes.restype = C.c_double
+        _lib.pf_level_pixels.restype = C.c_longlong
+    return _lib
+
+
+EXPORTS = [
+    "pf_device_count", "pf_create", "pf_destroy", "pf_last_error", "pf_version", "pf_max_percentage_by_name",
+    "pf_flow", "pf_flow_bidir", "pf_blend", "pf_novel_view", "pf_stitch_prepare", "pf_stitch_gather",
+    "pf_dev_alloc", "pf_dev_free", "pf_upload", "pf_download", "pf_sync",
+    "pf_flow_bidir_dev", "pf_blend_dev", "pf_novel_view_dev",
+    "pf_stage_preprocess", "pf_stage_pyr_down", "pf_stage_gradients", "pf_stage_gauss", "pf_stage_median5", "pf_stage_sweep",
+    "pf_stage_diffusion", "pf_stage_upsample_cubic", "pf_stage_final", "pf_stage_adjust_initial_flow", "pf_stage_level",
+    "pf_stage_blend_smooth",
+    "pf_profile_enable", "pf_profile_reset", "pf_profile_count", "pf_profile_get", "pf_algorithmic_bytes", "pf_level_pixels",
+]
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def max_percentage_by_name(name):
+    """makeOpticalFlowByName (CPU/PixFlow.hpp:459-500): raises on an unknown algorithm name."""
+    v = lib().pf_max_percentage_by_name(name.encode())
+    if v < 0:
+        raise PanoflowError(lib().pf_last_error(None).decode())
+    return v
+
+
+def algorithmic_bytes(cols, rows):
+    return float(lib().pf_algorithmic_bytes(cols, rows))
+
+
+def level_pixels(cols, rows):
+    n = C.c_int(0); s = C.c_longlong(0)
+    p = lib().pf_level_pixels(cols, rows, C.byref(n), C.byref(s))
+    return int(p), n.value, int(s.value)
+
+
+class Context:
+    def __init__(self, device=0):
+        self.l = lib()
+        self.h = self.l.pf_create(device)
+        if not self.h:
+            raise PanoflowError("pf_create failed: " + self.l.pf_last_error(None).decode())
+
+    def close(self):
+        if self.h:
+            self.l.pf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise PanoflowError("panoflow error %d: %s" % (rc, self.l.pf_last_error(self.h).decode()))
+
+    # ---- host-buffer entry points ----
+    def flow(self, i0, i1, max_pct, hint):
+        a = _u8(i0); b = _u8(i1); rows, cols, _ = a.shape
+        out = np.empty((rows, cols, 2), np.float32)
+        self._chk(self.l.pf_flow(self.h, _p(a), _p(b), cols, rows, C.c_size_t(cols * 4), max_pct, hint, _p(out), C.c_size_t(cols * 8)))
+        return out
+
+    def flow_bidir(self, L, R, max_pct):
+        a = _u8(L); b = _u8(R); rows, cols, _ = a.shape
+        f0 = np.empty((rows, cols, 2), np.float32); f1 = np.empty((rows, cols, 2), np.float32)
+        self._chk(self.l.pf_flow_bidir(self.h, _p(a), _p(b), cols, rows, C.c_size_t(cols * 4), max_pct, _p(f0), _p(f1), C.c_size_t(cols * 8)))
+        return f0, f1
+
+    def blend(self, L, R, f_l2r, f_r2l, blend):
+        a = _u8(L); b = _u8(R); rows, cols, _ = a.shape
+        out = np.empty((rows, cols, 4), np.uint8)
+        self._chk(self.l.pf_blend(self.h, _p(a), _p(b), C.c_size_t(cols * 4), _p(_f32(f_l2r)), _p(_f32(f_r2l)), C.c_size_t(cols * 8), _p(_f32(blend)),
+                                  C.c_size_t(cols * 4), cols, rows, _p(out), C.c_size_t(cols * 4)))
+        return out
+
+    def novel_view(self, L, R, max_pct, blend, want_flows=True):
+        a = _u8(L); b = _u8(R); rows, cols, _ = a.shape
+        out = np.empty((rows, cols, 4), np.uint8)
+        f0 = np.empty((rows, cols, 2), np.float32) if want_flows else None
+        f1 = np.empty((rows, cols, 2), np.float32) if want_flows else None
+        self._chk(self.l.pf_novel_view(self.h, _p(a), _p(b), cols, rows, C.c_size_t(cols * 4), max_pct, _p(_f32(blend)), C.c_size_t(cols * 4), _p(out),
+                                       C.c_size_t(cols * 4), _p(f0) if want_flows else None, _p(f1) if want_flows else None, C.c_size_t(cols * 8)))
+        return out, f0, f1
+
+    def stitch_prepare(self, L, R):
+        a = _u8(L); b = _u8(R); rows, cols, _ = a.shape
+        mp = np.empty((rows, cols), np.uint8); ovl = np.empty_like(a); ovr = np.empty_like(a)
+        bl = np.empty((rows, cols), np.float32); md = np.empty((rows, cols), np.float32)
+        self._chk(self.l.pf_stitch_prepare(self.h, _p(a), _p(b), cols, rows, C.c_size_t(cols * 4), _p(mp), C.c_size_t(cols), _p(ovl), _p(ovr), _p(bl),
+                                           C.c_size_t(cols * 4), _p(md)))
+        return mp, ovl, ovr, bl, md
+
+    def stitch_gather(self, L, R, merged, mp):
+        a = _u8(L); rows, cols, _ = a.shape
+        out = np.empty((rows, cols, 4), np.uint8)
+        self._chk(self.l.pf_stitch_gather(self.h, _p(a), _p(_u8(R)), _p(_u8(merged)), C.c_size_t(cols * 4), _p(_u8(mp)), C.c_size_t(cols), cols, rows,
+                                          _p(out), C.c_size_t(cols * 4)))
+        return out
+
+    # ---- device-resident entry points (raw device pointers as ints) ----
+    def dev_alloc(self, nbytes):
+        p = self.l.pf_dev_alloc(self.h, C.c_size_t(nbytes))
+        if not p:
+            raise PanoflowError(self.l.pf_last_error(self.h).decode())
+        return p
+
+    def dev_free(self, p):
+        self.l.pf_dev_free(self.h, C.c_void_p(p))
+
+    def upload(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.l.pf_upload(self.h, C.c_void_p(dptr), _p(arr), C.c_size_t(arr.nbytes)))
+
+    def download(self, arr, dptr):
+        self._chk(self.l.pf_download(self.h, _p(arr), C.c_void_p(dptr), C.c_size_t(arr.nbytes)))
+        return arr
+
+    def novel_view_dev(self, d_l, d_r, cols, rows, max_pct, d_blend, d_out, d_f0=None, d_f1=None):
+        self._chk(self.l.pf_novel_view_dev(self.h, C.c_void_p(d_l), C.c_void_p(d_r), cols, rows, max_pct, C.c_void_p(d_blend), C.c_void_p(d_out),
+                                           C.c_void_p(d_f0) if d_f0 else None, C.c_void_p(d_f1) if d_f1 else None))
+
+    def flow_bidir_dev(self, d_l, d_r, cols, rows, max_pct, d_f0, d_f1):
+        self._chk(self.l.pf_flow_bidir_dev(self.h, C.c_void_p(d_l), C.c_void_p(d_r), cols, rows, max_pct, C.c_void_p(d_f0), C.c_void_p(d_f1)))
+
+    def blend_dev(self, d_l, d_r, d_f0, d_f1, d_blend, cols, rows, d_out):
+        self._chk(self.l.pf_blend_dev(self.h, C.c_void_p(d_l), C.c_void_p(d_r), C.c_void_p(d_f0), C.c_void_p(d_f1), C.c_void_p(d_blend), cols, rows,
+                                      C.c_void_p(d_out)))
+
+    # ---- stage-level entry points ----
+    def stage_preprocess(self, bgra, pad=0):
+        a = _u8(bgra); rows, cols, _ = a.shape
+        dw = int(np.float32(cols + 2 * pad) * np.float32(0.5)); dh = int(np.float32(rows) * np.float32(0.5))
+        g = np.empty((dh, dw), np.float32); al = np.empty((dh, dw), np.float32)
+        self._chk(self.l.pf_stage_preprocess(self.h, _p(a), cols, rows, pad, _p(g), _p(al)))
+        return g, al
+
+    def stage_pyr_down(self, src, dw, dh):
+        s = _f32(src); sh, sw = s.shape
+        d = np.empty((dh, dw), np.float32)
+        self._chk(self.l.pf_stage_pyr_down(self.h, _p(s), sw, sh, _p(d), dw, dh))
+        return d
+
+    def stage_gradients(self, img):
+        s = _f32(img); h, w = s.shape
+        g = np.empty((h, w, 2), np.float32)
+        self._chk(self.l.pf_stage_gradients(self.h, _p(s), w, h, _p(g)))
+        return g
+
+    def stage_gauss(self, src, ksize, sigma):
+        s = _f32(src)
+        h, w = s.shape[:2]; cn = 1 if s.ndim == 2 else s.shape[2]
+        d = np.empty_like(s)
+        self._chk(self.l.pf_stage_gauss(self.h, _p(s), w, h, cn, ksize, C.c_double(sigma), _p(d)))
+        return d
+
+    def stage_median5(self, flow):
+        s = _f32(flow); h, w, _ = s.shape
+        d = np.empty_like(s)
+        self._chk(self.l.pf_stage_median5(self.h, _p(s), w, h, _p(d)))
+        return d
+
+    def stage_sweep(self, g0, g1, blurred, a0, a1, flow, forward):
+        f = _f32(flow).copy(); h, w, _ = f.shape
+        self._chk(self.l.pf_stage_sweep(self.h, _p(_f32(g0)), _p(_f32(g1)), _p(_f32(blurred)), _p(_f32(a0)), _p(_f32(a1)), _p(f), w, h, int(forward)))
+        return f
+
+    def stage_diffusion(self, a0, a1, flow):
+        f = _f32(flow).copy(); h, w, _ = f.shape
+        self._chk(self.l.pf_stage_diffusion(self.h, _p(_f32(a0)), _p(_f32(a1)), _p(f), w, h))
+        return f
+
+    def stage_upsample_cubic(self, flow, dw, dh, scale):
+        s = _f32(flow); sh, sw, _ = s.shape
+        d = np.empty((dh, dw, 2), np.float32)
+        self._chk(self.l.pf_stage_upsample_cubic(self.h, _p(s), sw, sh, _p(d), dw, dh, C.c_float(scale)))
+        return d
+
+    def stage_final(self, flow, pad_cols, rows, pad, scale):
+        s = _f32(flow); sh, sw, _ = s.shape
+        d = np.empty((rows, pad_cols - 2 * pad, 2), np.float32)
+        self._chk(self.l.pf_stage_final(self.h, _p(s), sw, sh, pad_cols, rows, pad, C.c_float(scale), _p(d)))
+        return d
+
+    def stage_adjust_initial_flow(self, i0, i1, a0, a1, hint, max_pct):
+        s = _f32(i0); h, w = s.shape
+        f = np.empty((h, w, 2), np.float32)
+        self._chk(self.l.pf_stage_adjust_initial_flow(self.h, _p(s), _p(_f32(i1)), _p(_f32(a0)), _p(_f32(a1)), w, h, hint, max_pct, _p(f)))
+        return f
+
+    def stage_level(self, i0, i1, a0, a1, flow_in, hint, max_pct):
+        s = _f32(i0); h, w = s.shape
+        f = np.empty((h, w, 2), np.float32)
+        fin = None if flow_in is None else _f32(flow_in)
+        self._chk(self.l.pf_stage_level(self.h, _p(s), _p(_f32(i1)), _p(_f32(a0)), _p(_f32(a1)), w, h, None if fin is None else _p(fin), hint, max_pct, _p(f)))
+        return f
+
+    def stage_blend_smooth(self, blend, md):
+        b = _f32(blend).copy(); rows, cols = b.shape
+        self._chk(self.l.pf_stage_blend_smooth(self.h, _p(b), _p(_f32(md)), cols, rows))
+        return b
+
+    # ---- profiling ----
+    def profile_enable(self, on=True):
+        self.l.pf_profile_enable(self.h, int(on))
+
+    def profile_reset(self):
+        self.l.pf_profile_reset(self.h)
+
+    def profile(self):
+        out = {}
+        for i in range(self.l.pf_profile_count(self.h)):
+            name = C.create_string_buffer(64); ms = C.c_double(0); n = C.c_int(0)
+            self.l.pf_profile_get(self.h, i, name, 64, C.byref(ms), C.byref(n))
+            out[name.value.decode()] = (ms.value, n.value)
+        return out

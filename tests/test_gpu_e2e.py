@@ -1,0 +1,93 @@
+"""GPU end-to-end parity through the C ABI vs the oracle on the same seeded inputs (config 1 size).
+Stated tolerance: max per-pixel |dflow| <= 1e-2 px, blended PSNR >= 50 dB; the
+measured result is bit-identical flows, which the test asserts (and reports the deltas if not)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(pf):
+    c = pf.Context(0)
+    yield c
+    c.close()
+
+
+def _psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+@pytest.fixture(scope="module")
+def pair512(synth):
+    return synth.make_pair_np(512, 512, 1234)
+
+
+@pytest.mark.parametrize("alg", ["pixflow_low", "pixflow_search_20"])
+def test_flow_bidir_and_blend_512(ctx, orc, pf, pair512, alg):
+    L, R, blend = pair512
+    mp = pf.max_percentage_by_name(alg)
+    rLR, rRL = orc.flow_bidir(L, R, mp)
+    rout = orc.combine_novel_views(L, R, rLR, rRL, blend)
+    out, fLR, fRL = ctx.novel_view(L, R, mp, blend)
+    dLR = np.abs(fLR - rLR).max(); dRL = np.abs(fRL - rRL).max()
+    print("max|dflow| LR %g RL %g" % (dLR, dRL))
+    assert dLR <= 1e-2 and dRL <= 1e-2
+    assert np.array_equal(fLR, rLR) and np.array_equal(fRL, rRL)
+    psnr = _psnr(out, rout)
+    off = np.abs(out.astype(np.int32) - rout.astype(np.int32))
+    print("blend PSNR %.2f dB, frac>1LSB %g, frac!=0 %g" % (psnr, (off > 1).mean(), (off > 0).mean()))
+    assert psnr >= 50.0 and (off > 1).mean() < 1e-4
+
+
+def test_blend_only(ctx, orc, pair512):
+    L, R, blend = pair512
+    r = np.random.default_rng(3)
+    fLR = (r.standard_normal((512, 512, 2)) * 3).astype(np.float32); fRL = (r.standard_normal((512, 512, 2)) * 3).astype(np.float32)
+    ref = orc.combine_novel_views(L, R, fLR, fRL, blend)
+    got = ctx.blend(L, R, fLR, fRL, blend)
+    off = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    assert off.max() <= 1 and (off > 0).mean() < 1e-3
+    # blend == 0 / 1 reproduces L / R exactly where both alphas > 0 and flow is zero
+    z = np.zeros((512, 512, 2), np.float32)
+    for b, src in ((0.0, L), (1.0, R)):
+        o = ctx.blend(L, R, z, z, np.full((512, 512), b, np.float32))
+        m = (L[..., 3] > 0) & (R[..., 3] > 0)
+        assert np.array_equal(o[m][:, :3], src[m][:, :3]) and (o[m][:, 3] == 255).all() and (o[~m] == 0).all()
+
+
+def test_single_direction_flow_unpadded(ctx, orc, synth):
+    L, R, _ = synth.make_pair_np(320, 256, 77)
+    for hint, mp in ((0, 20), (1, 20), (3, 0)):
+        ref = orc.compute_optical_flow(L, R, mp, hint)
+        got = ctx.flow(L, R, mp, hint)
+        assert np.array_equal(got, ref)
+
+
+def test_constant_images_give_zero_flow(ctx):
+    img = np.full((256, 300, 4), 128, np.uint8); img[..., 3] = 255
+    f0, f1 = ctx.flow_bidir(img, img, 0)
+    assert np.abs(f0).max() == 0 and np.abs(f1).max() == 0
+
+
+def test_bad_arguments(ctx, pf):
+    with pytest.raises(pf.PanoflowError):
+        ctx.flow(np.zeros((1, 1, 4), np.uint8), np.zeros((1, 1, 4), np.uint8), 0, 0)
+    with pytest.raises(pf.PanoflowError):
+        ctx.flow(np.zeros((64, 64, 4), np.uint8), np.zeros((64, 64, 4), np.uint8), 0, 9)
+
+
+def test_stitch_prepare_and_gather(ctx, orc, synth):
+    import torch
+    L, R = synth.make_canvas_pair(640, 420, 21)
+    L, R = L.numpy(), R.numpy()
+    rmap, rovl, rovr, rblend, rmd = orc.stitch_prepare(L, R, True)
+    mp, ovl, ovr, bl, md = ctx.stitch_prepare(L, R)
+    assert np.array_equal(mp, rmap) and np.array_equal(ovl, rovl) and np.array_equal(ovr, rovr)
+    assert np.array_equal(md, rmd)
+    assert np.array_equal(bl, rblend), "max|d| %g" % np.abs(bl - rblend).max()
+    assert set(np.unique(rmap)) >= {0, 50, 100, 150}
+    merged = np.where((rmap == 150)[..., None], ovl, 0).astype(np.uint8)
+    merged[200:210, 300:330] = 0  # a hole in the merged middle -> 8-direction probe path
+    assert np.array_equal(ctx.stitch_gather(L, R, merged, rmap), orc.stitch_gather(L, R, merged, rmap))

@@ -1,0 +1,137 @@
+"""GPU parity, stage by stage: every HIP kernel family vs the oracle's restatement of the same
+reference step on the same seeded inputs, through the C ABI.  Bar: bit-exact (np.array_equal treats
++0 == -0) for everything except the blend's libm transcendentals."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+rng = np.random.default_rng(11)
+
+
+@pytest.fixture(scope="module")
+def ctx(pf):
+    c = pf.Context(0)
+    yield c
+    c.close()
+
+
+def _planes(synth, orc, cols=300, rows=260, seed=5):
+    L, R, _ = synth.make_pair_np(cols, rows, seed)
+    I0, A0 = orc.preprocess(L)
+    I1, A1 = orc.preprocess(R)
+    return L, R, I0, A0, I1, A1
+
+
+@pytest.mark.parametrize("cols,rows,pad", [(300, 260, 0), (301, 203, 15), (512, 512, 25)])
+def test_preprocess(ctx, orc, synth, cols, rows, pad):
+    L, _, _ = synth.make_pair_np(cols, rows, 3)
+    if pad:
+        Lp = np.concatenate([L[:, cols - pad:], L, L[:, :pad]], axis=1)
+    else:
+        Lp = L
+    I, A = orc.preprocess(Lp)
+    g, a = ctx.stage_preprocess(L, pad)
+    assert np.array_equal(a, A)
+    assert np.array_equal(g, I)
+
+
+def test_pyr_down(ctx, orc):
+    src = rng.random((256, 281)).astype(np.float32)
+    for (w, h) in orc.pyramid_sizes(281, 256)[1:4]:
+        ref = orc.pyr_down(src, w, h)
+        got = ctx.stage_pyr_down(src, w, h)
+        assert np.array_equal(got, ref)
+        src = ref
+
+
+def test_gradients(ctx, orc):
+    img = rng.random((97, 131)).astype(np.float32)
+    ix, iy = orc.gradients(img)
+    g = ctx.stage_gradients(img)
+    assert np.array_equal(g[..., 0], ix) and np.array_equal(g[..., 1], iy)
+
+
+@pytest.mark.parametrize("ksize,sigma,cn,shape", [(5, 0.25, 1, (60, 77)), (3, 1.0, 2, (50, 64)), (15, 8.0, 2, (90, 120)), (15, 8.0, 2, (26, 29))])
+def test_gauss(ctx, orc, ksize, sigma, cn, shape):
+    img = rng.standard_normal(shape + ((cn,) if cn > 1 else ())).astype(np.float32)
+    assert np.array_equal(ctx.stage_gauss(img, ksize, sigma), orc.gaussian_blur(img, ksize, sigma))
+
+
+def test_median5(ctx, orc):
+    f = rng.standard_normal((70, 93, 2)).astype(np.float32)
+    f[10:20, 10:30] = 0.0
+    assert np.array_equal(ctx.stage_median5(f), orc.median5(f))
+
+
+def test_upsample_cubic(ctx, orc):
+    f = rng.standard_normal((45, 25, 2)).astype(np.float32)
+    ref = orc.resize_cubic_f32(f, 28, 50) * np.float32(1.0 / np.float32(0.9)) + np.float32(0)
+    got = ctx.stage_upsample_cubic(f, 28, 50, float(np.float32(1.0) / np.float32(0.9)))
+    assert np.array_equal(got, ref)
+
+
+def test_final(ctx, orc):
+    f = rng.standard_normal((100, 110, 2)).astype(np.float32)
+    pad_cols, rows, pad = 220, 200, 10
+    up = orc.resize_linear_f32(f, pad_cols, rows) * np.float32(2.0) + np.float32(0)
+    ref = orc.gaussian_blur(up, 3, 1.0)[:, pad:pad_cols - pad]
+    got = ctx.stage_final(f, pad_cols, rows, pad, 2.0)
+    assert np.array_equal(got, ref)
+
+
+def test_diffusion(ctx, orc):
+    f = rng.standard_normal((64, 80, 2)).astype(np.float32)
+    a0 = rng.random((64, 80)).astype(np.float32); a1 = rng.random((64, 80)).astype(np.float32)
+    a0[:, :20] = 0; a1[30:, :] = 1
+    assert np.array_equal(ctx.stage_diffusion(a0, a1, f), orc.diffusion(a0, a1, f))
+
+
+@pytest.mark.parametrize("hint", [1, 2, 3, 4])
+def test_adjust_initial_flow(ctx, orc, synth, hint):
+    _, _, I0, A0, I1, A1 = _planes(synth, orc)
+    sizes = orc.pyramid_sizes(I0.shape[1], I0.shape[0])
+    for (w, h) in sizes[1:]:
+        I0, I1, A0, A1 = (orc.pyr_down(p, w, h) for p in (I0, I1, A0, A1))
+    ref = orc.adjust_initial_flow(I0, I1, A0, A1, hint, 20)
+    got = ctx.stage_adjust_initial_flow(I0, I1, A0, A1, hint, 20)
+    assert np.array_equal(got, ref)
+    assert np.abs(ref).max() > 0  # the search moved something
+
+
+@pytest.mark.parametrize("w,h", [(90, 70), (150, 131), (64, 257)])
+@pytest.mark.parametrize("forward", [1, 0])
+def test_sweep_bit_exact(ctx, orc, w, h, forward):
+    """The hard one: the GPU wavefront must reproduce the sequential raster sweep bit for bit,
+    including hand-off between 64-row bands (h > 64) and gated-off pixels."""
+    r = np.random.default_rng(100 + w + h + forward)
+    img0 = r.random((h, w)).astype(np.float32); img1 = np.roll(img0, 2, axis=1) + 0.05 * r.random((h, w)).astype(np.float32)
+    g0 = np.stack(orc.gradients(img0), -1); g1 = np.stack(orc.gradients(img1), -1)
+    flow = (r.standard_normal((h, w, 2)) * 1.5).astype(np.float32)
+    blurred = orc.gaussian_blur(flow, 15, 8.0)
+    a0 = np.ones((h, w), np.float32); a1 = np.ones((h, w), np.float32)
+    a0[h // 3: h // 3 + 9, w // 4: w // 2] = 0.5   # gated-off hole
+    a1[:, :3] = 0.0
+    ref = orc.sweep(g0[..., 0], g0[..., 1], g1[..., 0], g1[..., 1], blurred, a0, a1, flow, forward)
+    got = ctx.stage_sweep(g0, g1, blurred, a0, a1, flow, forward)
+    assert np.array_equal(got, ref), "max |d| = %g, mismatches = %d" % (np.abs(got - ref).max(), (got != ref).sum())
+    assert not np.array_equal(ref, flow)
+
+
+@pytest.mark.parametrize("max_pct,hint", [(0, 3), (20, 3), (20, 1)])
+def test_level_coarsest(ctx, orc, synth, max_pct, hint):
+    _, _, I0, A0, I1, A1 = _planes(synth, orc, 400, 300, 9)
+    sizes = orc.pyramid_sizes(I0.shape[1], I0.shape[0])
+    for (w, h) in sizes[1:]:
+        I0, I1, A0, A1 = (orc.pyr_down(p, w, h) for p in (I0, I1, A0, A1))
+    ref = orc.level(I0, I1, A0, A1, None, hint, max_pct)
+    got = ctx.stage_level(I0, I1, A0, A1, None, hint, max_pct)
+    assert np.array_equal(got, ref)
+
+
+def test_level_mid_with_incoming_flow(ctx, orc, synth):
+    _, _, I0, A0, I1, A1 = _planes(synth, orc, 400, 300, 9)
+    h, w = I0.shape
+    fin = (rng.standard_normal((h, w, 2)) * 0.7).astype(np.float32)
+    ref = orc.level(I0, I1, A0, A1, fin, 3, 0)
+    got = ctx.stage_level(I0, I1, A0, A1, fin, 3, 0)
+    assert np.array_equal(got, ref), "max |d| = %g" % np.abs(got - ref).max()
