@@ -1,0 +1,78 @@
+// Drop-in for the reference's CPU/StitchTool.hpp (:21-61).  Map / overlap masks / blend ramp / composite
+// are computed by the StitchTool kernels through pf_stitch_prepare / pf_stitch_gather.
+#ifndef StitchTool_hpp
+#define StitchTool_hpp
+
+#include "util.hpp"
+
+namespace stitch_tools {
+using namespace panocv;
+
+class Stitchtools {
+ public:
+  Mat ImageL, ImageR;
+  Mat Blend;
+  Mat OverlappedL, OverlappedR;
+  Mat Mergedmiddle;  // merged image in the overlap
+  Mat Map;           // ImageL only: 100; ImageR only: 50; overlap: 150
+  Mat FinalResult;
+  Mat MergedDis;
+
+  Stitchtools() {}
+  ~Stitchtools() {}
+
+  // CPU/StitchTool.cpp:7-36
+  void prepare(const Mat& colorImageL, const Mat& colorImageR) {
+    if (colorImageL.type() != CV_8UC4 || colorImageR.type() != CV_8UC4 || colorImageL.rows != colorImageR.rows || colorImageL.cols != colorImageR.cols)
+      throw util::VrCamException("Stitchtools::prepare: inputs must be two CV_8UC4 images of equal size");
+    ImageL = colorImageL.clone();
+    ImageR = colorImageR.clone();
+    MatchImages();
+    GenerateBlend();
+  }
+  // CPU/StitchTool.cpp:38-50 (+ the overlap masking of :17-33).  One device pass produces everything
+  // prepare() needs; GenerateBlend() then only publishes the ramp.
+  void MatchImages() {
+    const int r = ImageL.rows, c = ImageL.cols;
+    Map = Mat(r, c, CV_8UC1); OverlappedL = Mat(r, c, CV_8UC4); OverlappedR = Mat(r, c, CV_8UC4);
+    ramp_ = Mat(r, c, CV_32FC1); MergedDis = Mat(r, c, CV_32FC1);
+    pano::check(pf_stitch_prepare(pano::context(), ImageL.data, ImageR.data, c, r, ImageL.step, Map.data, Map.step, OverlappedL.data, OverlappedR.data,
+                                  ramp_.ptr<float>(), ramp_.step, MergedDis.ptr<float>()));
+  }
+  // CPU/StitchTool.cpp:98-146
+  void GenerateBlend() {
+    if (ramp_.empty()) MatchImages();
+    Blend = ramp_.clone();
+  }
+  // CPU/StitchTool.cpp:148-191.  x is in wrap-extended map coordinates (cols/5 columns were prepended);
+  // returns the smoothed ramp value the device computed for that pixel.
+  float countblend(const int x, const int y) {
+    if (ramp_.empty()) MatchImages();
+    int sx = x - ImageL.cols / 5;
+    if (sx < 0) sx += ImageL.cols; else if (sx >= ImageL.cols) sx -= ImageL.cols;
+    return ramp_.at<float>(y, sx);
+  }
+  // CPU/StitchTool.cpp:52-96
+  void Gather() {
+    if (Mergedmiddle.empty() || Mergedmiddle.step != ImageL.step) throw util::VrCamException("Stitchtools::Gather: setMergedmiddle first");
+    FinalResult = Mat(ImageL.rows, ImageL.cols, CV_8UC4);
+    pano::check(pf_stitch_gather(pano::context(), ImageL.data, ImageR.data, Mergedmiddle.data, ImageL.step, Map.data, Map.step, ImageL.cols, ImageL.rows,
+                                 FinalResult.data, FinalResult.step));
+  }
+
+  Mat getImageL() { return ImageL; }
+  Mat getImageR() { return ImageR; }
+  Mat getBlend() { return Blend; }
+  Mat getMap() { return Map; }
+  Mat getOverlappedL() { return OverlappedL; }
+  Mat getOverlappedR() { return OverlappedR; }
+  Mat getFinalResult() { return FinalResult; }
+  void setMergedmiddle(const Mat& image) { Mergedmiddle = image.clone(); }
+
+ private:
+  Mat ramp_;
+};
+
+}  // namespace stitch_tools
+
+#endif /* StitchTool_hpp */

@@ -94,9 +94,10 @@ def level_pixels(cols, rows):
 class Context:
     def __init__(self, device=0):
         self.l = lib()
-        self.h = self.l.pf_create(device)
-        if not self.h:
+        h = self.l.pf_create(device)
+        if not h:
             raise PanoflowError("pf_create failed: " + self.l.pf_last_error(None).decode())
+        self.h = C.c_void_p(h)  # keep it a c_void_p: a bare int would be passed as a 32-bit C int
 
     def close(self):
         if self.h:
