@@ -133,10 +133,10 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
   }
 }
 
-int sweep_num_bands(int H) { return (H + kBandRows - 1) / kBandRows; }
+int sweep_num_bands(int H) { const int v1 = (H + kBandRows - 1) / kBandRows, v2 = sweep2_num_wgs(H); return v1 > v2 ? v1 : v2; }
 
 void launch_sweep(hipStream_t st, const SweepArgs& a) {
-  hipLaunchKernelGGL(k_sweep, dim3(sweep_num_bands(a.H)), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k_sweep, dim3((a.H + kBandRows - 1) / kBandRows), dim3(64), 0, st, a);
 }
 
 }  // namespace pf

@@ -1,0 +1,536 @@
+// K6 v2: exact Gauss-Seidel sweeps (CPU/PixFlow.hpp:315-337) restructured for CDNA4 latency.
+//
+// The sweep is dependency-latency bound (W+H-1 anti-diagonal steps per sweep), so the design minimises
+// the time of ONE step instead of bytes moved:
+//   * 8 lanes per pixel.  Everything about a pixel that does not depend on its neighbours -- E(C),
+//     E(C+dx), E(C+dy) for its own incoming flow C -- is computed by a fully parallel prepass
+//     (k_sweep_prep) which also packs the static per-pixel inputs into 48-byte records laid out in the
+//     order the wavefront consumes them.  In the sequential kernel six lanes evaluate
+//     E(L), E(L+dx), E(L+dy), E(T), E(T+dx), E(T+dy) for the two proposals (L = previous column,
+//     T = previous row) AT THE SAME TIME: one gather round per step instead of five dependent ones.
+//     Selection follows the reference order (current, then L, then T, strict '<'), the finite-difference
+//     gradient of the winner is already there.  Same arithmetic, same order => bit-identical.
+//   * one compute wave = a band of 8 rows (lane = 8*row + role).  Four compute waves (one per SIMD)
+//     + one I/O helper wave form a workgroup = 32 rows.  Rows inside a wave hand their result to the
+//     next row by cross-lane moves, waves inside a workgroup through an LDS ring, workgroups through
+//     8-byte data-is-flag granules in HBM (agent-scope relaxed atomics; cdna_hip_programming.md G16/R2).
+//   * compute waves never touch HBM except for the bilinear gather of (I1x,I1y): the helper wave
+//     streams records HBM->LDS ahead of the wavefront, drains results LDS->HBM, publishes the granules
+//     and polls the previous workgroup's granules, so the long-latency traffic sits in ITS in-order
+//     memory queue, not in the compute waves'.
+// Workgroups take their band index from an atomic ticket (a band only waits for bands already
+// running), every spin is bounded and raises ctrl[1] instead of hanging.
+#include "pf_common.hpp"
+
+namespace pf {
+
+namespace {
+constexpr int kRows = 8;     // rows per compute wave
+constexpr int kWaves = 4;    // compute waves per workgroup (2 per SIMD: a lone wave only uses ~1 issue slot in 4)
+constexpr int kRS = 32;      // record ring (steps)
+constexpr int kOS = 32;      // result ring (steps)
+constexpr int kBS = 256;     // boundary ring (columns)
+constexpr int kTS = 64;      // wave-to-wave top ring (columns); > kOS + 2*kRows so a producer can never lap its consumer
+constexpr int kChunk = 8;    // steps streamed per helper iteration and wave
+constexpr int kSpinLimit2 = 1 << 24;
+
+struct F2x2 { float a, b, c, d; } __attribute__((aligned(8)));
+
+// errorFunction (PixFlow.hpp:427-456); identical operation order to kernels_sweep.hip / the oracle.
+__device__ __forceinline__ float d_error2(const float2* __restrict__ g1, int W, float wm2, float hm2, float fW, int x, int y, float i0x, float i0y,
+                                          float bx, float by, float fdx, float fdy) {
+  const float matchX = float(x) + fdx, matchY = float(y) + fdy;
+  float cx = (0.0f < matchX) ? matchX : 0.0f; cx = (cx < wm2) ? cx : wm2;
+  float cy = (0.0f < matchY) ? matchY : 0.0f; cy = (cy < hm2) ? cy : hm2;
+  const int x0 = int(cx), y0 = int(cy);
+  const float xR = cx - float(x0), yR = cy - float(y0);
+  const float2* p = g1 + size_t(y0) * W + x0;
+  const F2x2 t0 = *reinterpret_cast<const F2x2*>(p);
+  const F2x2 t1 = *reinterpret_cast<const F2x2*>(p + W);
+  float i1x, i1y;
+  {
+    const float f00 = t0.a, f10 = t0.c, f01 = t1.a, f11 = t1.c;
+    const float a1 = f00, a2 = f10 - f00, a3 = f01 - f00, a4 = f00 + f11 - f10 - f01;
+    i1x = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
+  }
+  {
+    const float f00 = t0.b, f10 = t0.d, f01 = t1.b, f11 = t1.d;
+    const float a1 = f00, a2 = f10 - f00, a3 = f01 - f00, a4 = f00 + f11 - f10 - f01;
+    i1y = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
+  }
+  const float dfx = bx - fdx, dfy = by - fdy;
+  const float smoothness = sqrtf(dfx * dfx + dfy * dfy);
+  return sqrtf((i0x - i1x) * (i0x - i1x) + (i0y - i1y) * (i0y - i1y)) + smoothness * kSmoothnessCoef +
+         kVerticalRegularizationCoef * fabsf(fdy) / fW + kHorizontalRegularizationCoef * fabsf(fdx) / fW;
+}
+
+// ---- exact, cheaper forms of the two IEEE operations that dominate a lone wave's step ------------------
+// (measured on MI355X: correctly rounded sqrtf ~118 cycles, division ~78 cycles per dependent use)
+// sqrt: the core of LLVM's correctly rounded f32 sqrt (v_sqrt_f32 is within 1 ulp; test the two neighbours
+// with exact FMA residuals) without its denormal pre-scaling: valid for x == 0 or x >= 2^-96, finite.
+__device__ __forceinline__ float sqrt_core(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
+  const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+  s = (rm <= 0.0f) ? sm : s;
+  s = (rp > 0.0f) ? sp : s;
+  return s;
+}
+// a / c for a constant c with y = (float)(1.0 / (double)c): two FMA refinement steps (Markstein).  Verified
+// bit-exact against IEEE division on the CPU for every float a with |a| in [2^-100, 2^100] for c = 0.001f
+// (3.36e9 inputs) and for 4.8e9 random (a, c) with c = 2..12000 (tests/micro/divtest.c); a == 0 is exact.
+__device__ __forceinline__ float div_core(float a, float c, float y) {
+  const float q0 = a * y;
+  const float r0 = __builtin_fmaf(-q0, c, a);
+  const float q1 = __builtin_fmaf(r0, y, q0);
+  const float r1 = __builtin_fmaf(-q1, c, a);
+  return __builtin_fmaf(r1, y, q1);
+}
+// all of v0..v3 (>= 0) are zero or inside [2^-95, 2^100]: the range where sqrt_core/div_core are exact
+__device__ __forceinline__ bool fast_range_ok(float v0, float v1, float v2, float v3) {
+  const int e0 = __builtin_amdgcn_frexp_expf(v0), e1 = __builtin_amdgcn_frexp_expf(v1), e2 = __builtin_amdgcn_frexp_expf(v2),
+            e3 = __builtin_amdgcn_frexp_expf(v3);   // 0 for zero input; <= -125 for denormals
+  const int emin = min(min(e0, e1), min(e2, e3));
+  const float vmax = __builtin_fmaxf(__builtin_fmaxf(v0, v1), __builtin_fmaxf(v2, v3));
+  return emin >= -94 && vmax <= 0x1p100f;
+}
+
+// errorFunction with the fast exact forms; falls back to the IEEE sequence when an operand leaves their range.
+__device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, int W, float wm2, float hm2, float fW, float rW, int x, int y, float i0x,
+                                              float i0y, float bx, float by, float fdx, float fdy) {
+  const float matchX = float(x) + fdx, matchY = float(y) + fdy;
+  // min(w-2, max(0, v)) with std::min/max semantics (NaN -> 0), as v_max/v_min
+  const float cx = __builtin_fminf(__builtin_fmaxf(matchX, 0.0f), wm2);
+  const float cy = __builtin_fminf(__builtin_fmaxf(matchY, 0.0f), hm2);
+  const int x0 = int(cx), y0 = int(cy);
+  const float xR = cx - float(x0), yR = cy - float(y0);
+  const float2* p = g1 + (y0 * W + x0);
+  const F2x2 t0 = *reinterpret_cast<const F2x2*>(p);
+  const F2x2 t1 = *reinterpret_cast<const F2x2*>(p + W);
+  const float dfx = bx - fdx, dfy = by - fdy;
+  const float s2 = dfx * dfx + dfy * dfy;
+  const float av = kVerticalRegularizationCoef * fabsf(fdy), ah = kHorizontalRegularizationCoef * fabsf(fdx);
+  float i1x, i1y;
+  {
+    const float f00 = t0.a, f10 = t0.c, f01 = t1.a, f11 = t1.c;
+    const float a1 = f00, a2 = f10 - f00, a3 = f01 - f00, a4 = f00 + f11 - f10 - f01;
+    i1x = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
+  }
+  {
+    const float f00 = t0.b, f10 = t0.d, f01 = t1.b, f11 = t1.d;
+    const float a1 = f00, a2 = f10 - f00, a3 = f01 - f00, a4 = f00 + f11 - f10 - f01;
+    i1y = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
+  }
+  const float d2 = (i0x - i1x) * (i0x - i1x) + (i0y - i1y) * (i0y - i1y);
+  float err;
+  if (__builtin_expect(fast_range_ok(s2, av, ah, d2), 1)) {
+    err = sqrt_core(d2) + sqrt_core(s2) * kSmoothnessCoef + div_core(av, fW, rW) + div_core(ah, fW, rW);
+  } else {
+    err = sqrtf(d2) + sqrtf(s2) * kSmoothnessCoef + av / fW + ah / fW;
+  }
+  return err;
+}
+
+__device__ __forceinline__ unsigned long long pack2(float2 f) {
+  return (unsigned long long)__float_as_uint(f.x) | ((unsigned long long)__float_as_uint(f.y) << 32);
+}
+__device__ __forceinline__ float2 unpack2(unsigned long long v) {
+  return make_float2(__uint_as_float((unsigned)(v & 0xffffffffu)), __uint_as_float((unsigned)(v >> 32)));
+}
+
+// DPP cross-lane moves (wave64, rows of 16 lanes).  row_shl:n -> lane i reads lane i+n.
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ float dpp(float old, float src) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, BANK_MASK, false));
+}
+// value of lane (8*g) broadcast to the 8 lanes of group g
+__device__ __forceinline__ float bcast8(float v) {
+  const float q = dpp<0x00>(v, v);          // quad_perm [0,0,0,0]: lanes 0-3 <- lane 0, lanes 4-7 <- lane 4
+  return dpp<0x114, 0xF, 0xA>(q, q);        // row_shr:4 into banks 1,3 (lanes 4-7, 12-15): <- lanes 0-3, 8-11
+}
+
+struct Smem {
+  float4 rec[kWaves][kRS][kRows][3];
+  float2 out[kWaves][kOS][kRows];
+  unsigned long long bnd[kBS];            // granules of the previous workgroup's last row (poller -> wave 0); data is its own flag
+  unsigned long long topq[kWaves][kTS];   // last row of wave w-1 -> wave w, indexed by column; data is its own flag
+  int recHead[kWaves];   // steps of records available to wave w        (stream helper -> compute)
+  int outHead[kWaves];   // steps completed by wave w                    (compute -> helpers, next wave)
+  int outTail[kWaves];   // steps of wave w written to the flow plane    (stream helper -> compute)
+  int pubTail;           // steps of the last wave published as granules (granule helper -> compute)
+  int bndHead;           // boundary columns available to wave 0        (granule helper -> compute)
+  int abort;
+  int wg;
+};
+
+// LDS counters: a wave's LDS operations are executed in issue order by the CU's LDS unit, so "write data,
+// then write counter" / "read counter, then read data" needs no s_waitcnt between them -- only the
+// compiler must not reorder them (the empty asm is a compiler-only barrier).
+__device__ __forceinline__ int ld_cnt(const int* p) {
+  const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+  return v;
+}
+__device__ __forceinline__ void st_cnt(int* p, int v) {
+  asm volatile("" ::: "memory");
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+}  // namespace
+
+// wait until *cnt >= need (wave-uniform); false on timeout / abort
+__device__ __forceinline__ bool wait_ge(const int* cnt, int need, int& cached, const int* abortp) {
+  if (__builtin_expect(cached >= need, 1)) return true;
+  int spins = 0;
+  for (;;) {
+    cached = ld_cnt(cnt);
+    if (cached >= need) return true;
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > kSpinLimit2 || (((spins & 255) == 0) && ld_cnt(abortp))) return false;
+  }
+}
+
+// One compute wave: a band of 8 rows, lane = 8*row + role.  TOP: 0 = image border above, 1 = previous wave
+// of this workgroup (LDS result ring), 2 = previous workgroup (granule ring filled by the poller wave).
+template <int TOP>
+__device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict__ g1, int W, int H, int forward, int nsteps, int w, int band, int nact,
+                                             bool publishes, float rW, float rEps) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane >> 3, k = lane & 7;
+  const int ry = band * kRows + r;
+  const int y = forward ? ry : H - 1 - ry;   // only used when the record says the pixel exists
+  const bool hasTopRow = ry > 0;
+  const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
+  const bool candIsT = (k >= 3);
+  const int kk = k % 3;
+  const float addx = (kk == 1) ? kGradEpsilon : 0.0f, addy = (kk == 2) ? kGradEpsilon : 0.0f;
+  const bool lastPub = publishes && (w == kWaves - 1);
+  const bool hasNext = (w + 1 < nact);
+  const bool feedsNext = hasNext && (lane == (kRows - 1) * 8);   // lane 0 of the band's last row
+  unsigned long long* topin = (TOP == 1) ? &sm.topq[w][0] : &sm.bnd[0];
+  const int topmask = (TOP == 1) ? (kTS - 1) : (kBS - 1);
+  unsigned long long* topout = &sm.topq[hasNext ? w + 1 : w][0];
+  float2 prev = make_float2(0.f, 0.f);
+  int recAvail = 0;
+  unsigned long long tv = kNotReady;   // raw top value for the current step (prefetched during the previous one)
+  if (TOP != 0) tv = topin[0];
+  for (int s0 = 0; s0 < nsteps; s0 += kChunk) {
+    // ---- once per 8 steps: records of the chunk present, result-ring slots of the chunk free ----
+    if (!wait_ge(&sm.recHead[w], s0 + kChunk, recAvail, &sm.abort)) return false;
+    {
+      int spins = 0;
+      for (;;) {   // slot t%kOS may be reused once step t-kOS was written out, published and consumed by the next wave
+        int lim = ld_cnt(&sm.outTail[w]) + kOS;
+        if (lastPub) { const int c1 = ld_cnt(&sm.pubTail) + kOS; lim = lim < c1 ? lim : c1; }
+        if (hasNext) { const int c2 = ld_cnt(&sm.outHead[w + 1]) + kOS + kRows - 1; lim = lim < c2 ? lim : c2; }
+        if (lim >= s0 + kChunk) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSpinLimit2 || (((spins & 255) == 0) && ld_cnt(&sm.abort))) return false;
+      }
+    }
+    const int send = (s0 + kChunk < nsteps) ? s0 + kChunk : nsteps;
+    const float4* rp0 = &sm.rec[w][s0 % kRS][r][0];
+    float4 ra = rp0[0], rb = rp0[1], rc = rp0[2];
+#pragma unroll 1
+    for (int s = s0; s < send; ++s) {
+      // ---- top neighbour: row r-1's result of the previous step (DPP); row 0 from the ring ----
+      float2 up;
+      up.x = dpp<0x118, 0xF, 0xC>(prev.x, prev.x);           // row_shr:8 into lanes 8-15 of each row of 16
+      up.y = dpp<0x118, 0xF, 0xC>(prev.y, prev.y);
+      up.x = dpp<0x142, 0xE, 0x3>(up.x, prev.x);             // row_bcast:15 -> lanes 0-7 of rows 1..3 (lane 15 of the row above)
+      up.y = dpp<0x142, 0xE, 0x3>(up.y, prev.y);
+      if (TOP != 0 && s < W) {
+        if (__builtin_expect(tv == kNotReady, 0)) {
+          // at the edge of the producer: wait for this column, then fall one more column behind so that
+          // the following steps find their top value already prefetched (one LDS round trip less per step)
+          int spins = 0;
+          for (;;) {
+            tv = __hip_atomic_load(&topin[s & topmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (tv != kNotReady) break;
+            if (++spins > kSpinLimit2 || (((spins & 255) == 0) && ld_cnt(&sm.abort))) return false;
+          }
+          const int ahead = 1;
+          const int last = (s + ahead < W) ? s + ahead : W - 1;
+          for (;;) {
+            const unsigned long long nx = __hip_atomic_load(&topin[last & topmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (nx != kNotReady) break;
+            if (++spins > kSpinLimit2 || (((spins & 255) == 0) && ld_cnt(&sm.abort))) return false;
+          }
+        }
+        if (r == 0) up = unpack2(tv);
+        if (lane == 0) topin[s & topmask] = kNotReady;       // consumed: the slot is free for column s + ring size
+      }
+      // ---- the six proposal evaluations, one per lane ----
+      const int cx = s - r;
+      const int x = forward ? cx : W - 1 - cx;
+      const float2 C = make_float2(rb.x, rb.y);
+      const float eC = rb.z, exC = rb.w, eyC = rc.x, gatev = rc.y;
+      const float2 L = (cx > 0) ? prev : C;          // a missing neighbour proposes the current flow: never strictly better
+      const float2 T = hasTopRow ? up : C;
+      const float2 cand = candIsT ? T : L;
+      const float e = d_error_fast(g1, W, wm2, hm2, fW, rW, x, y, ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
+      // ---- prefetch next step's inputs (LDS) behind the gather ----
+      float4 na = ra, nb = rb, nc = rc;
+      if (s + 1 < send) { const float4* rp = &sm.rec[w][(s + 1) % kRS][r][0]; na = rp[0]; nb = rp[1]; nc = rp[2]; }
+      if (TOP != 0 && s + 1 < W) tv = topin[(s + 1) & topmask];   // plain load: stays in flight behind the gather; a stale 'not ready' only takes the slow path
+      // gather the group's six values in its lane 0 (row_shl:n reads lane+n)
+      const float eL = e, exL = dpp<0x101>(e, e), eyL = dpp<0x102>(e, e), eT = dpp<0x103>(e, e), exT = dpp<0x104>(e, e), eyT = dpp<0x105>(e, e);
+      // selection in the reference's order: current, then L, then T, strict '<'
+      const bool pickL = eL < eC;
+      float cur = pickL ? eL : eC, ex = pickL ? exL : exC, ey = pickL ? eyL : eyC;
+      float2 f; f.x = pickL ? L.x : C.x; f.y = pickL ? L.y : C.y;
+      const bool pickT = eT < cur;
+      cur = pickT ? eT : cur; ex = pickT ? exT : ex; ey = pickT ? eyT : ey;
+      f.x = pickT ? T.x : f.x; f.y = pickT ? T.y : f.y;
+      const float dgx = ex - cur, dgy = ey - cur;
+      float gx, gy;
+      {
+        const float ax = fabsf(dgx), ay = fabsf(dgy);
+        const int e0 = __builtin_amdgcn_frexp_expf(ax), e1 = __builtin_amdgcn_frexp_expf(ay);
+        if (__builtin_expect(min(e0, e1) >= -94 && __builtin_fmaxf(ax, ay) <= 0x1p100f, 1)) {
+          gx = div_core(dgx, kGradEpsilon, rEps); gy = div_core(dgy, kGradEpsilon, rEps);
+        } else {
+          gx = dgx / kGradEpsilon; gy = dgy / kGradEpsilon;
+        }
+      }
+      float2 fin = make_float2(f.x - kGradientStepSize * gx, f.y - kGradientStepSize * gy);
+      if (!(gatev > 0.0f)) fin = C;
+      fin.x = bcast8(fin.x); fin.y = bcast8(fin.y);
+      if (gatev >= 0.0f) prev = fin;
+      // ---- publish: next wave's top ring first (latency critical), then the result ring ----
+      if (feedsNext && cx >= 0 && cx < W) topout[cx & (kTS - 1)] = pack2(fin);
+      if (k == 0) sm.out[w][s % kOS][r] = fin;
+      st_cnt(&sm.outHead[w], s + 1);
+      ra = na; rb = nb; rc = nc;
+    }
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prepass: records in wavefront order.  rec[((band*nstepsPad + s)*8 + r)*3 + j], cx = s - r.
+//   j=0: (I0x, I0y, blurred.x, blurred.y)   j=1: (C.x, C.y, E(C), E(C+dx))   j=2: (E(C+dy), gate, 0, 0)
+//   gate: 1 = update (alpha0,alpha1 > 0.9), 0 = keep C, -1 = no pixel at this (step,row)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g0, const float2* __restrict__ g1, const float2* __restrict__ blurred,
+                                                    const uint8_t* __restrict__ gate, const float2* __restrict__ flow, int W, int H, int forward,
+                                                    int nstepsPad, int nbandsPad, float4* __restrict__ rec) {
+  const size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
+  if (tid >= total) return;
+  const int r = int(tid % kRows);
+  const int s = int((tid / kRows) % nstepsPad);
+  const int band = int(tid / (size_t(kRows) * nstepsPad));
+  const int cx = s - r, ry = band * kRows + r;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = make_float4(0.f, -1.0f, 0.f, 0.f);
+  if (cx >= 0 && cx < W && ry < H) {
+    const int x = forward ? cx : W - 1 - cx, y = forward ? ry : H - 1 - ry;
+    const size_t idx = size_t(y) * W + x;
+    const float2 f = flow[idx];
+    b.x = f.x; b.y = f.y; c.y = 0.0f;
+    if (gate[idx]) {
+      const float2 g = g0[idx], bl = blurred[idx];
+      const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
+      a = make_float4(g.x, g.y, bl.x, bl.y);
+      b.z = d_error2(g1, W, wm2, hm2, fW, x, y, g.x, g.y, bl.x, bl.y, f.x, f.y);
+      b.w = d_error2(g1, W, wm2, hm2, fW, x, y, g.x, g.y, bl.x, bl.y, f.x + kGradEpsilon, f.y + 0.0f);
+      c.x = d_error2(g1, W, wm2, hm2, fW, x, y, g.x, g.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
+      c.y = 1.0f;
+    }
+  }
+  rec[tid * 3 + 0] = a; rec[tid * 3 + 1] = b; rec[tid * 3 + 2] = c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 512 threads: waves 0-3 compute (one band of 8 rows each), wave 4 loads records, wave 5 publishes the
+// workgroup's last row as granules, wave 6 polls the previous workgroup's granules, wave 7 drains results.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
+                                                unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H, int forward,
+                                                int nstepsPad, int nbands, float rW, float rEps) {
+  __shared__ Smem sm;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  if (tid == 0) {
+    sm.wg = atomicAdd(&ctrl[0], 1);
+    sm.bndHead = 0; sm.abort = 0; sm.pubTail = 0;
+  }
+  if (tid < kWaves) { sm.recHead[tid] = 0; sm.outHead[tid] = 0; sm.outTail[tid] = 0; }
+  for (int i = tid; i < kBS; i += blockDim.x) sm.bnd[i] = kNotReady;
+  for (int i = tid; i < kWaves * kTS; i += blockDim.x) (&sm.topq[0][0])[i] = kNotReady;
+  __syncthreads();
+  const int wg = sm.wg;
+  const int nsteps = W + kRows - 1;
+  const int band0 = wg * kWaves;
+  const int nact = (nbands - band0) < kWaves ? (nbands - band0) : kWaves;  // active compute waves in this workgroup
+  const int lastRowOfWG = band0 * kRows + kWaves * kRows - 1;
+  const bool publishes = lastRowOfWG + 1 < H;                            // another workgroup band follows (then nact == kWaves)
+
+  if (wave < kWaves) {
+    // ======================= compute wave: band of 8 rows =======================
+    if (wave >= nact) return;
+    __builtin_amdgcn_s_setprio(3);   // the helper waves share SIMDs with compute waves: compute wins issue arbitration
+    const int top = (wave > 0) ? 1 : (wg > 0 ? 2 : 0);   // where row 0's top neighbour comes from
+    bool ok;
+    if (top == 1) ok = compute_band<1>(sm, g1, W, H, forward, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
+    else if (top == 2) ok = compute_band<2>(sm, g1, W, H, forward, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
+    else ok = compute_band<0>(sm, g1, W, H, forward, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
+    if (!ok) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    return;
+  }
+
+  if (wave == kWaves) {
+    // ======================= loader: records HBM -> LDS ring, up to kRS steps ahead of each compute wave =======================
+    int idle = 0;
+    for (;;) {
+      bool progress = false, done = true;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 va[kWaves], vb[kWaves], vc[kWaves];
+      int rh[kWaves]; bool ld[kWaves];
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        va[w] = z4; vb[w] = z4; vc[w] = z4; ld[w] = false; rh[w] = 0;
+        if (w < nact) {
+          rh[w] = sm.recHead[w];
+          const int oh = ld_cnt(&sm.outHead[w]);
+          ld[w] = rh[w] < nsteps && (rh[w] + kChunk - oh <= kRS);
+          if (rh[w] < nsteps) done = false;
+          if (ld[w]) {
+            const float4* src = rec + (size_t(band0 + w) * nstepsPad + rh[w]) * (kRows * 3);
+            va[w] = src[lane]; vb[w] = src[lane + 64]; vc[w] = src[lane + 128];
+          }
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        if (ld[w]) {
+          float4* dst = &sm.rec[w][rh[w] % kRS][0][0];
+          dst[lane] = va[w]; dst[lane + 64] = vb[w]; dst[lane + 128] = vc[w];
+          st_cnt(&sm.recHead[w], rh[w] + kChunk);
+          progress = true;
+        }
+      }
+      if (done) break;
+      if (progress) idle = 0;
+      else {
+        __builtin_amdgcn_s_sleep(8);
+        if (++idle > kSpinLimit2 || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+    return;
+  }
+
+  if (wave == kWaves + 3) {
+    // ======================= drainer: results LDS ring -> flow plane (stores only: never waits on HBM) =======================
+    int idle = 0;
+    for (;;) {
+      bool progress = false, done = true;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        if (w < nact) {
+          int ot = sm.outTail[w];
+          const int oh = ld_cnt(&sm.outHead[w]);
+          int n = oh - ot; n = n > 8 ? 8 : n;
+          if (n > 0) {
+            const int j = lane >> 3, r = lane & 7, t = ot + j;
+            if (j < n) {
+              const float2 val = sm.out[w][t % kOS][r];
+              const int cx = t - r, ry = (band0 + w) * kRows + r;
+              if (cx >= 0 && cx < W && ry < H) {
+                const int x = forward ? cx : W - 1 - cx, y = forward ? ry : H - 1 - ry;
+                flow[size_t(y) * W + x] = val;
+              }
+            }
+            ot += n;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ring slots are read before they are released
+            st_cnt(&sm.outTail[w], ot);
+            progress = true;
+          }
+          if (ot < nsteps) done = false;
+        }
+      }
+      if (done) break;
+      if (progress) idle = 0;
+      else {
+        __builtin_amdgcn_s_sleep(4);
+        if (++idle > kSpinLimit2 || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+    return;
+  }
+
+  if (wave == kWaves + 1) {
+    // ======================= publisher: last row of the workgroup -> granules in HBM (tight loop, never waits on HBM) =======================
+    if (!publishes) return;
+    unsigned long long* bnd_out = boundary + size_t(wg) * W;
+    const int wl = kWaves - 1;
+    int pt = 0, idle = 0;
+    while (pt < nsteps) {
+      const int ohl = ld_cnt(&sm.outHead[wl]);
+      int n = ohl - pt; n = n > kOS ? kOS : n;
+      if (n > 0) {
+        const int t = pt + lane;
+        if (lane < n) {
+          const float2 val = sm.out[wl][t % kOS][kRows - 1];
+          const int cx = t - (kRows - 1);
+          if (cx >= 0 && cx < W) __hip_atomic_store(bnd_out + cx, pack2(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        pt += n;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        st_cnt(&sm.pubTail, pt);
+        idle = 0;
+      } else {
+        __builtin_amdgcn_s_sleep(6);
+        if (++idle > kSpinLimit2 || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+    return;
+  }
+
+  // ======================= poller: previous workgroup's granules HBM -> LDS ring =======================
+  {
+    if (wg == 0 || wave != kWaves + 2) return;
+    const unsigned long long* bnd_in = boundary + size_t(wg - 1) * W;
+    int bh = 0, idle = 0;
+    while (bh < W) {
+      const int oh0 = ld_cnt(&sm.outHead[0]);
+      if (bh + 64 - oh0 <= kBS) {
+        unsigned long long g = kNotReady;
+        if (bh + lane < W) g = __hip_atomic_load(bnd_in + bh + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ready = (g != kNotReady) || (bh + lane >= W);
+        const unsigned long long m = __ballot(ready);
+        const int n = (m == ~0ull) ? 64 : __builtin_ctzll(~m);
+        if (n > 0) {
+          if (lane < n && bh + lane < W) sm.bnd[(bh + lane) % kBS] = g;
+          bh += n;
+          st_cnt(&sm.bndHead, bh);
+          idle = 0;
+          continue;
+        }
+        __builtin_amdgcn_s_sleep(6);
+      } else {
+        __builtin_amdgcn_s_sleep(8);
+      }
+      if (++idle > kSpinLimit2 || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+}
+
+// ---- host side ----
+int sweep2_num_wgs(int H) { const int nbands = (H + kRows - 1) / kRows; return (nbands + kWaves - 1) / kWaves; }
+size_t sweep2_rec_bytes(int W, int H) {
+  const int nstepsPad = ((W + kRows - 1) + kChunk - 1) / kChunk * kChunk;
+  return size_t(sweep2_num_wgs(H)) * kWaves * nstepsPad * kRows * 48;
+}
+void launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
+  const int nbands = (a.H + kRows - 1) / kRows, nwg = sweep2_num_wgs(a.H), nbandsPad = nwg * kWaves;
+  const int nstepsPad = ((a.W + kRows - 1) + kChunk - 1) / kChunk * kChunk;
+  const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
+  hipLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.g0, a.g1, a.blurred, a.gate, a.flow, a.W, a.H, a.forward,
+                     nstepsPad, nbandsPad, reinterpret_cast<float4*>(rec));
+  hipLaunchKernelGGL(k_sweep2, dim3(nwg), dim3(64 * (kWaves + 4)), 0, st, reinterpret_cast<const float4*>(rec), a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, a.forward,
+                     nstepsPad, nbands, (float)(1.0 / (double)(float)a.W), (float)(1.0 / (double)kGradEpsilon));
+}
+
+}  // namespace pf

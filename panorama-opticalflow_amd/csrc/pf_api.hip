@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -37,6 +38,7 @@ struct pf_ctx {
   std::map<std::string, DevBuf> bufs;  // named grow-only arena: everything a solve needs stays resident
   Gauss g5, g3_05, g3_1, g15;
   bool prof = false;
+  int sweep_version = 2;
   std::vector<std::string> prof_names;
   std::vector<ProfEntry> prof_tot;
   std::vector<ProfPending> prof_pending;
@@ -143,16 +145,17 @@ int check_dims(pf_ctx* c, int cols, int rows, int pad) {
 
 // One level of one direction (PixFlow.hpp:272-340, gradients excluded: they are precomputed for all levels).
 // flow_a holds the incoming flow and receives the level's result (flow_b, blurred, tmp are scratch).
-struct LevelBufs { float *flow_a, *flow_b, *blurred, *tmp; };
+struct LevelBufs { float *flow_a, *flow_b, *blurred, *tmp, *rec; };
 void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, const float* a0, const float* a1, const uint8_t* gate, int w, int h,
                const LevelBufs& b, unsigned long long* bnd_fwd, unsigned long long* bnd_bwd, int* ctrl_fwd, int* ctrl_bwd, float** result) {
   { PROF(c, st, "gauss15_blurredFlow"); launch_gauss15(st, b.flow_a, b.tmp, b.blurred, w, h, c->g15); }
   SweepArgs sa;
   sa.g0 = reinterpret_cast<const float2*>(g0); sa.g1 = reinterpret_cast<const float2*>(g1);
   sa.blurred = reinterpret_cast<const float2*>(b.blurred); sa.gate = gate; sa.W = w; sa.H = h;
-  { PROF(c, st, "sweep"); sa.flow = reinterpret_cast<float2*>(b.flow_a); sa.boundary = bnd_fwd; sa.ctrl = ctrl_fwd; sa.forward = 1; launch_sweep(st, sa); }
+  auto sweep = [&](const SweepArgs& a) { if (c->sweep_version == 1) launch_sweep(st, a); else launch_sweep2(st, a, b.rec); };
+  { PROF(c, st, "sweep"); sa.flow = reinterpret_cast<float2*>(b.flow_a); sa.boundary = bnd_fwd; sa.ctrl = ctrl_fwd; sa.forward = 1; sweep(sa); }
   { PROF(c, st, "median5"); launch_median5(st, b.flow_a, b.flow_b, w, h); }
-  { PROF(c, st, "sweep"); sa.flow = reinterpret_cast<float2*>(b.flow_b); sa.boundary = bnd_bwd; sa.ctrl = ctrl_bwd; sa.forward = 0; launch_sweep(st, sa); }
+  { PROF(c, st, "sweep"); sa.flow = reinterpret_cast<float2*>(b.flow_b); sa.boundary = bnd_bwd; sa.ctrl = ctrl_bwd; sa.forward = 0; sweep(sa); }
   { PROF(c, st, "median5"); launch_median5(st, b.flow_b, b.flow_a, w, h); }
   { PROF(c, st, "gauss15_diffusion"); launch_gauss15_mix(st, b.flow_a, b.tmp, a0, a1, w, h, c->g15, b.flow_b); }
   *result = b.flow_b;
@@ -180,14 +183,16 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   size_t bnd_total = 0;
   for (int l = 0; l < g.n; ++l) { bnd_off[l] = bnd_total; bnd_total += size_t(sweep_num_bands(g.hs[l])) * g.ws[l]; }
   LevelBufs lb[2]; unsigned long long* bnd[2]; int* ctrl[2]; float* ratio[2];
-  const char* nb[2][7] = {{"d0_flow_a", "d0_flow_b", "d0_blurred", "d0_tmp", "d0_bnd", "d0_ctrl", "d0_ratio"},
-                          {"d1_flow_a", "d1_flow_b", "d1_blurred", "d1_tmp", "d1_bnd", "d1_ctrl", "d1_ratio"}};
+  const char* nb[2][8] = {{"d0_flow_a", "d0_flow_b", "d0_blurred", "d0_tmp", "d0_bnd", "d0_ctrl", "d0_ratio", "d0_rec"},
+                          {"d1_flow_a", "d1_flow_b", "d1_blurred", "d1_tmp", "d1_bnd", "d1_ctrl", "d1_ratio", "d1_rec"}};
   for (int d = 0; d < ndirs; ++d) {
     lb[d].flow_a = (float*)ensure(c, nb[d][0], n0 * 8); lb[d].flow_b = (float*)ensure(c, nb[d][1], n0 * 8);
     lb[d].blurred = (float*)ensure(c, nb[d][2], n0 * 8); lb[d].tmp = (float*)ensure(c, nb[d][3], n0 * 8);
     bnd[d] = (unsigned long long*)ensure(c, nb[d][4], bnd_total * 2 * 8);
     ctrl[d] = (int*)ensure(c, nb[d][5], size_t(g.n) * 2 * 2 * sizeof(int));
     ratio[d] = (float*)ensure(c, nb[d][6], 256);
+    lb[d].rec = (float*)ensure(c, nb[d][7], sweep2_rec_bytes(g.w0, g.h0));
+    if (!lb[d].rec) return PF_ERR_NOMEM;
     if (!lb[d].flow_a || !lb[d].flow_b || !lb[d].blurred || !lb[d].tmp || !bnd[d] || !ctrl[d] || !ratio[d]) return PF_ERR_NOMEM;
   }
 
@@ -314,6 +319,7 @@ pf_ctx* pf_create(int device) {
   ok = ok && hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) == hipSuccess;
   for (int d = 0; d < 2 && ok; ++d) ok = hipEventCreateWithFlags(&c->ev_dir[d], hipEventDisableTiming) == hipSuccess;
   if (!ok) { fail(nullptr, PF_ERR_DEVICE, "stream/event creation failed"); delete c; return nullptr; }
+  if (const char* sv = getenv("PANOFLOW_SWEEP")) c->sweep_version = atoi(sv) == 1 ? 1 : 2;
   c->g5 = make_gauss(5, 0.25); c->g3_05 = make_gauss(3, 0.5); c->g3_1 = make_gauss(3, 1.0); c->g15 = make_gauss(15, 8.0);
   return c;
 }
@@ -598,7 +604,9 @@ int pf_stage_sweep(pf_ctx* c, const float* g0, const float* g1, const float* blu
   HIPCHK(c, hipMemsetAsync(ctrl, 0, 16, sm));
   SweepArgs sa; sa.g0 = (const float2*)dg0; sa.g1 = (const float2*)dg1; sa.blurred = (const float2*)dbl; sa.gate = gate; sa.flow = (float2*)df;
   sa.boundary = bnd; sa.ctrl = ctrl; sa.W = w; sa.H = h; sa.forward = forward;
-  launch_sweep(sm, sa);
+  float* rec = (float*)ensure(c, "sg_rec", sweep2_rec_bytes(w, h));
+  if (!rec) return PF_ERR_NOMEM;
+  { PROF(c, sm, "sweep"); if (c->sweep_version == 1) launch_sweep(sm, sa); else launch_sweep2(sm, sa, rec); }
   int hc[4] = {0, 0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(hc, ctrl, 16, hipMemcpyDeviceToHost, sm));
   if (int e = stage_down(c, flow, df, n * 8)) return e;
@@ -646,7 +654,8 @@ int pf_stage_level(pf_ctx* c, const float* i0, const float* i1, const float* a0,
   float* d0 = (float*)stage_up(c, "sg_a", i0, n * 4); float* d1 = (float*)stage_up(c, "sg_b", i1, n * 4); float* da0 = (float*)stage_up(c, "sg_c", a0, n * 4);
   float* da1 = (float*)stage_up(c, "sg_d", a1, n * 4);
   float* g0 = (float*)ensure(c, "sg_e", n * 8); float* g1 = (float*)ensure(c, "sg_f", n * 8); uint8_t* gate = (uint8_t*)ensure(c, "sg_g", n);
-  LevelBufs b; b.flow_a = (float*)ensure(c, "sg_h", n * 8); b.flow_b = (float*)ensure(c, "sg_i", n * 8); b.blurred = (float*)ensure(c, "sg_j", n * 8); b.tmp = (float*)ensure(c, "sg_k", n * 8);
+  LevelBufs b; b.rec = (float*)ensure(c, "sg_rec", sweep2_rec_bytes(w, h)); if (!b.rec) return PF_ERR_NOMEM;
+  b.flow_a = (float*)ensure(c, "sg_h", n * 8); b.flow_b = (float*)ensure(c, "sg_i", n * 8); b.blurred = (float*)ensure(c, "sg_j", n * 8); b.tmp = (float*)ensure(c, "sg_k", n * 8);
   const size_t nb = size_t(sweep_num_bands(h)) * w;
   unsigned long long* bnd = (unsigned long long*)ensure(c, "sg_l", nb * 16); int* ctrl = (int*)ensure(c, "sg_m", 16); float* rt = (float*)ensure(c, "sg_n", 256);
   if (!d0 || !d1 || !da0 || !da1 || !g0 || !g1 || !gate || !b.flow_a || !b.flow_b || !b.blurred || !b.tmp || !bnd || !ctrl || !rt) return PF_ERR_NOMEM;

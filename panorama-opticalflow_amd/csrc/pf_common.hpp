@@ -102,8 +102,11 @@ struct SweepArgs {
   int* ctrl;              // [0] ticket, [1] abort/timeout flag
   int W, H, forward;
 };
-int sweep_num_bands(int H);
-void launch_sweep(hipStream_t st, const SweepArgs& a);
+int sweep_num_bands(int H);   // hand-off rows needed per sweep launch (covers both sweep kernels)
+void launch_sweep(hipStream_t st, const SweepArgs& a);          // v1: 64 rows per wave, kept as a cross-check (PANOFLOW_SWEEP=1)
+int sweep2_num_wgs(int H);
+size_t sweep2_rec_bytes(int W, int H);
+void launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec);  // v2: prepass + 8 lanes/pixel + helper wave
 // coarsest-level search
 void launch_adjust_initial_flow(hipStream_t st, const float* i0, const float* i1, const float* a0, const float* a1, int w, int h, int hint,
                                 int max_pct, float* i1eq_tmp, float* flow);
