@@ -73,10 +73,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+    force_dist = os.environ.get("PANOFLOW_FORCE_DIST") == "1"   # exercise the RCCL path on a single GPU
+    if world > 1 or force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
-    pf = _load("pyabi"); synth = _load("synth")
+    pf = _load("pyabi"); synth = _load("synth"); shard = _load("shard")
     cols, rows = args.cols, args.rows
     max_pct = pf.max_percentage_by_name(args.alg)
     ctx = pf.Context(local_rank)
@@ -86,17 +88,20 @@ def main():
     out = torch.empty((rows, cols, 4), dtype=torch.uint8, device=dev)
     f0 = torch.empty((rows, cols, 2), dtype=torch.float32, device=dev)
     f1 = torch.empty((rows, cols, 2), dtype=torch.float32, device=dev)
-    gathered = [torch.empty_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    my_pairs = shard.pairs_for_rank(world, rank, world)   # one pair per GPU: pair i on rank i
+    assert my_pairs == [rank]
     torch.cuda.synchronize()
 
     def step():
         # flows + blended strip end up resident in HBM; the call is synchronous on return
         ctx.novel_view_dev(L.data_ptr(), R.data_ptr(), cols, rows, max_pct, blend.data_ptr(), out.data_ptr(), f0.data_ptr(), f1.data_ptr())
         if world > 1:  # the only exchange of the path: final gather of the blended strips over RCCL/xGMI
-            dist.gather(out, gathered, dst=0)
+            shard.gather_to_rank0({rank: out}, world, rank, world, out)
+        elif force_dist:
+            dist.gather(out, [torch.empty_like(out)], dst=0)
 
     def fence():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -111,10 +116,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = shard.max_over_ranks(dt, dev)
 
     prof = ctx.profile()
     if rank == 0:
@@ -155,7 +157,7 @@ def main():
             res["parity_vs_cpu"] = {"max_abs_dflow_px": float(max(np.abs(g0 - r0).max(), np.abs(g1 - r1).max())),
                                     "blend_pixels_off": int((off > 0).sum()), "blend_max_lsb": int(off.max())}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

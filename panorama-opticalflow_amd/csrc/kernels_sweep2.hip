@@ -32,7 +32,7 @@ constexpr int kOS = 32;      // result ring (steps)
 constexpr int kBS = 256;     // boundary ring (columns)
 constexpr int kTS = 64;      // wave-to-wave top ring (columns); > kOS + 2*kRows so a producer can never lap its consumer
 constexpr int kChunk = 8;    // steps streamed per helper iteration and wave
-constexpr int kSpinLimit2 = 1 << 24;
+constexpr int kSpinLimit2 = 1 << 20;   // ~0.2 s of polling: a stuck band raises ctrl[1] instead of hanging the GPU
 
 struct F2x2 { float a, b, c, d; } __attribute__((aligned(8)));
 

@@ -1,0 +1,50 @@
+"""Multi-GPU host logic of the path: overlap pairs are independent units, so they
+are sharded round-robin over ranks (one process per GPU) with NO collective on the data path; the only
+exchange is the final gather of the blended strips to rank 0 (RCCL over xGMI on GPUs, gloo in CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def pairs_for_rank(n_pairs, rank, world):
+    """Static round-robin: pair i runs on rank i % world (SURVEY.md 8(e) 'Partitioning')."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    return list(range(rank, n_pairs, world))
+
+
+def run_sharded(n_pairs, rank, world, make_pair, process_pair):
+    """Each rank processes its own pairs; returns {pair_index: result_tensor} for the local shard."""
+    return {i: process_pair(*make_pair(i)) for i in pairs_for_rank(n_pairs, rank, world)}
+
+
+def gather_to_rank0(local, n_pairs, rank, world, like):
+    """Final gather of per-pair results (all the same shape/dtype as `like`) to rank 0, in pair order.
+    Uses grouped send/recv semantics of dist.gather round by round (round j moves pair j*world + r)."""
+    out = [None] * n_pairs if rank == 0 else None
+    rounds = (n_pairs + world - 1) // world
+    for j in range(rounds):
+        idx = j * world + rank
+        mine = local.get(idx)
+        buf = mine if mine is not None else torch.zeros_like(like)
+        if world == 1:
+            if idx < n_pairs:
+                out[idx] = buf
+            continue
+        recv = [torch.empty_like(like) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, recv, dst=0)
+        if rank == 0:
+            for r in range(world):
+                k = j * world + r
+                if k < n_pairs:
+                    out[k] = recv[r]
+    return out
+
+
+def max_over_ranks(seconds, device="cpu"):
+    """The job's time is the slowest rank's (bench.py contract)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
