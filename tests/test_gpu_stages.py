@@ -135,3 +135,27 @@ def test_level_mid_with_incoming_flow(ctx, orc, synth):
     ref = orc.level(I0, I1, A0, A1, fin, 3, 0)
     got = ctx.stage_level(I0, I1, A0, A1, fin, 3, 0)
     assert np.array_equal(got, ref), "max |d| = %g" % np.abs(got - ref).max()
+
+
+def test_sweep_v1_kernel_cross_check(pf, orc):
+    """Two independent GPU implementations of the sweep (v1: 64 rows/wave, 5 dependent evaluations;
+    v2: prepass + 8 lanes/pixel + I/O waves) must both equal the sequential oracle."""
+    import os
+    r = np.random.default_rng(77)
+    h, w = 203, 171
+    img0 = r.random((h, w)).astype(np.float32); img1 = np.roll(img0, 1, axis=0) + 0.03 * r.random((h, w)).astype(np.float32)
+    g0 = np.stack(orc.gradients(img0), -1); g1 = np.stack(orc.gradients(img1), -1)
+    flow = (r.standard_normal((h, w, 2)) * 2.0).astype(np.float32)
+    blurred = orc.gaussian_blur(flow, 15, 8.0)
+    a = np.ones((h, w), np.float32); a[50:60, 30:90] = 0.2
+    os.environ["PANOFLOW_SWEEP"] = "1"
+    try:
+        c1 = pf.Context(0)
+    finally:
+        del os.environ["PANOFLOW_SWEEP"]
+    c2 = pf.Context(0)
+    for fwd in (1, 0):
+        ref = orc.sweep(g0[..., 0], g0[..., 1], g1[..., 0], g1[..., 1], blurred, a, a, flow, fwd)
+        assert np.array_equal(c1.stage_sweep(g0, g1, blurred, a, a, flow, fwd), ref)
+        assert np.array_equal(c2.stage_sweep(g0, g1, blurred, a, a, flow, fwd), ref)
+    c1.close(); c2.close()
