@@ -95,21 +95,39 @@ __device__ __forceinline__ bool fast_range_ok(float v0, float v1, float v2, floa
   return emin >= -94 && vmax <= 0x1p100f;
 }
 
+// v (>= 0) is zero or inside [2^-95, 2^100]
+__device__ __forceinline__ bool fast_range_ok1(float v) {
+  return __builtin_amdgcn_frexp_expf(v) >= -94 && v <= 0x1p100f;
+}
+
 // errorFunction with the fast exact forms; falls back to the IEEE sequence when an operand leaves their range.
+// Scheduled in three phases: (A) address + issue of the two 16-byte gathers, (B) every term that does not need
+// the gathered texels (smoothness, the two regularisers) in the shadow of the gather latency, (C) bilinear +
+// data term.  sched_barrier keeps the compiler from sinking phase B below the wait.
 __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, int W, float wm2, float hm2, float fW, float rW, int x, int y, float i0x,
                                               float i0y, float bx, float by, float fdx, float fdy) {
+  // ---- A ----
   const float matchX = float(x) + fdx, matchY = float(y) + fdy;
-  // min(w-2, max(0, v)) with std::min/max semantics (NaN -> 0), as v_max/v_min
-  const float cx = __builtin_fminf(__builtin_fmaxf(matchX, 0.0f), wm2);
+  const float cx = __builtin_fminf(__builtin_fmaxf(matchX, 0.0f), wm2);   // min(w-2, max(0, v)), std::min/max semantics (NaN -> 0)
   const float cy = __builtin_fminf(__builtin_fmaxf(matchY, 0.0f), hm2);
   const int x0 = int(cx), y0 = int(cy);
-  const float xR = cx - float(x0), yR = cy - float(y0);
   const float2* p = g1 + (y0 * W + x0);
   const F2x2 t0 = *reinterpret_cast<const F2x2*>(p);
   const F2x2 t1 = *reinterpret_cast<const F2x2*>(p + W);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- B ----
+  const float xR = cx - float(x0), yR = cy - float(y0);
   const float dfx = bx - fdx, dfy = by - fdy;
   const float s2 = dfx * dfx + dfy * dfy;
   const float av = kVerticalRegularizationCoef * fabsf(fdy), ah = kHorizontalRegularizationCoef * fabsf(fdx);
+  float sm, rv, rh;
+  if (__builtin_expect(fast_range_ok(s2, av, ah, 1.0f), 1)) {
+    sm = sqrt_core(s2) * kSmoothnessCoef; rv = div_core(av, fW, rW); rh = div_core(ah, fW, rW);
+  } else {
+    sm = sqrtf(s2) * kSmoothnessCoef; rv = av / fW; rh = ah / fW;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- C ----
   float i1x, i1y;
   {
     const float f00 = t0.a, f10 = t0.c, f01 = t1.a, f11 = t1.c;
@@ -122,13 +140,8 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, int
     i1y = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
   }
   const float d2 = (i0x - i1x) * (i0x - i1x) + (i0y - i1y) * (i0y - i1y);
-  float err;
-  if (__builtin_expect(fast_range_ok(s2, av, ah, d2), 1)) {
-    err = sqrt_core(d2) + sqrt_core(s2) * kSmoothnessCoef + div_core(av, fW, rW) + div_core(ah, fW, rW);
-  } else {
-    err = sqrtf(d2) + sqrtf(s2) * kSmoothnessCoef + av / fW + ah / fW;
-  }
-  return err;
+  const float dt = __builtin_expect(fast_range_ok1(d2), 1) ? sqrt_core(d2) : sqrtf(d2);
+  return dt + sm + rv + rh;
 }
 
 __device__ __forceinline__ unsigned long long pack2(float2 f) {
@@ -212,10 +225,12 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   unsigned long long* topout = &sm.topq[hasNext ? w + 1 : w][0];
   float2 prev = make_float2(0.f, 0.f);
   int recAvail = 0;
+  bool dead = false;
   unsigned long long tv = kNotReady;   // raw top value for the current step (prefetched during the previous one)
   if (TOP != 0) tv = topin[0];
   for (int s0 = 0; s0 < nsteps; s0 += kChunk) {
     // ---- once per 8 steps: records of the chunk present, result-ring slots of the chunk free ----
+    if (dead) return false;
     if (!wait_ge(&sm.recHead[w], s0 + kChunk, recAvail, &sm.abort)) return false;
     {
       int spins = 0;
@@ -242,20 +257,16 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       if (TOP != 0 && s < W) {
         if (__builtin_expect(tv == kNotReady, 0)) {
           // at the edge of the producer: wait for this column, then fall one more column behind so that
-          // the following steps find their top value already prefetched (one LDS round trip less per step)
+          // the following steps find their top value already prefetched (one LDS round trip less per step).
+          // No early exit from the hot loop: a timeout only marks the band dead (checked once per chunk).
+          const int last = (s + 1 < W) ? s + 1 : W - 1;
           int spins = 0;
-          for (;;) {
+          unsigned long long nx;
+          do {
             tv = __hip_atomic_load(&topin[s & topmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (tv != kNotReady) break;
-            if (++spins > kSpinLimit2 || (((spins & 255) == 0) && ld_cnt(&sm.abort))) return false;
-          }
-          const int ahead = 1;
-          const int last = (s + ahead < W) ? s + ahead : W - 1;
-          for (;;) {
-            const unsigned long long nx = __hip_atomic_load(&topin[last & topmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (nx != kNotReady) break;
-            if (++spins > kSpinLimit2 || (((spins & 255) == 0) && ld_cnt(&sm.abort))) return false;
-          }
+            nx = __hip_atomic_load(&topin[last & topmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (++spins > kSpinLimit2 || (((spins & 255) == 0) && ld_cnt(&sm.abort))) { dead = true; break; }
+          } while (tv == kNotReady || nx == kNotReady);
         }
         if (r == 0) up = unpack2(tv);
         if (lane == 0) topin[s & topmask] = kNotReady;       // consumed: the slot is free for column s + ring size
@@ -304,7 +315,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       ra = na; rb = nb; rc = nc;
     }
   }
-  return true;
+  return !dead;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -383,6 +394,7 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
   if (wave == kWaves) {
     // ======================= loader: records HBM -> LDS ring, up to kRS steps ahead of each compute wave =======================
     int idle = 0;
+    float touch = 0.f;
     for (;;) {
       bool progress = false, done = true;
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -409,6 +421,17 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
           dst[lane] = va[w]; dst[lane + 64] = vb[w]; dst[lane + 128] = vc[w];
           st_cnt(&sm.recHead[w], rh[w] + kChunk);
           progress = true;
+          // touch-ahead: pull the (I1x,I1y) lines these 64 pixels will gather from (around x + C) into this CU's
+          // L1/L2 so the compute wave's dependent gather hits; C (incoming flow) approximates the proposals.
+          const int j = lane >> 3, r = lane & 7, cx = rh[w] + j - r, ry = (band0 + w) * kRows + r;
+          const float4 rb = sm.rec[w][(rh[w] + j) % kRS][r][1];
+          if (cx >= 0 && cx < W && ry < H) {
+            const int x = forward ? cx : W - 1 - cx, y = forward ? ry : H - 1 - ry;
+            const float mx = __builtin_fminf(__builtin_fmaxf(float(x) + rb.x, 0.0f), float(W) - 2.0f);
+            const float my = __builtin_fminf(__builtin_fmaxf(float(y) + rb.y, 0.0f), float(H) - 2.0f);
+            const float2* q = g1 + (int(my) * W + int(mx));
+            touch += q[0].x + q[W + 1].x;
+          }
         }
       }
       if (done) break;
@@ -418,6 +441,7 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
         if (++idle > kSpinLimit2 || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
     }
+    if (touch == 1.2345678e-30f) ctrl[1] = 2;   // never true: keeps the touch-ahead loads alive
     return;
   }
 
