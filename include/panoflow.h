@@ -123,7 +123,7 @@ int pf_stage_level(pf_ctx* ctx, const float* i0, const float* i1, const float* a
 int pf_stage_blend_smooth(pf_ctx* ctx, float* blend_inout, const float* merged_dis, int cols, int rows); /* StitchTool.cpp:130-143 */
 
 /* ---- per-kernel-family timing (HIP events on the streams the kernels run on) ---------------- */
-int pf_profile_enable(pf_ctx* ctx, int on);
+int pf_profile_enable(pf_ctx* ctx, int on);   /* 0 off, 1 all kernel families, 2 only the sweep kernels */
 int pf_profile_reset(pf_ctx* ctx);
 int pf_profile_count(pf_ctx* ctx);                                       /* number of kernel families seen */
 int pf_profile_get(pf_ctx* ctx, int idx, char* name, int name_cap, double* total_ms, int* launches);

@@ -37,7 +37,7 @@ struct pf_ctx {
   std::string err;
   std::map<std::string, DevBuf> bufs;  // named grow-only arena: everything a solve needs stays resident
   Gauss g5, g3_05, g3_1, g15;
-  bool prof = false;
+  int prof = 0;   // 0 off, 1 every kernel family, 2 only the dominant family (the sweeps): fewer events in a timed region
   int sweep_version = 2;
   std::vector<std::string> prof_names;
   std::vector<ProfEntry> prof_tot;
@@ -94,7 +94,7 @@ hipEvent_t prof_event(pf_ctx* c) {
 }
 struct ProfScope {
   pf_ctx* c; hipStream_t st; ProfPending p; bool on;
-  ProfScope(pf_ctx* c_, hipStream_t st_, const char* name) : c(c_), st(st_), on(c_->prof) {
+  ProfScope(pf_ctx* c_, hipStream_t st_, const char* name) : c(c_), st(st_), on(c_->prof == 1 || (c_->prof == 2 && strncmp(name, "sweep", 5) == 0)) {
     if (!on) return;
     p.id = prof_id(c, name); p.a = prof_event(c); p.b = prof_event(c);
     hipEventRecord(p.a, st);
@@ -687,7 +687,7 @@ int pf_stage_blend_smooth(pf_ctx* c, float* blend, const float* md, int cols, in
 }
 
 // ---- profiling ----
-int pf_profile_enable(pf_ctx* c, int on) { if (!c) return PF_ERR_ARG; c->prof = on != 0; return 0; }
+int pf_profile_enable(pf_ctx* c, int on) { if (!c) return PF_ERR_ARG; c->prof = on < 0 ? 0 : (on > 2 ? 1 : on); return 0; }
 int pf_profile_reset(pf_ctx* c) { if (!c) return PF_ERR_ARG; for (auto& t : c->prof_tot) t = ProfEntry(); return 0; }
 int pf_profile_count(pf_ctx* c) { return c ? (int)c->prof_names.size() : 0; }
 int pf_profile_get(pf_ctx* c, int idx, char* name, int cap, double* ms, int* launches) {

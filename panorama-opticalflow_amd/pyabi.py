@@ -262,6 +262,7 @@ class Context:
 
     # ---- profiling ----
     def profile_enable(self, on=True):
+        """0/False off, 1/True every kernel family, 2 only the sweep kernels."""
         self.l.pf_profile_enable(self.h, int(on))
 
     def profile_reset(self):
