@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
   }
 }
 
-int sweep_num_bands(int H) { const int v1 = (H + kBandRows - 1) / kBandRows, v2 = sweep2_num_wgs(H); return v1 > v2 ? v1 : v2; }
+size_t sweep_boundary_elems(int W, int H) { const size_t v1 = size_t((H + kBandRows - 1) / kBandRows) * W, v2 = sweep2_boundary_elems(W, H); return v1 > v2 ? v1 : v2; }
 
 void launch_sweep(hipStream_t st, const SweepArgs& a) {
   hipLaunchKernelGGL(k_sweep, dim3((a.H + kBandRows - 1) / kBandRows), dim3(64), 0, st, a);

@@ -206,13 +206,13 @@ __device__ __forceinline__ bool wait_ge(const int* cnt, int need, int& cached, c
 // One compute wave: a band of 8 rows, lane = 8*row + role.  TOP: 0 = image border above, 1 = previous wave
 // of this workgroup (LDS result ring), 2 = previous workgroup (granule ring filled by the poller wave).
 template <int TOP>
-__device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict__ g1, int W, int H, int forward, int nsteps, int w, int band, int nact,
-                                             bool publishes, float rW, float rEps) {
+__device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict__ g1, int W, int H, int forward, int transposed, int nsteps, int w, int band,
+                                             int nact, bool publishes, float rW, float rEps) {
   const int lane = threadIdx.x & 63;
   const int r = lane >> 3, k = lane & 7;
-  const int ry = band * kRows + r;
-  const int y = forward ? ry : H - 1 - ry;   // only used when the record says the pixel exists
-  const bool hasTopRow = ry > 0;
+  const int ib = band * kRows + r;           // index across the bands: row (normal) or column (transposed)
+  const int LS = transposed ? H : W;         // extent along the step axis
+  const bool hasCross = ib > 0;              // the cross-lane neighbour (row/column before this one) exists
   const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
   const bool candIsT = (k >= 3);
   const int kk = k % 3;
@@ -254,12 +254,12 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       up.y = dpp<0x118, 0xF, 0xC>(prev.y, prev.y);
       up.x = dpp<0x142, 0xE, 0x3>(up.x, prev.x);             // row_bcast:15 -> lanes 0-7 of rows 1..3 (lane 15 of the row above)
       up.y = dpp<0x142, 0xE, 0x3>(up.y, prev.y);
-      if (TOP != 0 && s < W) {
+      if (TOP != 0 && s < LS) {
         if (__builtin_expect(tv == kNotReady, 0)) {
           // at the edge of the producer: wait for this column, then fall one more column behind so that
           // the following steps find their top value already prefetched (one LDS round trip less per step).
           // No early exit from the hot loop: a timeout only marks the band dead (checked once per chunk).
-          const int last = (s + 1 < W) ? s + 1 : W - 1;
+          const int last = (s + 1 < LS) ? s + 1 : LS - 1;
           int spins = 0;
           unsigned long long nx;
           do {
@@ -272,18 +272,24 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
         if (lane == 0) topin[s & topmask] = kNotReady;       // consumed: the slot is free for column s + ring size
       }
       // ---- the six proposal evaluations, one per lane ----
-      const int cx = s - r;
-      const int x = forward ? cx : W - 1 - cx;
+      const int ia = s - r;                          // index along the step axis
+      const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;
+      const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;   // only used when the record says the pixel exists
       const float2 C = make_float2(rb.x, rb.y);
       const float eC = rb.z, exC = rb.w, eyC = rc.x, gatev = rc.y;
-      const float2 L = (cx > 0) ? prev : C;          // a missing neighbour proposes the current flow: never strictly better
-      const float2 T = hasTopRow ? up : C;
+      // previous pixel along the step axis = own result of the previous step; previous pixel across = DPP/ring.
+      // Reference order is always "previous column, then previous row" (PixFlow.hpp:319-320 / :332-333);
+      // a missing neighbour proposes the current flow, which can never be strictly better.
+      const float2 along = (ia > 0) ? prev : C;
+      const float2 cross = hasCross ? up : C;
+      const float2 L = transposed ? cross : along;
+      const float2 T = transposed ? along : cross;
       const float2 cand = candIsT ? T : L;
       const float e = d_error_fast(g1, W, wm2, hm2, fW, rW, x, y, ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
       // ---- prefetch next step's inputs (LDS) behind the gather ----
       float4 na = ra, nb = rb, nc = rc;
       if (s + 1 < send) { const float4* rp = &sm.rec[w][(s + 1) % kRS][r][0]; na = rp[0]; nb = rp[1]; nc = rp[2]; }
-      if (TOP != 0 && s + 1 < W) tv = topin[(s + 1) & topmask];   // plain load: stays in flight behind the gather; a stale 'not ready' only takes the slow path
+      if (TOP != 0 && s + 1 < LS) tv = topin[(s + 1) & topmask];   // plain load: stays in flight behind the gather; a stale 'not ready' only takes the slow path
       // gather the group's six values in its lane 0 (row_shl:n reads lane+n)
       const float eL = e, exL = dpp<0x101>(e, e), eyL = dpp<0x102>(e, e), eT = dpp<0x103>(e, e), exT = dpp<0x104>(e, e), eyT = dpp<0x105>(e, e);
       // selection in the reference's order: current, then L, then T, strict '<'
@@ -309,7 +315,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       fin.x = bcast8(fin.x); fin.y = bcast8(fin.y);
       if (gatev >= 0.0f) prev = fin;
       // ---- publish: next wave's top ring first (latency critical), then the result ring ----
-      if (feedsNext && cx >= 0 && cx < W) topout[cx & (kTS - 1)] = pack2(fin);
+      if (feedsNext && ia >= 0 && ia < LS) topout[ia & (kTS - 1)] = pack2(fin);
       if (k == 0) sm.out[w][s % kOS][r] = fin;
       st_cnt(&sm.outHead[w], s + 1);
       ra = na; rb = nb; rc = nc;
@@ -325,17 +331,19 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g0, const float2* __restrict__ g1, const float2* __restrict__ blurred,
                                                     const uint8_t* __restrict__ gate, const float2* __restrict__ flow, int W, int H, int forward,
-                                                    int nstepsPad, int nbandsPad, float4* __restrict__ rec) {
+                                                    int transposed, int nstepsPad, int nbandsPad, float4* __restrict__ rec) {
   const size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
   if (tid >= total) return;
   const int r = int(tid % kRows);
   const int s = int((tid / kRows) % nstepsPad);
   const int band = int(tid / (size_t(kRows) * nstepsPad));
-  const int cx = s - r, ry = band * kRows + r;
+  const int LS = transposed ? H : W, LB = transposed ? W : H;   // extent along the step axis / across the bands
+  const int ia = s - r, ib = band * kRows + r;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = make_float4(0.f, -1.0f, 0.f, 0.f);
-  if (cx >= 0 && cx < W && ry < H) {
-    const int x = forward ? cx : W - 1 - cx, y = forward ? ry : H - 1 - ry;
+  if (ia >= 0 && ia < LS && ib < LB) {
+    const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;   // position in sweep order
+    const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
     const size_t idx = size_t(y) * W + x;
     const float2 f = flow[idx];
     b.x = f.x; b.y = f.y; c.y = 0.0f;
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
                                                 unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H, int forward,
-                                                int nstepsPad, int nbands, float rW, float rEps) {
+                                                int transposed, int nstepsPad, int nbands, float rW, float rEps) {
   __shared__ Smem sm;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -372,11 +380,12 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
   for (int i = tid; i < kWaves * kTS; i += blockDim.x) (&sm.topq[0][0])[i] = kNotReady;
   __syncthreads();
   const int wg = sm.wg;
-  const int nsteps = W + kRows - 1;
+  const int LS = transposed ? H : W, LB = transposed ? W : H;   // extent along the step axis / across the bands
+  const int nsteps = LS + kRows - 1;
   const int band0 = wg * kWaves;
   const int nact = (nbands - band0) < kWaves ? (nbands - band0) : kWaves;  // active compute waves in this workgroup
   const int lastRowOfWG = band0 * kRows + kWaves * kRows - 1;
-  const bool publishes = lastRowOfWG + 1 < H;                            // another workgroup band follows (then nact == kWaves)
+  const bool publishes = lastRowOfWG + 1 < LB;                            // another workgroup band follows (then nact == kWaves)
 
   if (wave < kWaves) {
     // ======================= compute wave: band of 8 rows =======================
@@ -384,9 +393,9 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
     __builtin_amdgcn_s_setprio(3);   // the helper waves share SIMDs with compute waves: compute wins issue arbitration
     const int top = (wave > 0) ? 1 : (wg > 0 ? 2 : 0);   // where row 0's top neighbour comes from
     bool ok;
-    if (top == 1) ok = compute_band<1>(sm, g1, W, H, forward, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
-    else if (top == 2) ok = compute_band<2>(sm, g1, W, H, forward, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
-    else ok = compute_band<0>(sm, g1, W, H, forward, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
+    if (top == 1) ok = compute_band<1>(sm, g1, W, H, forward, transposed, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
+    else if (top == 2) ok = compute_band<2>(sm, g1, W, H, forward, transposed, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
+    else ok = compute_band<0>(sm, g1, W, H, forward, transposed, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
     if (!ok) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     return;
   }
@@ -423,10 +432,11 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
           progress = true;
           // touch-ahead: pull the (I1x,I1y) lines these 64 pixels will gather from (around x + C) into this CU's
           // L1/L2 so the compute wave's dependent gather hits; C (incoming flow) approximates the proposals.
-          const int j = lane >> 3, r = lane & 7, cx = rh[w] + j - r, ry = (band0 + w) * kRows + r;
+          const int j = lane >> 3, r = lane & 7, ia = rh[w] + j - r, ib = (band0 + w) * kRows + r;
           const float4 rb = sm.rec[w][(rh[w] + j) % kRS][r][1];
-          if (cx >= 0 && cx < W && ry < H) {
-            const int x = forward ? cx : W - 1 - cx, y = forward ? ry : H - 1 - ry;
+          if (ia >= 0 && ia < LS && ib < LB) {
+            const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;
+            const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
             const float mx = __builtin_fminf(__builtin_fmaxf(float(x) + rb.x, 0.0f), float(W) - 2.0f);
             const float my = __builtin_fminf(__builtin_fmaxf(float(y) + rb.y, 0.0f), float(H) - 2.0f);
             const float2* q = g1 + (int(my) * W + int(mx));
@@ -460,9 +470,10 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
             const int j = lane >> 3, r = lane & 7, t = ot + j;
             if (j < n) {
               const float2 val = sm.out[w][t % kOS][r];
-              const int cx = t - r, ry = (band0 + w) * kRows + r;
-              if (cx >= 0 && cx < W && ry < H) {
-                const int x = forward ? cx : W - 1 - cx, y = forward ? ry : H - 1 - ry;
+              const int ia = t - r, ib = (band0 + w) * kRows + r;
+              if (ia >= 0 && ia < LS && ib < LB) {
+                const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;
+                const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
                 flow[size_t(y) * W + x] = val;
               }
             }
@@ -487,7 +498,7 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
   if (wave == kWaves + 1) {
     // ======================= publisher: last row of the workgroup -> granules in HBM (tight loop, never waits on HBM) =======================
     if (!publishes) return;
-    unsigned long long* bnd_out = boundary + size_t(wg) * W;
+    unsigned long long* bnd_out = boundary + size_t(wg) * LS;
     const int wl = kWaves - 1;
     int pt = 0, idle = 0;
     while (pt < nsteps) {
@@ -498,7 +509,7 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
         if (lane < n) {
           const float2 val = sm.out[wl][t % kOS][kRows - 1];
           const int cx = t - (kRows - 1);
-          if (cx >= 0 && cx < W) __hip_atomic_store(bnd_out + cx, pack2(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (cx >= 0 && cx < LS) __hip_atomic_store(bnd_out + cx, pack2(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         pt += n;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -515,18 +526,18 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
   // ======================= poller: previous workgroup's granules HBM -> LDS ring =======================
   {
     if (wg == 0 || wave != kWaves + 2) return;
-    const unsigned long long* bnd_in = boundary + size_t(wg - 1) * W;
+    const unsigned long long* bnd_in = boundary + size_t(wg - 1) * LS;
     int bh = 0, idle = 0;
-    while (bh < W) {
+    while (bh < LS) {
       const int oh0 = ld_cnt(&sm.outHead[0]);
       if (bh + 64 - oh0 <= kBS) {
         unsigned long long g = kNotReady;
-        if (bh + lane < W) g = __hip_atomic_load(bnd_in + bh + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool ready = (g != kNotReady) || (bh + lane >= W);
+        if (bh + lane < LS) g = __hip_atomic_load(bnd_in + bh + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ready = (g != kNotReady) || (bh + lane >= LS);
         const unsigned long long m = __ballot(ready);
         const int n = (m == ~0ull) ? 64 : __builtin_ctzll(~m);
         if (n > 0) {
-          if (lane < n && bh + lane < W) sm.bnd[(bh + lane) % kBS] = g;
+          if (lane < n && bh + lane < LS) sm.bnd[(bh + lane) % kBS] = g;
           bh += n;
           st_cnt(&sm.bndHead, bh);
           idle = 0;
@@ -542,19 +553,30 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
 }
 
 // ---- host side ----
-int sweep2_num_wgs(int H) { const int nbands = (H + kRows - 1) / kRows; return (nbands + kWaves - 1) / kWaves; }
+// Bands run across the SHORTER image side (fewer band-to-band hand-offs on the critical path):
+// normal = bands of 8 rows stepping along x; transposed = bands of 8 columns stepping along y.
+static inline bool sweep2_transposed(int W, int H) { return W < H; }
+static inline int wgs_for(int LB) { const int nbands = (LB + kRows - 1) / kRows; return (nbands + kWaves - 1) / kWaves; }
+static inline int steps_pad(int LS) { return ((LS + kRows - 1) + kChunk - 1) / kChunk * kChunk; }
+int sweep2_num_wgs(int H) { return wgs_for(H); }
+size_t sweep2_boundary_elems(int W, int H) {   // hand-off granules of one sweep launch, either orientation
+  const size_t a = size_t(wgs_for(H)) * W, b = size_t(wgs_for(W)) * H;
+  return a > b ? a : b;
+}
 size_t sweep2_rec_bytes(int W, int H) {
-  const int nstepsPad = ((W + kRows - 1) + kChunk - 1) / kChunk * kChunk;
-  return size_t(sweep2_num_wgs(H)) * kWaves * nstepsPad * kRows * 48;
+  const size_t a = size_t(wgs_for(H)) * kWaves * steps_pad(W), b = size_t(wgs_for(W)) * kWaves * steps_pad(H);
+  return (a > b ? a : b) * kRows * 48;
 }
 void launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
-  const int nbands = (a.H + kRows - 1) / kRows, nwg = sweep2_num_wgs(a.H), nbandsPad = nwg * kWaves;
-  const int nstepsPad = ((a.W + kRows - 1) + kChunk - 1) / kChunk * kChunk;
+  const int tr = sweep2_transposed(a.W, a.H) ? 1 : 0;
+  const int LS = tr ? a.H : a.W, LB = tr ? a.W : a.H;
+  const int nbands = (LB + kRows - 1) / kRows, nwg = wgs_for(LB), nbandsPad = nwg * kWaves;
+  const int nstepsPad = steps_pad(LS);
   const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
-  hipLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.g0, a.g1, a.blurred, a.gate, a.flow, a.W, a.H, a.forward,
+  hipLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.g0, a.g1, a.blurred, a.gate, a.flow, a.W, a.H, a.forward, tr,
                      nstepsPad, nbandsPad, reinterpret_cast<float4*>(rec));
   hipLaunchKernelGGL(k_sweep2, dim3(nwg), dim3(64 * (kWaves + 4)), 0, st, reinterpret_cast<const float4*>(rec), a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, a.forward,
-                     nstepsPad, nbands, (float)(1.0 / (double)(float)a.W), (float)(1.0 / (double)kGradEpsilon));
+                     tr, nstepsPad, nbands, (float)(1.0 / (double)(float)a.W), (float)(1.0 / (double)kGradEpsilon));
 }
 
 }  // namespace pf

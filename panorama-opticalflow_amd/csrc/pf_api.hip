@@ -181,7 +181,7 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   // hand-off rows + control words of every sweep launch of this solve
   std::vector<size_t> bnd_off(g.n);
   size_t bnd_total = 0;
-  for (int l = 0; l < g.n; ++l) { bnd_off[l] = bnd_total; bnd_total += size_t(sweep_num_bands(g.hs[l])) * g.ws[l]; }
+  for (int l = 0; l < g.n; ++l) { bnd_off[l] = bnd_total; bnd_total += sweep_boundary_elems(g.ws[l], g.hs[l]); }
   LevelBufs lb[2]; unsigned long long* bnd[2]; int* ctrl[2]; float* ratio[2];
   const char* nb[2][8] = {{"d0_flow_a", "d0_flow_b", "d0_blurred", "d0_tmp", "d0_bnd", "d0_ctrl", "d0_ratio", "d0_rec"},
                           {"d1_flow_a", "d1_flow_b", "d1_blurred", "d1_tmp", "d1_bnd", "d1_ctrl", "d1_ratio", "d1_rec"}};
@@ -596,7 +596,7 @@ int pf_stage_sweep(pf_ctx* c, const float* g0, const float* g1, const float* blu
   float* dg0 = (float*)stage_up(c, "sg_a", g0, n * 8); float* dg1 = (float*)stage_up(c, "sg_b", g1, n * 8); float* dbl = (float*)stage_up(c, "sg_c", blurred, n * 8);
   float* da0 = (float*)stage_up(c, "sg_d", a0, n * 4); float* da1 = (float*)stage_up(c, "sg_e", a1, n * 4); float* df = (float*)stage_up(c, "sg_f", flow, n * 8);
   uint8_t* gate = (uint8_t*)ensure(c, "sg_g", n);
-  const size_t nb = size_t(sweep_num_bands(h)) * w;
+  const size_t nb = sweep_boundary_elems(w, h);
   unsigned long long* bnd = (unsigned long long*)ensure(c, "sg_h", nb * 8); int* ctrl = (int*)ensure(c, "sg_i", 16);
   if (!dg0 || !dg1 || !dbl || !da0 || !da1 || !df || !gate || !bnd || !ctrl) return PF_ERR_NOMEM;
   launch_gate(sm, da0, da1, (int)n, gate);
@@ -656,7 +656,7 @@ int pf_stage_level(pf_ctx* c, const float* i0, const float* i1, const float* a0,
   float* g0 = (float*)ensure(c, "sg_e", n * 8); float* g1 = (float*)ensure(c, "sg_f", n * 8); uint8_t* gate = (uint8_t*)ensure(c, "sg_g", n);
   LevelBufs b; b.rec = (float*)ensure(c, "sg_rec", sweep2_rec_bytes(w, h)); if (!b.rec) return PF_ERR_NOMEM;
   b.flow_a = (float*)ensure(c, "sg_h", n * 8); b.flow_b = (float*)ensure(c, "sg_i", n * 8); b.blurred = (float*)ensure(c, "sg_j", n * 8); b.tmp = (float*)ensure(c, "sg_k", n * 8);
-  const size_t nb = size_t(sweep_num_bands(h)) * w;
+  const size_t nb = sweep_boundary_elems(w, h);
   unsigned long long* bnd = (unsigned long long*)ensure(c, "sg_l", nb * 16); int* ctrl = (int*)ensure(c, "sg_m", 16); float* rt = (float*)ensure(c, "sg_n", 256);
   if (!d0 || !d1 || !da0 || !da1 || !g0 || !g1 || !gate || !b.flow_a || !b.flow_b || !b.blurred || !b.tmp || !bnd || !ctrl || !rt) return PF_ERR_NOMEM;
   launch_gradients(sm, d0, w, h, g0, c->g3_05);

@@ -102,9 +102,10 @@ struct SweepArgs {
   int* ctrl;              // [0] ticket, [1] abort/timeout flag
   int W, H, forward;
 };
-int sweep_num_bands(int H);   // hand-off rows needed per sweep launch (covers both sweep kernels)
+size_t sweep_boundary_elems(int W, int H);   // hand-off granules needed per sweep launch (covers both sweep kernels)
 void launch_sweep(hipStream_t st, const SweepArgs& a);          // v1: 64 rows per wave, kept as a cross-check (PANOFLOW_SWEEP=1)
 int sweep2_num_wgs(int H);
+size_t sweep2_boundary_elems(int W, int H);   // granules one sweep launch may need (either band orientation)
 size_t sweep2_rec_bytes(int W, int H);
 void launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec);  // v2: prepass + 8 lanes/pixel + helper wave
 // coarsest-level search
