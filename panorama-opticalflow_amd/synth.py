@@ -125,3 +125,35 @@ def make_canvas_pair(cols, rows, seed=1234, device="cpu"):
     inR = (x >= (cols * 4) // 10 - wob) & (x < (cols * 9) // 10)
     L = torch.where(inL, L, torch.zeros_like(L)); R = torch.where(inR, R, torch.zeros_like(R))
     return L, R
+
+
+def make_stitch_set(cols, rows, seed=1234, n=5, device="cpu"):
+    """Config-4 style canvases: a 'top' image covering rows [0, 0.35R) and n horizontal images,
+    image i covering a column window of width 0.26*C centred at (i-0.5)/n*C (with wrap) and rows [0.25R, R),
+    each with its own parallax (displacement scaled by (i-3)/2).  Fully transparent (all channels 0) elsewhere."""
+    x = torch.arange(cols, device=device)[None, :, None]
+    y = torch.arange(rows, device=device)[:, None, None]
+    base, _, _, _ = make_pair(cols, rows, seed, device, disp_scale=0.0)
+    base[..., 3] = 255
+    # make_pair zeroes colour where its alpha mask is 0; regenerate a hole-free texture for canvases
+    ks = texture_params(seed)
+    xs = torch.arange(cols, dtype=torch.float64, device=device)[None, :].expand(rows, cols)
+    ys = torch.arange(rows, dtype=torch.float64, device=device)[:, None].expand(rows, cols)
+
+    def tex(scale):
+        dx, dy = displacement(xs, ys, cols, rows, scale)
+        t = _texture(xs + dx / 2, ys + dy / 2, ks)
+        img = torch.empty((rows, cols, 4), dtype=torch.uint8, device=device)
+        for ch in range(3):
+            img[..., ch] = torch.clamp(torch.round(torch.clamp(t[ch], 16.0, 240.0)), 0, 255).to(torch.uint8)
+        img[..., 3] = 255
+        return img
+
+    top = torch.where(y < int(0.35 * rows), tex(0.0), torch.zeros((rows, cols, 4), dtype=torch.uint8, device=device))
+    imgs = []
+    for i in range(1, n + 1):
+        centre = (i - 0.5) / n * cols
+        d = torch.remainder(x.double() - centre + cols / 2, cols) - cols / 2
+        inside = (d.abs() <= 0.13 * cols) & (y >= int(0.25 * rows))
+        imgs.append(torch.where(inside, tex((i - 3) / 2.0), torch.zeros((rows, cols, 4), dtype=torch.uint8, device=device)))
+    return top, imgs

@@ -1,0 +1,78 @@
+// Drop-in for the reference's CLI driver (CPU/main.cpp:47-110): same flags, same file names, same
+// 5-step chain (R_i = FinalResult_{i-1}, main.cpp:64-65), same timing lines; all pixel work on the MI355X.
+//   pano_stitch -test_dir <dir> -top_img top.tif -flow_alg pixflow_low|pixflow_search_20 [-steps 5]
+// reads <dir>/<top_img> and <dir>/1.tif .. 5.tif (8-bit RGB/RGBA TIFF or PNG), writes ProcessResult{i}.png and
+// FinalResult.png (main.cpp:97-100).
+#include <cstdlib>
+#include <iostream>
+#include <map>
+#include <string>
+
+#include "../include/OpticalFlow.hpp"
+#include "../include/StitchTool.hpp"
+#include "image_io.hpp"
+
+using namespace panocv;
+using namespace util;
+using namespace optical_flow;
+using namespace stitch_tools;
+
+static std::map<std::string, std::string> parseFlags(int argc, char** argv) {   // gflags syntax: -name value | --name=value
+  std::map<std::string, std::string> f;
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    if (a.empty() || a[0] != '-') throw VrCamException("unexpected argument: " + a);
+    a = a.substr(a.find_first_not_of('-'));
+    const size_t eq = a.find('=');
+    if (eq != std::string::npos) f[a.substr(0, eq)] = a.substr(eq + 1);
+    else if (i + 1 < argc) f[a] = argv[++i];
+    else throw VrCamException("missing value for flag: " + a);
+  }
+  return f;
+}
+
+int main(int argc, char** argv) {
+  try {
+    auto flags = parseFlags(argc, argv);
+    const std::string FLAGS_test_dir = flags["test_dir"], FLAGS_top_img = flags["top_img"], FLAGS_flow_alg = flags["flow_alg"];
+    const int nsteps = flags.count("steps") ? atoi(flags["steps"].c_str()) : 5;
+    double StartTime = getCurrTimeSec();
+    requireArg(FLAGS_test_dir, "test_dir");
+    requireArg(FLAGS_top_img, "top_img");
+    requireArg(FLAGS_flow_alg, "flow_alg");
+
+    Mat colorImageL, colorImageR, FinalResult;
+    Mat colorImageT = pano_io::imreadExceptionOnFail(FLAGS_test_dir + "/" + FLAGS_top_img);
+    for (int i = 1; i <= nsteps; i++) {
+      double StepStart = getCurrTimeSec();
+      if (i == 1) colorImageR = colorImageT; else colorImageR = FinalResult;
+      colorImageL = pano_io::imreadExceptionOnFail(FLAGS_test_dir + "/" + char(i + 48) + ".tif");
+
+      Stitchtools Stools;
+      Stools.prepare(colorImageL, colorImageR);
+      Mat overlappedL = Stools.getOverlappedL();
+      Mat overlappedR = Stools.getOverlappedR();
+      Mat blend = Stools.getBlend();
+
+      NovelViewGenerator* novelViewGen = new NovelViewGeneratorAsymmetricFlow(FLAGS_flow_alg);
+      novelViewGen->prepare(overlappedL, overlappedR);
+      novelViewGen->setBlend(blend);
+      Mat novelViewMerged = Mat();
+      novelViewGen->generateNovelView(novelViewMerged);
+
+      Stools.setMergedmiddle(novelViewMerged);
+      Stools.Gather();
+      FinalResult = Stools.getFinalResult();
+
+      if (i == nsteps) pano_io::imwriteExceptionOnFail(FLAGS_test_dir + "/" + "FinalResult.png", FinalResult);
+      else pano_io::imwriteExceptionOnFail(FLAGS_test_dir + "/" + "ProcessResult" + char(i + 48) + ".png", FinalResult);
+      delete novelViewGen;
+      std::cout << "Part" << i << " Finished!" << "RUNTIME (sec) = " << (getCurrTimeSec() - StepStart) << std::endl;
+    }
+    std::cout << "TotalRunTime (sec) = " << (getCurrTimeSec() - StartTime) << std::endl;
+    return EXIT_SUCCESS;
+  } catch (const VrCamException& e) {
+    std::cerr << "VrCamException: " << e.what() << std::endl;   // the reference's terminate handler prints and aborts (util.cpp:59-78)
+    return EXIT_FAILURE;
+  }
+}
