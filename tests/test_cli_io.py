@@ -17,13 +17,19 @@ def _bgra_to_rgba(a):
 
 
 def _oracle_chain(orc, top, imgs, alg_pct):
-    R = top
+    R = top; steps = []
     for L in imgs:
         mp, ovl, ovr, blend, _ = orc.stitch_prepare(L, R, True)
         f0, f1 = orc.flow_bidir(ovl, ovr, alg_pct)
         merged = orc.combine_novel_views(ovl, ovr, f0, f1, blend)
         R = orc.stitch_gather(L, R, merged, mp)
-    return R
+        steps.append(R)
+    return steps
+
+
+def _psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
 
 
 def test_cli_rejects_missing_flags_and_bad_files(tmp_path):
@@ -49,10 +55,12 @@ def test_cli_three_step_chain(tmp_path, orc, synth, compression):
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "Part1 Finished!RUNTIME (sec) = " in out.stdout and "TotalRunTime (sec) = " in out.stdout
-    got = np.array(Image.open(tmp_path / "FinalResult.png"))[..., [2, 1, 0, 3]]
+    rd = lambda name: np.array(Image.open(tmp_path / name))[..., [2, 1, 0, 3]]
     ref = _oracle_chain(orc, top, imgs, 20)
-    d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
-    # flows are bit-exact; libm ulps in the blend give <= 1 LSB on a few pixels per step, and a changed pixel can
-    # move a later step's flow slightly, so compare by error statistics
-    assert (d > 1).mean() < 2e-3 and (d > 0).mean() < 5e-2, ((d > 1).mean(), (d > 0).mean())
-    assert os.path.exists(tmp_path / "ProcessResult1.png") and os.path.exists(tmp_path / "ProcessResult2.png")
+    # step 1 sees identical inputs: flows are bit-exact, only libm ulps in the blend remain (<= 1 LSB, rare)
+    d1 = np.abs(rd("ProcessResult1.png").astype(np.int32) - ref[0].astype(np.int32))
+    assert d1.max() <= 1 and (d1 > 0).mean() < 2e-3
+    # later steps start from images that differ in those few LSBs; the solver's strict '<' decisions amplify them
+    # (inherent to the algorithm), so the chain is held to the PSNR bar of BASELINE.md section 4
+    assert _psnr(rd("ProcessResult2.png"), ref[1]) >= 50.0
+    assert _psnr(rd("FinalResult.png"), ref[2]) >= 45.0
