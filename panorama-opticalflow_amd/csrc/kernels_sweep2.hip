@@ -27,11 +27,14 @@ namespace pf {
 namespace {
 constexpr int kRows = 8;     // rows per compute wave
 constexpr int kWaves = 4;    // compute waves per workgroup (2 per SIMD: a lone wave only uses ~1 issue slot in 4)
-constexpr int kRS = 32;      // record ring (steps)
+constexpr int kRS = 16;      // record ring (steps)
 constexpr int kOS = 32;      // result ring (steps)
 constexpr int kBS = 256;     // boundary ring (columns)
 constexpr int kTS = 64;      // wave-to-wave top ring (columns); > kOS + 2*kRows so a producer can never lap its consumer
 constexpr int kChunk = 8;    // steps streamed per helper iteration and wave
+constexpr int kRad = 8;      // LDS window of the gathered plane: +-kRad texels around the band
+constexpr int kWA = kRows + 2 * kRad + 1;   // window extent across the band (25)
+constexpr int kWC = 64;      // window ring along the step axis (columns)
 constexpr int kSpinLimit2 = 1 << 20;   // ~0.2 s of polling: a stuck band raises ctrl[1] instead of hanging the GPU
 
 struct F2x2 { float a, b, c, d; } __attribute__((aligned(8)));
@@ -101,19 +104,40 @@ __device__ __forceinline__ bool fast_range_ok1(float v) {
 }
 
 // errorFunction with the fast exact forms; falls back to the IEEE sequence when an operand leaves their range.
-// Scheduled in three phases: (A) address + issue of the two 16-byte gathers, (B) every term that does not need
-// the gathered texels (smoothness, the two regularisers) in the shadow of the gather latency, (C) bilinear +
-// data term.  sched_barrier keeps the compiler from sinking phase B below the wait.
-__device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, int W, float wm2, float hm2, float fW, float rW, int x, int y, float i0x,
-                                              float i0y, float bx, float by, float fdx, float fdy) {
+// The four bilinear texels come from the band's LDS window (filled by the loader wave) when the proposal points
+// within +-(kRad-1) texels of the pixel, otherwise from HBM.  Scheduled in three phases: (A) addresses + issue of
+// the texel reads, (B) every term that does not need the texels (smoothness, the two regularisers) in the shadow
+// of their latency, (C) bilinear + data term.  sched_barrier keeps the compiler from sinking B below the wait.
+template <bool TR, bool FWD>
+__device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, const float2* __restrict__ win, int ob, int W, int H, float wm2, float hm2,
+                                              float fW, float rW, int x, int y, float i0x, float i0y, float bx, float by, float fdx, float fdy) {
   // ---- A ----
-  const float matchX = float(x) + fdx, matchY = float(y) + fdy;
+  const float fx = float(x), fy = float(y);
+  const float matchX = fx + fdx, matchY = fy + fdy;
   const float cx = __builtin_fminf(__builtin_fmaxf(matchX, 0.0f), wm2);   // min(w-2, max(0, v)), std::min/max semantics (NaN -> 0)
   const float cy = __builtin_fminf(__builtin_fmaxf(matchY, 0.0f), hm2);
   const int x0 = int(cx), y0 = int(cy);
-  const float2* p = g1 + (y0 * W + x0);
-  const F2x2 t0 = *reinterpret_cast<const F2x2*>(p);
-  const F2x2 t1 = *reinterpret_cast<const F2x2*>(p + W);
+  const bool inwin = (fabsf(cx - fx) <= float(kRad - 1)) && (fabsf(cy - fy) <= float(kRad - 1));
+  // sweep-order coordinates of texel (x0,y0): u along the step axis, v across the bands
+  const int cxc = FWD ? x0 : W - 1 - x0, cyc = FWD ? y0 : H - 1 - y0;
+  const int u0 = TR ? cyc : cxc, v0 = TR ? cxc : cyc;
+  constexpr int sg = FWD ? 1 : -1;
+  const int a0 = v0 - ob;
+  const int o00 = a0 * kWC + (u0 & (kWC - 1)), oal = a0 * kWC + ((u0 + sg) & (kWC - 1));   // +1 along the step axis (ring wrap)
+  const int o10 = TR ? o00 + sg * kWC : oal;          // texel (x0+1, y0)
+  const int o01 = TR ? oal : o00 + sg * kWC;          // texel (x0, y0+1)
+  const int o11 = oal + sg * kWC;                     // texel (x0+1, y0+1)
+  // LDS reads are unconditional (out-of-window lanes read slot 0 and are overwritten below) so that the two
+  // address spaces never meet in one pointer -- a merged pointer would turn every access into a slow flat_load.
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) const f2v lds_f2;
+  lds_f2* win3 = (lds_f2*)win;   // explicit LDS address space: ds_read_b64, never a flat access
+  const f2v w00 = win3[inwin ? o00 : 0], w10 = win3[inwin ? o10 : 0], w01 = win3[inwin ? o01 : 0], w11 = win3[inwin ? o11 : 0];
+  float2 t00 = make_float2(w00.x, w00.y), t10 = make_float2(w10.x, w10.y), t01 = make_float2(w01.x, w01.y), t11 = make_float2(w11.x, w11.y);
+  if (__builtin_expect(!inwin, 0)) {
+    const float2* p = g1 + (y0 * W + x0);
+    t00 = p[0]; t10 = p[1]; t01 = p[W]; t11 = p[W + 1];
+  }
   __builtin_amdgcn_sched_barrier(0);
   // ---- B ----
   const float xR = cx - float(x0), yR = cy - float(y0);
@@ -130,12 +154,12 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, int
   // ---- C ----
   float i1x, i1y;
   {
-    const float f00 = t0.a, f10 = t0.c, f01 = t1.a, f11 = t1.c;
+    const float f00 = t00.x, f10 = t10.x, f01 = t01.x, f11 = t11.x;
     const float a1 = f00, a2 = f10 - f00, a3 = f01 - f00, a4 = f00 + f11 - f10 - f01;
     i1x = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
   }
   {
-    const float f00 = t0.b, f10 = t0.d, f01 = t1.b, f11 = t1.d;
+    const float f00 = t00.y, f10 = t10.y, f01 = t01.y, f11 = t11.y;
     const float a1 = f00, a2 = f10 - f00, a3 = f01 - f00, a4 = f00 + f11 - f10 - f01;
     i1y = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
   }
@@ -165,6 +189,7 @@ __device__ __forceinline__ float bcast8(float v) {
 struct Smem {
   float4 rec[kWaves][kRS][kRows][3];
   float2 out[kWaves][kOS][kRows];
+  float2 win[kWaves][kWA][kWC];           // (I1x,I1y) texels around each band, sweep-order coordinates, ring along the step axis
   unsigned long long bnd[kBS];            // granules of the previous workgroup's last row (poller -> wave 0); data is its own flag
   unsigned long long topq[kWaves][kTS];   // last row of wave w-1 -> wave w, indexed by column; data is its own flag
   int recHead[kWaves];   // steps of records available to wave w        (stream helper -> compute)
@@ -205,14 +230,17 @@ __device__ __forceinline__ bool wait_ge(const int* cnt, int need, int& cached, c
 
 // One compute wave: a band of 8 rows, lane = 8*row + role.  TOP: 0 = image border above, 1 = previous wave
 // of this workgroup (LDS result ring), 2 = previous workgroup (granule ring filled by the poller wave).
-template <int TOP>
-__device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict__ g1, int W, int H, int forward, int transposed, int nsteps, int w, int band,
+template <int TOP, bool TR, bool FWD>
+__device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict__ g1, int W, int H, int nsteps, int w, int band,
                                              int nact, bool publishes, float rW, float rEps) {
+  constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0;
   const int lane = threadIdx.x & 63;
   const int r = lane >> 3, k = lane & 7;
   const int ib = band * kRows + r;           // index across the bands: row (normal) or column (transposed)
   const int LS = transposed ? H : W;         // extent along the step axis
   const bool hasCross = ib > 0;              // the cross-lane neighbour (row/column before this one) exists
+  const float2* win = &sm.win[w][0][0];
+  const int ob = band * kRows - kRad;         // window origin across the bands
   const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
   const bool candIsT = (k >= 3);
   const int kk = k % 3;
@@ -285,7 +313,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       const float2 L = transposed ? cross : along;
       const float2 T = transposed ? along : cross;
       const float2 cand = candIsT ? T : L;
-      const float e = d_error_fast(g1, W, wm2, hm2, fW, rW, x, y, ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
+      const float e = d_error_fast<TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, x, y, ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
       // ---- prefetch next step's inputs (LDS) behind the gather ----
       float4 na = ra, nb = rb, nc = rc;
       if (s + 1 < send) { const float4* rp = &sm.rec[w][(s + 1) % kRS][r][0]; na = rp[0]; nb = rp[1]; nc = rp[2]; }
@@ -364,9 +392,11 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
 // 512 threads: waves 0-3 compute (one band of 8 rows each), wave 4 loads records, wave 5 publishes the
 // workgroup's last row as granules, wave 6 polls the previous workgroup's granules, wave 7 drains results.
 // ------------------------------------------------------------------------------------------------
+template <bool TR, bool FWD>
 __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
-                                                unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H, int forward,
-                                                int transposed, int nstepsPad, int nbands, float rW, float rEps) {
+                                                unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H,
+                                                int nstepsPad, int nbands, float rW, float rEps) {
+  constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0;
   __shared__ Smem sm;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -393,21 +423,39 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
     __builtin_amdgcn_s_setprio(3);   // the helper waves share SIMDs with compute waves: compute wins issue arbitration
     const int top = (wave > 0) ? 1 : (wg > 0 ? 2 : 0);   // where row 0's top neighbour comes from
     bool ok;
-    if (top == 1) ok = compute_band<1>(sm, g1, W, H, forward, transposed, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
-    else if (top == 2) ok = compute_band<2>(sm, g1, W, H, forward, transposed, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
-    else ok = compute_band<0>(sm, g1, W, H, forward, transposed, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
+    if (top == 1) ok = compute_band<1, TR, FWD>(sm, g1, W, H, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
+    else if (top == 2) ok = compute_band<2, TR, FWD>(sm, g1, W, H, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
+    else ok = compute_band<0, TR, FWD>(sm, g1, W, H, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
     if (!ok) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     return;
   }
 
   if (wave == kWaves) {
-    // ======================= loader: records HBM -> LDS ring, up to kRS steps ahead of each compute wave =======================
+    // ======================= loader: records + gather window HBM -> LDS, up to kRS steps ahead of each compute wave =======================
+    // Window batch b = the 8 texel columns (along the step axis) [8b-16, 8b-8) x kWA texels across the band.
+    // A compute wave working on chunk j (steps 8j..8j+7) reads columns [8j-15, 8j+16], i.e. batches j..j+4,
+    // so chunk j is published only after batch j+4 has landed (batches 2..4 in the prologue).
+    auto win_addr = [&](int w, int b, int t, int& slot) -> const float2* {   // texel t (0..8*kWA-1) of batch b of wave w
+      const int c = TR ? t / kWA : (t & 7), a = TR ? t % kWA : (t >> 3);
+      const int u = 8 * b - 16 + c, v = (band0 + w) * kRows - kRad + a;
+      slot = a * kWC + (u & (kWC - 1));
+      if (t >= 8 * kWA || u < 0 || u >= LS || v < 0 || v >= LB) return nullptr;
+      const int cxc = TR ? v : u, cyc = TR ? u : v;
+      const int x = FWD ? cxc : W - 1 - cxc, y = FWD ? cyc : H - 1 - cyc;
+      return g1 + (y * W + x);
+    };
+    for (int w = 0; w < nact; ++w)
+      for (int b = 2; b <= 3; ++b)
+        for (int k = 0; k < 4; ++k) {
+          int slot; const float2* q = win_addr(w, b, lane + 64 * k, slot);
+          if (q) (&sm.win[w][0][0])[slot] = *q;
+        }
     int idle = 0;
-    float touch = 0.f;
     for (;;) {
       bool progress = false, done = true;
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       float4 va[kWaves], vb[kWaves], vc[kWaves];
+      float2 wv[kWaves][4]; int ws[kWaves][4]; bool wok[kWaves][4];
       int rh[kWaves]; bool ld[kWaves];
 #pragma unroll
       for (int w = 0; w < kWaves; ++w) {
@@ -420,6 +468,13 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
           if (ld[w]) {
             const float4* src = rec + (size_t(band0 + w) * nstepsPad + rh[w]) * (kRows * 3);
             va[w] = src[lane]; vb[w] = src[lane + 64]; vc[w] = src[lane + 128];
+            const int b = rh[w] / kChunk + 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float2* q = win_addr(w, b, lane + 64 * k, ws[w][k]);
+              wok[w][k] = q != nullptr;
+              wv[w][k] = wok[w][k] ? *q : make_float2(0.f, 0.f);
+            }
           }
         }
       }
@@ -428,20 +483,10 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
         if (ld[w]) {
           float4* dst = &sm.rec[w][rh[w] % kRS][0][0];
           dst[lane] = va[w]; dst[lane + 64] = vb[w]; dst[lane + 128] = vc[w];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (wok[w][k]) (&sm.win[w][0][0])[ws[w][k]] = wv[w][k];
           st_cnt(&sm.recHead[w], rh[w] + kChunk);
           progress = true;
-          // touch-ahead: pull the (I1x,I1y) lines these 64 pixels will gather from (around x + C) into this CU's
-          // L1/L2 so the compute wave's dependent gather hits; C (incoming flow) approximates the proposals.
-          const int j = lane >> 3, r = lane & 7, ia = rh[w] + j - r, ib = (band0 + w) * kRows + r;
-          const float4 rb = sm.rec[w][(rh[w] + j) % kRS][r][1];
-          if (ia >= 0 && ia < LS && ib < LB) {
-            const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;
-            const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
-            const float mx = __builtin_fminf(__builtin_fmaxf(float(x) + rb.x, 0.0f), float(W) - 2.0f);
-            const float my = __builtin_fminf(__builtin_fmaxf(float(y) + rb.y, 0.0f), float(H) - 2.0f);
-            const float2* q = g1 + (int(my) * W + int(mx));
-            touch += q[0].x + q[W + 1].x;
-          }
         }
       }
       if (done) break;
@@ -451,7 +496,6 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
         if (++idle > kSpinLimit2 || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
     }
-    if (touch == 1.2345678e-30f) ctrl[1] = 2;   // never true: keeps the touch-ahead loads alive
     return;
   }
 
@@ -575,8 +619,13 @@ void launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
   const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
   hipLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.g0, a.g1, a.blurred, a.gate, a.flow, a.W, a.H, a.forward, tr,
                      nstepsPad, nbandsPad, reinterpret_cast<float4*>(rec));
-  hipLaunchKernelGGL(k_sweep2, dim3(nwg), dim3(64 * (kWaves + 4)), 0, st, reinterpret_cast<const float4*>(rec), a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, a.forward,
-                     tr, nstepsPad, nbands, (float)(1.0 / (double)(float)a.W), (float)(1.0 / (double)kGradEpsilon));
+  const dim3 grid(nwg), block(64 * (kWaves + 4));
+  const float rW = (float)(1.0 / (double)(float)a.W), rEps = (float)(1.0 / (double)kGradEpsilon);
+  const float4* r4 = reinterpret_cast<const float4*>(rec);
+#define PF_LAUNCH_SWEEP2(TRV, FWV) hipLaunchKernelGGL((k_sweep2<TRV, FWV>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps)
+  if (tr) { if (a.forward) PF_LAUNCH_SWEEP2(true, true); else PF_LAUNCH_SWEEP2(true, false); }
+  else { if (a.forward) PF_LAUNCH_SWEEP2(false, true); else PF_LAUNCH_SWEEP2(false, false); }
+#undef PF_LAUNCH_SWEEP2
 }
 
 }  // namespace pf

@@ -159,3 +159,20 @@ def test_sweep_v1_kernel_cross_check(pf, orc):
         assert np.array_equal(c1.stage_sweep(g0, g1, blurred, a, a, flow, fwd), ref)
         assert np.array_equal(c2.stage_sweep(g0, g1, blurred, a, a, flow, fwd), ref)
     c1.close(); c2.close()
+
+
+@pytest.mark.parametrize("w,h", [(140, 100), (100, 140)])
+def test_sweep_large_flows_use_global_fallback(ctx, orc, w, h):
+    """Proposals pointing further than the LDS gather window (+-7 texels) must take the HBM fallback and still be
+    bit-exact; also covers both band orientations (W>H normal, W<H transposed)."""
+    r = np.random.default_rng(5 + w)
+    img0 = r.random((h, w)).astype(np.float32); img1 = r.random((h, w)).astype(np.float32)
+    g0 = np.stack(orc.gradients(img0), -1); g1 = np.stack(orc.gradients(img1), -1)
+    flow = (r.standard_normal((h, w, 2)) * 12.0).astype(np.float32)      # many |flow| > 7, some far outside the image
+    flow[::7, ::5] *= 20.0
+    blurred = orc.gaussian_blur(flow, 15, 8.0)
+    a = np.ones((h, w), np.float32)
+    for fwd in (1, 0):
+        ref = orc.sweep(g0[..., 0], g0[..., 1], g1[..., 0], g1[..., 1], blurred, a, a, flow, fwd)
+        got = ctx.stage_sweep(g0, g1, blurred, a, a, flow, fwd)
+        assert np.array_equal(got, ref), "mismatches %d" % (got != ref).sum()
