@@ -141,7 +141,7 @@ def main():
             ms, n = prof["sweep"]
             bytes_total = 48.0 * P * 4 * args.steps
             ach = bytes_total / (ms * 1e-3) / 1e9
-            res["roofline"] = {"bound": "hbm", "kernel": "k_sweep", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6),
+            res["roofline"] = {"bound": "hbm", "kernel": "k_sweep_prep+k_sweep2", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6),
                                "traffic": None, "launches": n, "avg_launch_us": round(1000 * ms / n, 2),
                                "note": "exact Gauss-Seidel sweep is dependency-latency bound (critical path %d wavefront steps/direction), not HBM bound" % sweep_steps}
         else:
