@@ -128,3 +128,36 @@ def test_cpp_dropin_headers_one_stitch_step(orc, synth, pf, tmp_path):
     assert np.abs(gf.astype(np.int32) - final.astype(np.int32)).max() <= 1 and (gf != final).mean() < 1e-3
     # unknown algorithm name -> VrCamException -> exit code 1 (PixFlow.hpp:499)
     assert subprocess.call([exe, str(cols), str(rows), str(tmp_path / "L.bgra"), str(tmp_path / "R.bgra"), "nope", str(tmp_path / "x")]) == 1
+
+
+@pytest.mark.parametrize("cols,rows", [(52, 52), (61, 53), (201, 157), (96, 300), (300, 96)])
+def test_odd_and_minimal_sizes(ctx, orc, synth, cols, rows):
+    """Smallest pyramid (one level: half-res 26x26), odd sizes, extreme aspect ratios (both band orientations)."""
+    L, R, _ = synth.make_pair_np(cols, rows, 9 + cols)
+    for mp in (0, 20):
+        r0, r1 = orc.flow_bidir(L, R, mp)
+        f0, f1 = ctx.flow_bidir(L, R, mp)
+        assert np.array_equal(f0, r0) and np.array_equal(f1, r1)
+
+
+def test_degenerate_alpha(ctx, orc, synth):
+    """No pixel gated (alpha 0 everywhere in one image) and every pixel gated (alpha 255 everywhere)."""
+    L, R, _ = synth.make_pair_np(160, 120, 3)
+    L0 = L.copy(); L0[..., 3] = 0
+    for a, b in ((L0, R), (L, L0)):
+        r0, r1 = orc.flow_bidir(a, b, 20)
+        f0, f1 = ctx.flow_bidir(a, b, 20)
+        assert np.array_equal(f0, r0) and np.array_equal(f1, r1)
+    Lf = L.copy(); Rf = R.copy(); Lf[..., 3] = 255; Rf[..., 3] = 255
+    r0, r1 = orc.flow_bidir(Lf, Rf, 0)
+    f0, f1 = ctx.flow_bidir(Lf, Rf, 0)
+    assert np.array_equal(f0, r0) and np.array_equal(f1, r1)
+
+
+def test_repeated_calls_and_size_changes_reuse_context(ctx, orc, synth):
+    """The arena grows and is reused; results must not depend on what ran before (stale hand-off state etc.)."""
+    for (cols, rows, seed) in [(240, 200, 1), (128, 96, 2), (240, 200, 1), (320, 256, 3)]:
+        L, R, blend = synth.make_pair_np(cols, rows, seed)
+        r0, r1 = orc.flow_bidir(L, R, 0)
+        out, f0, f1 = ctx.novel_view(L, R, 0, blend)
+        assert np.array_equal(f0, r0) and np.array_equal(f1, r1)
