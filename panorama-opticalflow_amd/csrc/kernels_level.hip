@@ -50,6 +50,17 @@ void launch_gate(hipStream_t st, const float* a0, const float* a1, int n, uint8_
   hipLaunchKernelGGL(k_gate, dim3((n + 255) / 256), dim3(256), 0, st, a0, a1, n, gate);
 }
 
+__global__ __launch_bounds__(256) void k_count_gate(const uint8_t* __restrict__ gate, int n, unsigned* __restrict__ count) {
+  int c = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c += gate[i];
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned)c);
+}
+void launch_count_gate(hipStream_t st, const uint8_t* gate, int n, unsigned* count) {
+  const int blocks = (n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256;
+  hipLaunchKernelGGL(k_count_gate, dim3(blocks), dim3(256), 0, st, gate, n, count);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K5 Gaussian 15x15 s8 on the float2 flow, BORDER_REFLECT_101 (PixFlow.hpp:306-311, :389-394).
 // [OpenCV filter.cpp] row pass = RowFilter (plain left-to-right accumulation), column pass =

@@ -230,7 +230,7 @@ __device__ __forceinline__ bool wait_ge(const int* cnt, int need, int& cached, c
 
 // One compute wave: a band of 8 rows, lane = 8*row + role.  TOP: 0 = image border above, 1 = previous wave
 // of this workgroup (LDS result ring), 2 = previous workgroup (granule ring filled by the poller wave).
-template <int TOP, bool TR, bool FWD>
+template <int TOP, bool TR, bool FWD, bool SPARSE>
 __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict__ g1, int W, int H, int nsteps, int w, int band,
                                              int nact, bool publishes, float rW, float rEps) {
   constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0;
@@ -308,6 +308,11 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       // previous pixel along the step axis = own result of the previous step; previous pixel across = DPP/ring.
       // Reference order is always "previous column, then previous row" (PixFlow.hpp:319-320 / :332-333);
       // a missing neighbour proposes the current flow, which can never be strictly better.
+      float2 fin = C;
+      float4 na = ra, nb = rb, nc = rc;
+      // Sparse overlap (full-canvas inputs, CPU/StitchTool.cpp:17-33): when no pixel of this anti-diagonal is gated
+      // the whole step is bookkeeping only (wave-uniform branch; an ungated pixel keeps its flow, PixFlow.hpp:317).
+      if (!SPARSE || __any(gatev > 0.0f)) {
       const float2 along = (ia > 0) ? prev : C;
       const float2 cross = hasCross ? up : C;
       const float2 L = transposed ? cross : along;
@@ -315,9 +320,8 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       const float2 cand = candIsT ? T : L;
       const float e = d_error_fast<TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, x, y, ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
       // ---- prefetch next step's inputs (LDS) behind the gather ----
-      float4 na = ra, nb = rb, nc = rc;
       if (s + 1 < send) { const float4* rp = &sm.rec[w][(s + 1) % kRS][r][0]; na = rp[0]; nb = rp[1]; nc = rp[2]; }
-      if (TOP != 0 && s + 1 < LS) tv = topin[(s + 1) & topmask];   // plain load: stays in flight behind the gather; a stale 'not ready' only takes the slow path
+      if (TOP != 0 && s + 1 < LS) tv = topin[(s + 1) & topmask];   // plain load; a stale 'not ready' only takes the slow path
       // gather the group's six values in its lane 0 (row_shl:n reads lane+n)
       const float eL = e, exL = dpp<0x101>(e, e), eyL = dpp<0x102>(e, e), eT = dpp<0x103>(e, e), exT = dpp<0x104>(e, e), eyT = dpp<0x105>(e, e);
       // selection in the reference's order: current, then L, then T, strict '<'
@@ -338,9 +342,14 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
           gx = dgx / kGradEpsilon; gy = dgy / kGradEpsilon;
         }
       }
-      float2 fin = make_float2(f.x - kGradientStepSize * gx, f.y - kGradientStepSize * gy);
+      fin = make_float2(f.x - kGradientStepSize * gx, f.y - kGradientStepSize * gy);
       if (!(gatev > 0.0f)) fin = C;
       fin.x = bcast8(fin.x); fin.y = bcast8(fin.y);
+      } else {
+      // ---- prefetch next step's inputs (LDS) behind the gather ----
+      if (s + 1 < send) { const float4* rp = &sm.rec[w][(s + 1) % kRS][r][0]; na = rp[0]; nb = rp[1]; nc = rp[2]; }
+      if (TOP != 0 && s + 1 < LS) tv = topin[(s + 1) & topmask];   // plain load; a stale 'not ready' only takes the slow path
+      }
       if (gatev >= 0.0f) prev = fin;
       // ---- publish: next wave's top ring first (latency critical), then the result ring ----
       if (feedsNext && ia >= 0 && ia < LS) topout[ia & (kTS - 1)] = pack2(fin);
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
 // 512 threads: waves 0-3 compute (one band of 8 rows each), wave 4 loads records, wave 5 publishes the
 // workgroup's last row as granules, wave 6 polls the previous workgroup's granules, wave 7 drains results.
 // ------------------------------------------------------------------------------------------------
-template <bool TR, bool FWD>
+template <bool TR, bool FWD, bool SPARSE>
 __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
                                                 unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H,
                                                 int nstepsPad, int nbands, float rW, float rEps) {
@@ -423,9 +432,9 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
     __builtin_amdgcn_s_setprio(3);   // the helper waves share SIMDs with compute waves: compute wins issue arbitration
     const int top = (wave > 0) ? 1 : (wg > 0 ? 2 : 0);   // where row 0's top neighbour comes from
     bool ok;
-    if (top == 1) ok = compute_band<1, TR, FWD>(sm, g1, W, H, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
-    else if (top == 2) ok = compute_band<2, TR, FWD>(sm, g1, W, H, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
-    else ok = compute_band<0, TR, FWD>(sm, g1, W, H, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
+    if (top == 1) ok = compute_band<1, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
+    else if (top == 2) ok = compute_band<2, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
+    else ok = compute_band<0, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
     if (!ok) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     return;
   }
@@ -622,7 +631,8 @@ void launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
   const dim3 grid(nwg), block(64 * (kWaves + 4));
   const float rW = (float)(1.0 / (double)(float)a.W), rEps = (float)(1.0 / (double)kGradEpsilon);
   const float4* r4 = reinterpret_cast<const float4*>(rec);
-#define PF_LAUNCH_SWEEP2(TRV, FWV) hipLaunchKernelGGL((k_sweep2<TRV, FWV>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps)
+#define PF_LAUNCH_SWEEP2(TRV, FWV) do { if (a.sparse) hipLaunchKernelGGL((k_sweep2<TRV, FWV, true>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps); \
+    else hipLaunchKernelGGL((k_sweep2<TRV, FWV, false>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps); } while (0)
   if (tr) { if (a.forward) PF_LAUNCH_SWEEP2(true, true); else PF_LAUNCH_SWEEP2(true, false); }
   else { if (a.forward) PF_LAUNCH_SWEEP2(false, true); else PF_LAUNCH_SWEEP2(false, false); }
 #undef PF_LAUNCH_SWEEP2

@@ -146,12 +146,12 @@ int check_dims(pf_ctx* c, int cols, int rows, int pad) {
 // One level of one direction (PixFlow.hpp:272-340, gradients excluded: they are precomputed for all levels).
 // flow_a holds the incoming flow and receives the level's result (flow_b, blurred, tmp are scratch).
 struct LevelBufs { float *flow_a, *flow_b, *blurred, *tmp, *rec; };
-void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, const float* a0, const float* a1, const uint8_t* gate, int w, int h,
+void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, const float* a0, const float* a1, const uint8_t* gate, int w, int h, int sparse,
                const LevelBufs& b, unsigned long long* bnd_fwd, unsigned long long* bnd_bwd, int* ctrl_fwd, int* ctrl_bwd, float** result) {
   { PROF(c, st, "gauss15_blurredFlow"); launch_gauss15(st, b.flow_a, b.tmp, b.blurred, w, h, c->g15); }
   SweepArgs sa;
   sa.g0 = reinterpret_cast<const float2*>(g0); sa.g1 = reinterpret_cast<const float2*>(g1);
-  sa.blurred = reinterpret_cast<const float2*>(b.blurred); sa.gate = gate; sa.W = w; sa.H = h;
+  sa.blurred = reinterpret_cast<const float2*>(b.blurred); sa.gate = gate; sa.W = w; sa.H = h; sa.sparse = sparse;
   auto sweep = [&](const SweepArgs& a) { if (c->sweep_version == 1) launch_sweep(st, a); else launch_sweep2(st, a, b.rec); };
   { PROF(c, st, "sweep"); sa.flow = reinterpret_cast<float2*>(b.flow_a); sa.boundary = bnd_fwd; sa.ctrl = ctrl_fwd; sa.forward = 1; sweep(sa); }
   { PROF(c, st, "median5"); launch_median5(st, b.flow_a, b.flow_b, w, h); }
@@ -219,6 +219,17 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
     launch_fill_u64(sm, bnd[d], bnd_total * 2, kNotReady);
     HIPCHK(c, hipMemsetAsync(ctrl[d], 0, size_t(g.n) * 2 * 2 * sizeof(int), sm));
   }
+  // One host decision per pair: are the inputs sparse (full-canvas images whose overlap is a small part,
+  // CPU/StitchTool.cpp:17-33)?  Then the sweep variant that skips ungated anti-diagonals is used.  Costs one
+  // stream sync (the level-0 gate count) before the directions are launched; results are identical either way.
+  unsigned* d_cnt = (unsigned*)ensure(c, "gate_count", 256);
+  if (!d_cnt) return PF_ERR_NOMEM;
+  HIPCHK(c, hipMemsetAsync(d_cnt, 0, 4, sm));
+  launch_count_gate(sm, gate, g.ws[0] * g.hs[0], d_cnt);
+  unsigned h_cnt = 0;
+  HIPCHK(c, hipMemcpyAsync(&h_cnt, d_cnt, 4, hipMemcpyDeviceToHost, sm));
+  HIPCHK(c, hipStreamSynchronize(sm));
+  const int sparse = (double)h_cnt < 0.5 * (double)g.ws[0] * g.hs[0] ? 1 : 0;
   HIPCHK(c, hipEventRecord(c->ev_pre, sm));
 
   // --- the two directions are independent (OpticalFlow.cpp:130-139): one stream each ---
@@ -238,7 +249,7 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
         }
       }
       float* res = nullptr;
-      run_level(c, st, grad[i0] + 2 * o, grad[i1] + 2 * o, pyrA[i0] + o, pyrA[i1] + o, gate + o, w, h, b, bnd[d] + bnd_off[level],
+      run_level(c, st, grad[i0] + 2 * o, grad[i1] + 2 * o, pyrA[i0] + o, pyrA[i1] + o, gate + o, w, h, sparse, b, bnd[d] + bnd_off[level],
                 bnd[d] + bnd_total + bnd_off[level], ctrl[d] + level * 4, ctrl[d] + level * 4 + 2, &res);
       if (level > 0) {
         PROF(c, st, "upsample_cubic");
@@ -603,7 +614,7 @@ int pf_stage_sweep(pf_ctx* c, const float* g0, const float* g1, const float* blu
   launch_fill_u64(sm, bnd, nb, kNotReady);
   HIPCHK(c, hipMemsetAsync(ctrl, 0, 16, sm));
   SweepArgs sa; sa.g0 = (const float2*)dg0; sa.g1 = (const float2*)dg1; sa.blurred = (const float2*)dbl; sa.gate = gate; sa.flow = (float2*)df;
-  sa.boundary = bnd; sa.ctrl = ctrl; sa.W = w; sa.H = h; sa.forward = forward;
+  sa.boundary = bnd; sa.ctrl = ctrl; sa.W = w; sa.H = h; sa.forward = forward; sa.sparse = (w * h) % 2;   // stage test: exercise both variants
   float* rec = (float*)ensure(c, "sg_rec", sweep2_rec_bytes(w, h));
   if (!rec) return PF_ERR_NOMEM;
   { PROF(c, sm, "sweep"); if (c->sweep_version == 1) launch_sweep(sm, sa); else launch_sweep2(sm, sa, rec); }
@@ -670,7 +681,7 @@ int pf_stage_level(pf_ctx* c, const float* i0, const float* i1, const float* a0,
     if (max_pct > 0 && hint != PF_HINT_UNKNOWN) launch_adjust_initial_flow(sm, d0, d1, da0, da1, w, h, hint, max_pct, rt, b.flow_a);
   }
   float* res = nullptr;
-  run_level(c, sm, g0, g1, da0, da1, gate, w, h, b, bnd, bnd + nb, ctrl, ctrl + 2, &res);
+  run_level(c, sm, g0, g1, da0, da1, gate, w, h, (w + h) % 2, b, bnd, bnd + nb, ctrl, ctrl + 2, &res);
   int hc[4] = {0, 0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(hc, ctrl, 16, hipMemcpyDeviceToHost, sm));
   if (int e = stage_down(c, flow_out, res, n * 8)) return e;

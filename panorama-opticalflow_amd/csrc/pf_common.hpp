@@ -84,6 +84,7 @@ void launch_pyr_down4(hipStream_t st, const float* s0, const float* s1, const fl
 // per level
 void launch_gradients(hipStream_t st, const float* img, int w, int h, float* gxy, const Gauss& g3);
 void launch_gate(hipStream_t st, const float* a0, const float* a1, int n, uint8_t* gate);
+void launch_count_gate(hipStream_t st, const uint8_t* gate, int n, unsigned* count /* zeroed by the caller */);
 void launch_gauss15(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const Gauss& g15);
 void launch_gauss15_mix(hipStream_t st, float* flow, float* tmp, const float* a0, const float* a1, int w, int h, const Gauss& g15,
                         float* out);
@@ -101,6 +102,7 @@ struct SweepArgs {
   unsigned long long* boundary;  // [nbands][W] hand-off rows, pre-filled with kNotReady
   int* ctrl;              // [0] ticket, [1] abort/timeout flag
   int W, H, forward;
+  int sparse;             // few pixels gated (full-canvas inputs): use the kernel variant that skips ungated anti-diagonals
 };
 size_t sweep_boundary_elems(int W, int H);   // hand-off granules needed per sweep launch (covers both sweep kernels)
 void launch_sweep(hipStream_t st, const SweepArgs& a);          // v1: 64 rows per wave, kept as a cross-check (PANOFLOW_SWEEP=1)
