@@ -84,6 +84,13 @@ int pf_stitch_prepare(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra,
 int pf_stitch_gather(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, const uint8_t* merged_bgra, size_t step_bytes,
                      const uint8_t* map, size_t map_step_bytes, int cols, int rows, uint8_t* out_bgra, size_t out_step_bytes);
 
+/* One whole iteration of the stitch loop of CPU/main.cpp:70-95 on the device: Stitchtools::prepare ->
+ * NovelViewGeneratorAsymmetricFlow::prepare + generateNovelView -> Stitchtools::Gather.  Only the inputs go up
+ * and only the composite comes down.  r_bgra == NULL chains on the previous call's result, which stays in HBM
+ * (main.cpp:64-65: R_i = FinalResult_{i-1}).  out_bgra may be NULL (intermediate steps). */
+int pf_stitch_step(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, int cols, int rows, size_t step_bytes,
+                   int max_percentage, uint8_t* out_bgra, size_t out_step_bytes);
+
 /* ---- device-resident entry points (packed buffers already in this context's HBM) -----------
  * Same semantics as above; used by bench.py (inputs resident when the clock starts) and by the
  * multi-GPU driver.  Pointers are device pointers on the context's device. */

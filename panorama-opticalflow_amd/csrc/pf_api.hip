@@ -39,6 +39,7 @@ struct pf_ctx {
   Gauss g5, g3_05, g3_1, g15;
   int prof = 0;   // 0 off, 1 every kernel family, 2 only the dominant family (the sweeps): fewer events in a timed region
   int sweep_version = 2;
+  int chain_cols = 0, chain_rows = 0;   // size of the stitch-chain result resident in "ch_final"
   std::vector<std::string> prof_names;
   std::vector<ProfEntry> prof_tot;
   std::vector<ProfPending> prof_pending;
@@ -543,6 +544,42 @@ int pf_stitch_gather(pf_ctx* c, const uint8_t* l, const uint8_t* r, const uint8_
   if (int e = down2d(c, out, ostep, dout, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
   HIPCHK(c, hipGetLastError());
   return finish(c);
+}
+
+
+// One whole iteration of the reference's stitch loop (CPU/main.cpp:70-95) without leaving the device:
+// Stitchtools::prepare -> NovelViewGeneratorAsymmetricFlow::prepare/generateNovelView -> Gather.
+// r_bgra == NULL chains on the previous call's result, which stays resident in HBM (main.cpp:64-65).
+int pf_stitch_step(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int rows, size_t step, int max_pct, uint8_t* out, size_t ostep) {
+  if (int e = use(c)) return e;
+  if (!l || cols <= 0 || rows <= 0 || step < size_t(cols) * 4) return fail(c, PF_ERR_ARG, "bad argument");
+  if (int e = check_dims(c, cols, rows, cols / 20)) return e;
+  const size_t n = size_t(cols) * rows;
+  uint8_t* dl = (uint8_t*)ensure(c, "ch_l", n * 4); uint8_t* dr = (uint8_t*)ensure(c, "ch_r", n * 4); uint8_t* dfin = (uint8_t*)ensure(c, "ch_final", n * 4);
+  uint8_t* dm = (uint8_t*)ensure(c, "st_map", n); uint8_t* dol = (uint8_t*)ensure(c, "st_ovl", n * 4); uint8_t* dor = (uint8_t*)ensure(c, "st_ovr", n * 4);
+  float* db = (float*)ensure(c, "st_blend", n * 4); float* dmd = (float*)ensure(c, "st_md", n * 4); uint8_t* dmerged = (uint8_t*)ensure(c, "st_merged", n * 4);
+  float* f0 = (float*)ensure(c, "nv_flow_l2r", n * 8); float* f1 = (float*)ensure(c, "nv_flow_r2l", n * 8);
+  if (!dl || !dr || !dfin || !dm || !dol || !dor || !db || !dmd || !dmerged || !f0 || !f1) return PF_ERR_NOMEM;
+  hipStream_t sm = c->s_main;
+  if (int e = up2d(c, dl, size_t(cols) * 4, l, step, size_t(cols) * 4, rows)) return e;
+  if (r) { if (int e = up2d(c, dr, size_t(cols) * 4, r, step, size_t(cols) * 4, rows)) return e; }
+  else {
+    if (c->chain_cols != cols || c->chain_rows != rows) return fail(c, PF_ERR_ARG, "pf_stitch_step: no previous result of this size to chain on");
+    HIPCHK(c, hipMemcpyAsync(dr, dfin, n * 4, hipMemcpyDeviceToDevice, sm));
+  }
+  { PROF(c, sm, "match_images"); launch_match_images(sm, dl, dr, cols, rows, dm, dol, dor); }
+  { PROF(c, sm, "countblend"); launch_countblend(sm, dm, cols, rows, db, dmd); }
+  if (int e = blend_smooth_dev(c, db, dmd, cols, rows)) return e;
+  const int hints[2] = {PF_HINT_LEFT, PF_HINT_RIGHT}; float* outs[2] = {f0, f1};
+  const int pad = cols / 20;
+  if (int e = solve(c, dol, dor, cols, rows, pad, max_pct, 2, hints, outs)) return e;
+  { PROF(c, sm, "blend"); launch_blend(sm, dol, dor, f0, f1, db, cols, rows, dmerged); }
+  { PROF(c, sm, "gather"); launch_gather(sm, dl, dr, dmerged, dm, cols, rows, dfin); }
+  if (out) if (int e = down2d(c, out, ostep, dfin, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
+  HIPCHK(c, hipGetLastError());
+  if (int e = finish(c)) return e;
+  c->chain_cols = cols; c->chain_rows = rows;
+  return check_sweeps(c, cols, rows, pad, 2);
 }
 
 // ---- stage-level entry points (tests) ----

@@ -3,6 +3,8 @@
 #ifndef StitchTool_hpp
 #define StitchTool_hpp
 
+#include <string>
+
 #include "util.hpp"
 
 namespace stitch_tools {
@@ -72,6 +74,20 @@ class Stitchtools {
  private:
   Mat ramp_;
 };
+
+// One whole iteration of the stitch loop (CPU/main.cpp:70-95) without leaving the device (pf_stitch_step).
+// colorImageR == nullptr chains on the previous call's result, which stays resident in HBM (main.cpp:64-65).
+static inline Mat stitchStep(const Mat& colorImageL, const Mat* colorImageR, const std::string& flowAlgName) {
+  const int maxPct = pf_max_percentage_by_name(flowAlgName.c_str());
+  if (maxPct < 0) throw util::VrCamException("unrecognized flow algorithm name: " + flowAlgName);
+  if (colorImageL.type() != CV_8UC4 || (colorImageR && (colorImageR->type() != CV_8UC4 || colorImageR->rows != colorImageL.rows ||
+                                                         colorImageR->cols != colorImageL.cols || colorImageR->step != colorImageL.step)))
+    throw util::VrCamException("stitchStep: inputs must be CV_8UC4 images of equal size");
+  Mat out(colorImageL.rows, colorImageL.cols, CV_8UC4);
+  pano::check(pf_stitch_step(pano::context(), colorImageL.data, colorImageR ? colorImageR->data : nullptr, colorImageL.cols, colorImageL.rows,
+                             colorImageL.step, maxPct, out.data, out.step));
+  return out;
+}
 
 }  // namespace stitch_tools
 

@@ -51,7 +51,7 @@ def lib():
 
 EXPORTS = [
     "pf_device_count", "pf_create", "pf_destroy", "pf_last_error", "pf_version", "pf_max_percentage_by_name",
-    "pf_flow", "pf_flow_bidir", "pf_blend", "pf_novel_view", "pf_stitch_prepare", "pf_stitch_gather",
+    "pf_flow", "pf_flow_bidir", "pf_blend", "pf_novel_view", "pf_stitch_prepare", "pf_stitch_gather", "pf_stitch_step",
     "pf_dev_alloc", "pf_dev_free", "pf_upload", "pf_download", "pf_sync",
     "pf_flow_bidir_dev", "pf_blend_dev", "pf_novel_view_dev",
     "pf_stage_preprocess", "pf_stage_pyr_down", "pf_stage_gradients", "pf_stage_gauss", "pf_stage_median5", "pf_stage_sweep",
@@ -156,6 +156,14 @@ class Context:
         out = np.empty((rows, cols, 4), np.uint8)
         self._chk(self.l.pf_stitch_gather(self.h, _p(a), _p(_u8(R)), _p(_u8(merged)), C.c_size_t(cols * 4), _p(_u8(mp)), C.c_size_t(cols), cols, rows,
                                           _p(out), C.c_size_t(cols * 4)))
+        return out
+
+    def stitch_step(self, L, R, max_pct, want_out=True):
+        """One iteration of main.cpp's loop on the device; R=None chains on the previous result kept in HBM."""
+        a = _u8(L); rows, cols, _ = a.shape
+        out = np.empty((rows, cols, 4), np.uint8) if want_out else None
+        self._chk(self.l.pf_stitch_step(self.h, _p(a), None if R is None else _p(_u8(R)), cols, rows, C.c_size_t(cols * 4), max_pct,
+                                        None if out is None else _p(out), C.c_size_t(cols * 4)))
         return out
 
     # ---- device-resident entry points (raw device pointers as ints) ----

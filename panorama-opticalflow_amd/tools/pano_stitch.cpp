@@ -1,6 +1,6 @@
 // Drop-in for the reference's CLI driver (CPU/main.cpp:47-110): same flags, same file names, same
 // 5-step chain (R_i = FinalResult_{i-1}, main.cpp:64-65), same timing lines; all pixel work on the MI355X.
-//   pano_stitch -test_dir <dir> -top_img top.tif -flow_alg pixflow_low|pixflow_search_20 [-steps 5]
+//   pano_stitch -test_dir <dir> -top_img top.tif -flow_alg pixflow_low|pixflow_search_20 [-steps 5] [-fused 0|1]
 // reads <dir>/<top_img> and <dir>/1.tif .. 5.tif (8-bit RGB/RGBA TIFF or PNG), writes ProcessResult{i}.png and
 // FinalResult.png (main.cpp:97-100).
 #include <cstdlib>
@@ -36,6 +36,7 @@ int main(int argc, char** argv) {
     auto flags = parseFlags(argc, argv);
     const std::string FLAGS_test_dir = flags["test_dir"], FLAGS_top_img = flags["top_img"], FLAGS_flow_alg = flags["flow_alg"];
     const int nsteps = flags.count("steps") ? atoi(flags["steps"].c_str()) : 5;
+    const bool fused = !flags.count("fused") || atoi(flags["fused"].c_str()) != 0;   // -fused 0: the reference's object-by-object sequence
     double StartTime = getCurrTimeSec();
     requireArg(FLAGS_test_dir, "test_dir");
     requireArg(FLAGS_top_img, "top_img");
@@ -48,6 +49,10 @@ int main(int argc, char** argv) {
       if (i == 1) colorImageR = colorImageT; else colorImageR = FinalResult;
       colorImageL = pano_io::imreadExceptionOnFail(FLAGS_test_dir + "/" + char(i + 48) + ".tif");
 
+      if (fused) {
+        // same kernels, same results; the step's intermediates and the chained R stay in HBM
+        FinalResult = stitchStep(colorImageL, i == 1 ? &colorImageR : nullptr, FLAGS_flow_alg);
+      } else {
       Stitchtools Stools;
       Stools.prepare(colorImageL, colorImageR);
       Mat overlappedL = Stools.getOverlappedL();
@@ -63,10 +68,11 @@ int main(int argc, char** argv) {
       Stools.setMergedmiddle(novelViewMerged);
       Stools.Gather();
       FinalResult = Stools.getFinalResult();
+      delete novelViewGen;
+      }
 
       if (i == nsteps) pano_io::imwriteExceptionOnFail(FLAGS_test_dir + "/" + "FinalResult.png", FinalResult);
       else pano_io::imwriteExceptionOnFail(FLAGS_test_dir + "/" + "ProcessResult" + char(i + 48) + ".png", FinalResult);
-      delete novelViewGen;
       std::cout << "Part" << i << " Finished!" << "RUNTIME (sec) = " << (getCurrTimeSec() - StepStart) << std::endl;
     }
     std::cout << "TotalRunTime (sec) = " << (getCurrTimeSec() - StartTime) << std::endl;

@@ -42,8 +42,8 @@ def test_cli_rejects_missing_flags_and_bad_files(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("compression", [None, "tiff_lzw", "tiff_adobe_deflate"])
-def test_cli_three_step_chain(tmp_path, orc, synth, compression):
+@pytest.mark.parametrize("compression,fused", [(None, "1"), ("tiff_lzw", "0"), ("tiff_adobe_deflate", "1")])
+def test_cli_three_step_chain(tmp_path, orc, synth, compression, fused):
     cols, rows, n = 480, 320, 3
     top, imgs = synth.make_stitch_set(cols, rows, 77, 5)
     top = top.numpy(); imgs = [im.numpy() for im in imgs[:n]]
@@ -51,7 +51,7 @@ def test_cli_three_step_chain(tmp_path, orc, synth, compression):
     Image.fromarray(_bgra_to_rgba(top), "RGBA").save(tmp_path / "top.tif", **kw)
     for i, im in enumerate(imgs):
         Image.fromarray(_bgra_to_rgba(im), "RGBA").save(tmp_path / ("%d.tif" % (i + 1)), **kw)
-    out = subprocess.run([EXE, "-test_dir", str(tmp_path), "-top_img", "top.tif", "--flow_alg=pixflow_search_20", "-steps", str(n)],
+    out = subprocess.run([EXE, "-test_dir", str(tmp_path), "-top_img", "top.tif", "--flow_alg=pixflow_search_20", "-steps", str(n), "-fused", fused],
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "Part1 Finished!RUNTIME (sec) = " in out.stdout and "TotalRunTime (sec) = " in out.stdout

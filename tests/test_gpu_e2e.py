@@ -161,3 +161,18 @@ def test_repeated_calls_and_size_changes_reuse_context(ctx, orc, synth):
         r0, r1 = orc.flow_bidir(L, R, 0)
         out, f0, f1 = ctx.novel_view(L, R, 0, blend)
         assert np.array_equal(f0, r0) and np.array_equal(f1, r1)
+
+
+def test_fused_stitch_step_equals_object_sequence(ctx, synth):
+    """pf_stitch_step (device-resident iteration, chained R kept in HBM) runs the same kernels as
+    stitch_prepare + novel_view + stitch_gather: identical bytes, step after step."""
+    cols, rows = 480, 320
+    top, imgs = synth.make_stitch_set(cols, rows, 5, 5)
+    top = top.numpy(); imgs = [im.numpy() for im in imgs[:3]]
+    R = top
+    for i, L in enumerate(imgs):
+        mp, ovl, ovr, blend, _ = ctx.stitch_prepare(L, R)
+        merged, _, _ = ctx.novel_view(ovl, ovr, 20, blend)
+        R = ctx.stitch_gather(L, R, merged, mp)
+        fused = ctx.stitch_step(L, top if i == 0 else None, 20)
+        assert np.array_equal(fused, R), "step %d" % (i + 1)
