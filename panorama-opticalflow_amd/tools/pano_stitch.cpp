@@ -1,6 +1,7 @@
 // Drop-in for the reference's CLI driver (CPU/main.cpp:47-110): same flags, same file names, same
 // 5-step chain (R_i = FinalResult_{i-1}, main.cpp:64-65), same timing lines; all pixel work on the MI355X.
 //   pano_stitch -test_dir <dir> -top_img top.tif -flow_alg pixflow_low|pixflow_search_20 [-steps 5] [-fused 0|1]
+//   pano_stitch -inputs 4 -test_dir <dir> -flow_alg ...      the one-pass 4-photo variant (CPU_4Input/main.cpp:45-120)
 // reads <dir>/<top_img> and <dir>/1.tif .. 5.tif (8-bit RGB/RGBA TIFF or PNG), writes ProcessResult{i}.png and
 // FinalResult.png (main.cpp:97-100).
 #include <cstdlib>
@@ -31,12 +32,45 @@ static std::map<std::string, std::string> parseFlags(int argc, char** argv) {   
   return f;
 }
 
+
+// CPU_4Input/main.cpp:54-113: crop every photo to the columns where its centre row is opaque, L = 1 + 3, R = 2 + 4
+// (saturating), then ONE stitch step.  The crop/sum is the driver's own image preparation (byte copies on the host,
+// as in the reference); the stitch step runs on the device.
+static int run4Input(const std::string& dir, const std::string& flow_alg) {
+  double StartTime = getCurrTimeSec();
+  Mat im[4];
+  for (int i = 0; i < 4; ++i) im[i] = pano_io::imreadExceptionOnFail(dir + "/" + char(i + 49) + ".tif");
+  for (int i = 1; i < 4; ++i)
+    if (im[i].rows != im[0].rows || im[i].cols != im[0].cols) throw VrCamException("4-input mode: the four photos must have the same size");
+  const int rows = im[0].rows, cols = im[0].cols;
+  for (int i = 0; i < 4; ++i)
+    for (int x = 0; x < cols; ++x)
+      if (!im[i].at<Vec4b>(rows / 2, x)[3])
+        for (int y = 0; y < rows; ++y) im[i].at<Vec4b>(y, x) = Vec4b(0, 0, 0, 0);
+  Mat colorImageL(rows, cols, CV_8UC4), colorImageR(rows, cols, CV_8UC4);
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols * 4; ++x) {
+      const int l = im[0].ptr<unsigned char>(y)[x] + im[2].ptr<unsigned char>(y)[x], r = im[1].ptr<unsigned char>(y)[x] + im[3].ptr<unsigned char>(y)[x];
+      colorImageL.ptr<unsigned char>(y)[x] = (unsigned char)(l > 255 ? 255 : l);   // cv::Mat + cv::Mat on CV_8U saturates
+      colorImageR.ptr<unsigned char>(y)[x] = (unsigned char)(r > 255 ? 255 : r);
+    }
+  Mat FinalResult = stitchStep(colorImageL, &colorImageR, flow_alg);
+  pano_io::imwriteExceptionOnFail(dir + "/FinalResult.png", FinalResult);
+  std::cout << "TotalRunTime (sec) = " << (getCurrTimeSec() - StartTime) << std::endl;
+  return EXIT_SUCCESS;
+}
+
 int main(int argc, char** argv) {
   try {
     auto flags = parseFlags(argc, argv);
     const std::string FLAGS_test_dir = flags["test_dir"], FLAGS_top_img = flags["top_img"], FLAGS_flow_alg = flags["flow_alg"];
     const int nsteps = flags.count("steps") ? atoi(flags["steps"].c_str()) : 5;
     const bool fused = !flags.count("fused") || atoi(flags["fused"].c_str()) != 0;   // -fused 0: the reference's object-by-object sequence
+    if (flags.count("inputs") && atoi(flags["inputs"].c_str()) == 4) {
+      requireArg(FLAGS_test_dir, "test_dir");
+      requireArg(FLAGS_flow_alg, "flow_alg");
+      return run4Input(FLAGS_test_dir, FLAGS_flow_alg);
+    }
     double StartTime = getCurrTimeSec();
     requireArg(FLAGS_test_dir, "test_dir");
     requireArg(FLAGS_top_img, "top_img");

@@ -64,3 +64,24 @@ def test_cli_three_step_chain(tmp_path, orc, synth, compression, fused):
     # (inherent to the algorithm), so the chain is held to the PSNR bar of BASELINE.md section 4
     assert _psnr(rd("ProcessResult2.png"), ref[1]) >= 50.0
     assert _psnr(rd("FinalResult.png"), ref[2]) >= 45.0
+
+
+@pytest.mark.gpu
+def test_cli_four_input_mode(tmp_path, orc, synth):
+    """CPU_4Input/main.cpp:54-113: centre-row alpha crop, 1+3 -> L, 2+4 -> R (saturating), one stitch step."""
+    cols, rows = 480, 320
+    _, imgs = synth.make_stitch_set(cols, rows, 31, 4)
+    imgs = [im.numpy().copy() for im in imgs]
+    imgs[0][: rows // 2 + 5, 40:60, 3] = 255; imgs[0][rows // 2 + 5:, 40:60] = 0   # columns the centre-row crop must clear
+    for i, im in enumerate(imgs):
+        Image.fromarray(_bgra_to_rgba(im), "RGBA").save(tmp_path / ("%d.tif" % (i + 1)))
+    out = subprocess.run([EXE, "-inputs", "4", "-test_dir", str(tmp_path), "-flow_alg", "pixflow_low"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    cropped = []
+    for im in imgs:
+        c = im.copy(); c[:, im[rows // 2, :, 3] == 0] = 0; cropped.append(c.astype(np.int32))
+    L = np.clip(cropped[0] + cropped[2], 0, 255).astype(np.uint8); R = np.clip(cropped[1] + cropped[3], 0, 255).astype(np.uint8)
+    ref = _oracle_chain(orc, R, [L], 0)[0]
+    got = np.array(Image.open(tmp_path / "FinalResult.png"))[..., [2, 1, 0, 3]]
+    d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3
