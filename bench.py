@@ -137,12 +137,24 @@ def main():
         # roofline of the dominant kernel (the exact wavefront sweep): algorithmic bytes per launch =
         # 48 B per level-pixel (alpha/grad0 16 + blurred 8 + flow r/w 16 + grad1 gather 8)
         # x the level's pixels; 2 sweeps x 2 directions x all levels = 4*48*P bytes per step.
+        # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
+        # figure comes from the committed rocprofv3 --pmc pass of this same command (profiles/, see its note); it only
+        # applies to the default workload.
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_bench.json")
+        if (cols, rows, args.alg) == (2000, 4000, "pixflow_low") and os.path.exists(pmc_path):
+            try:
+                pl = json.load(open(pmc_path))["sweep_per_launch"]
+                traffic = round(0.5 * (pl["traffic_bytes_lo"] + pl["traffic_bytes_hi"]))
+                traffic_src = "profiles/r01_pmc_bench.json (FETCH_SIZE+WRITE_SIZE per sweep launch; read side bracketed [raw,2x raw], midpoint reported)"
+            except Exception:
+                pass
         if "sweep" in prof and prof["sweep"][1] > 0:
             ms, n = prof["sweep"]
             bytes_total = 48.0 * P * 4 * args.steps
             ach = bytes_total / (ms * 1e-3) / 1e9
             res["roofline"] = {"bound": "hbm", "kernel": "k_sweep_prep+k_sweep2", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6),
-                               "traffic": None, "launches": n, "avg_launch_us": round(1000 * ms / n, 2),
+                               "traffic": traffic, "traffic_source": traffic_src, "launches": n, "avg_launch_us": round(1000 * ms / n, 2),
                                "note": "exact Gauss-Seidel sweep is dependency-latency bound (critical path %d wavefront steps/direction), not HBM bound" % sweep_steps}
         else:
             res["roofline"] = {"bound": "hbm", "kernel": "k_sweep", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None}
