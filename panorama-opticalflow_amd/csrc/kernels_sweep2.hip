@@ -164,7 +164,8 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, con
     i1y = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
   }
   const float d2 = (i0x - i1x) * (i0x - i1x) + (i0y - i1y) * (i0y - i1y);
-  const float dt = __builtin_expect(fast_range_ok1(d2), 1) ? sqrt_core(d2) : sqrtf(d2);
+  float dt = sqrt_core(d2);                                   // speculative: the range guard runs beside it, off the dependency chain
+  if (__builtin_expect(!fast_range_ok1(d2), 0)) dt = sqrtf(d2);
   return dt + sm + rv + rh;
 }
 
@@ -336,9 +337,8 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       {
         const float ax = fabsf(dgx), ay = fabsf(dgy);
         const int e0 = __builtin_amdgcn_frexp_expf(ax), e1 = __builtin_amdgcn_frexp_expf(ay);
-        if (__builtin_expect(min(e0, e1) >= -94 && __builtin_fmaxf(ax, ay) <= 0x1p100f, 1)) {
-          gx = div_core(dgx, kGradEpsilon, rEps); gy = div_core(dgy, kGradEpsilon, rEps);
-        } else {
+        gx = div_core(dgx, kGradEpsilon, rEps); gy = div_core(dgy, kGradEpsilon, rEps);   // speculative, guard beside it
+        if (__builtin_expect(!(min(e0, e1) >= -94 && __builtin_fmaxf(ax, ay) <= 0x1p100f), 0)) {
           gx = dgx / kGradEpsilon; gy = dgy / kGradEpsilon;
         }
       }
