@@ -35,7 +35,12 @@ constexpr int kChunk = 8;    // steps streamed per helper iteration and wave
 constexpr int kRad = 8;      // LDS window of the gathered plane: +-kRad texels around the band
 constexpr int kWA = kRows + 2 * kRad + 1;   // window extent across the band (25)
 constexpr int kWC = 64;      // window ring along the step axis (columns)
-constexpr int kSpinLimit2 = 1 << 20;   // ~0.2 s of polling: a stuck band raises ctrl[1] instead of hanging the GPU
+constexpr int kSpinLimit2 = 1 << 20;
+#ifndef PF_SWEEP_UNROLL
+#define PF_SWEEP_UNROLL 2
+#endif
+#define PF_STR2(x) #x
+#define PF_STR(x) PF_STR2(x)   // ~0.2 s of polling: a stuck band raises ctrl[1] instead of hanging the GPU
 
 struct F2x2 { float a, b, c, d; } __attribute__((aligned(8)));
 
@@ -122,17 +127,18 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, con
   const int cxc = FWD ? x0 : W - 1 - x0, cyc = FWD ? y0 : H - 1 - y0;
   const int u0 = TR ? cyc : cxc, v0 = TR ? cxc : cyc;
   constexpr int sg = FWD ? 1 : -1;
-  const int a0 = v0 - ob;
+  // out-of-window lanes are clamped to a valid window row (they read garbage that the HBM path below overwrites)
+  const int a0 = min(max(v0 - ob, FWD ? 0 : 1), FWD ? kWA - 2 : kWA - 1);
   const int o00 = a0 * kWC + (u0 & (kWC - 1)), oal = a0 * kWC + ((u0 + sg) & (kWC - 1));   // +1 along the step axis (ring wrap)
   const int o10 = TR ? o00 + sg * kWC : oal;          // texel (x0+1, y0)
   const int o01 = TR ? oal : o00 + sg * kWC;          // texel (x0, y0+1)
   const int o11 = oal + sg * kWC;                     // texel (x0+1, y0+1)
-  // LDS reads are unconditional (out-of-window lanes read slot 0 and are overwritten below) so that the two
+  // LDS reads are unconditional (out-of-window lanes read a clamped slot and are overwritten below) so that the two
   // address spaces never meet in one pointer -- a merged pointer would turn every access into a slow flat_load.
   typedef float f2v __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) const f2v lds_f2;
   lds_f2* win3 = (lds_f2*)win;   // explicit LDS address space: ds_read_b64, never a flat access
-  const f2v w00 = win3[inwin ? o00 : 0], w10 = win3[inwin ? o10 : 0], w01 = win3[inwin ? o01 : 0], w11 = win3[inwin ? o11 : 0];
+  const f2v w00 = win3[o00], w10 = win3[o10], w01 = win3[o01], w11 = win3[o11];
   float2 t00 = make_float2(w00.x, w00.y), t10 = make_float2(w10.x, w10.y), t01 = make_float2(w01.x, w01.y), t11 = make_float2(w11.x, w11.y);
   if (__builtin_expect(!inwin, 0)) {
     const float2* p = g1 + (y0 * W + x0);
@@ -140,7 +146,7 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, con
   }
   __builtin_amdgcn_sched_barrier(0);
   // ---- B ----
-  const float xR = cx - float(x0), yR = cy - float(y0);
+  const float xR = __builtin_amdgcn_fractf(cx), yR = __builtin_amdgcn_fractf(cy);   // cx, cy >= 0: exactly cx - float(int(cx))
   const float dfx = bx - fdx, dfy = by - fdy;
   const float s2 = dfx * dfx + dfy * dfy;
   const float av = kVerticalRegularizationCoef * fabsf(fdy), ah = kHorizontalRegularizationCoef * fabsf(fdx);
@@ -180,6 +186,11 @@ __device__ __forceinline__ float2 unpack2(unsigned long long v) {
 template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
 __device__ __forceinline__ float dpp(float old, float src) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, BANK_MASK, false));
+}
+// lane i reads lane i+N of its row of 16; lanes whose source falls outside the row read 0 (bound_ctrl), no 'old' operand to set up
+template <int N>
+__device__ __forceinline__ float dpp_shl0(float src) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(src), 0x100 + N, 0xF, 0xF, true));
 }
 // value of lane (8*g) broadcast to the 8 lanes of group g
 __device__ __forceinline__ float bcast8(float v) {
@@ -256,7 +267,12 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   int recAvail = 0;
   bool dead = false;
   unsigned long long tv = kNotReady;   // raw top value for the current step (prefetched during the previous one)
-  if (TOP != 0) tv = topin[0];
+  if (TOP != 0) {
+    tv = topin[0];
+    unsigned tlo = unsigned(tv), thi = unsigned(tv >> 32);
+    asm volatile("" : "+v"(tlo), "+v"(thi));
+    tv = (unsigned long long)tlo | ((unsigned long long)thi << 32);
+  }
   for (int s0 = 0; s0 < nsteps; s0 += kChunk) {
     // ---- once per 8 steps: records of the chunk present, result-ring slots of the chunk free ----
     if (dead) return false;
@@ -272,10 +288,10 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
         if (++spins > kSpinLimit2 || (((spins & 255) == 0) && ld_cnt(&sm.abort))) return false;
       }
     }
-    const int send = (s0 + kChunk < nsteps) ? s0 + kChunk : nsteps;
+    const int send = s0 + kChunk;   // nsteps is a whole number of chunks
     const float4* rp0 = &sm.rec[w][s0 % kRS][r][0];
     float4 ra = rp0[0], rb = rp0[1], rc = rp0[2];
-#pragma unroll 1
+#pragma unroll PF_SWEEP_UNROLL
     for (int s = s0; s < send; ++s) {
       // ---- top neighbour: row r-1's result of the previous step (DPP); row 0 from the ring ----
       float2 up;
@@ -283,7 +299,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       up.y = dpp<0x118, 0xF, 0xC>(prev.y, prev.y);
       up.x = dpp<0x142, 0xE, 0x3>(up.x, prev.x);             // row_bcast:15 -> lanes 0-7 of rows 1..3 (lane 15 of the row above)
       up.y = dpp<0x142, 0xE, 0x3>(up.y, prev.y);
-      if (TOP != 0 && s < LS) {
+      if (TOP != 0) {   // steps s >= LS keep the last valid tv (no prefetch below), row 0 has no pixel there
         if (__builtin_expect(tv == kNotReady, 0)) {
           // at the edge of the producer: wait for this column, then fall one more column behind so that
           // the following steps find their top value already prefetched (one LDS round trip less per step).
@@ -296,9 +312,12 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
             nx = __hip_atomic_load(&topin[last & topmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (++spins > kSpinLimit2 || (((spins & 255) == 0) && ld_cnt(&sm.abort))) { dead = true; break; }
           } while (tv == kNotReady || nx == kNotReady);
+          // leave nothing in flight at the join with the fast path (the compiler would wait there on every step)
+          unsigned tlo = unsigned(tv), thi = unsigned(tv >> 32);
+          asm volatile("" : "+v"(tlo), "+v"(thi) : "v"(unsigned(nx)), "v"(unsigned(nx >> 32)));
+          tv = (unsigned long long)tlo | ((unsigned long long)thi << 32);
         }
         if (r == 0) up = unpack2(tv);
-        if (lane == 0) topin[s & topmask] = kNotReady;       // consumed: the slot is free for column s + ring size
       }
       // ---- the six proposal evaluations, one per lane ----
       const int ia = s - r;                          // index along the step axis
@@ -314,22 +333,23 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       // Sparse overlap (full-canvas inputs, CPU/StitchTool.cpp:17-33): when no pixel of this anti-diagonal is gated
       // the whole step is bookkeeping only (wave-uniform branch; an ungated pixel keeps its flow, PixFlow.hpp:317).
       if (!SPARSE || __any(gatev > 0.0f)) {
-      const float2 along = (ia > 0) ? prev : C;
-      const float2 cross = hasCross ? up : C;
-      const float2 L = transposed ? cross : along;
-      const float2 T = transposed ? along : cross;
+      // a missing neighbour is evaluated anyway (its slot holds a finite stale flow) and masked out of the selection
+      const bool hasAlong = ia > 0;
+      const float2 L = transposed ? up : prev;
+      const float2 T = transposed ? prev : up;
+      const bool okL = transposed ? hasCross : hasAlong, okT = transposed ? hasAlong : hasCross;
       const float2 cand = candIsT ? T : L;
       const float e = d_error_fast<TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, x, y, ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
       // ---- prefetch next step's inputs (LDS) behind the gather ----
       if (s + 1 < send) { const float4* rp = &sm.rec[w][(s + 1) % kRS][r][0]; na = rp[0]; nb = rp[1]; nc = rp[2]; }
       if (TOP != 0 && s + 1 < LS) tv = topin[(s + 1) & topmask];   // plain load; a stale 'not ready' only takes the slow path
       // gather the group's six values in its lane 0 (row_shl:n reads lane+n)
-      const float eL = e, exL = dpp<0x101>(e, e), eyL = dpp<0x102>(e, e), eT = dpp<0x103>(e, e), exT = dpp<0x104>(e, e), eyT = dpp<0x105>(e, e);
+      const float eL = e, exL = dpp_shl0<1>(e), eyL = dpp_shl0<2>(e), eT = dpp_shl0<3>(e), exT = dpp_shl0<4>(e), eyT = dpp_shl0<5>(e);
       // selection in the reference's order: current, then L, then T, strict '<'
-      const bool pickL = eL < eC;
+      const bool pickL = okL && (eL < eC);
       float cur = pickL ? eL : eC, ex = pickL ? exL : exC, ey = pickL ? eyL : eyC;
       float2 f; f.x = pickL ? L.x : C.x; f.y = pickL ? L.y : C.y;
-      const bool pickT = eT < cur;
+      const bool pickT = okT && (eT < cur);
       cur = pickT ? eT : cur; ex = pickT ? exT : ex; ey = pickT ? eyT : ey;
       f.x = pickT ? T.x : f.x; f.y = pickT ? T.y : f.y;
       const float dgx = ex - cur, dgy = ey - cur;
@@ -350,7 +370,15 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       if (s + 1 < send) { const float4* rp = &sm.rec[w][(s + 1) % kRS][r][0]; na = rp[0]; nb = rp[1]; nc = rp[2]; }
       if (TOP != 0 && s + 1 < LS) tv = topin[(s + 1) & topmask];   // plain load; a stale 'not ready' only takes the slow path
       }
-      if (gatev >= 0.0f) prev = fin;
+      if (TOP != 0) {
+        // Touch the prefetched top value BEFORE the stores below: LDS operations return in order, so the wait for it
+        // at the top of the next step would otherwise also wait for this step's publishing stores.
+        unsigned tlo = unsigned(tv), thi = unsigned(tv >> 32);
+        asm volatile("" : "+v"(tlo), "+v"(thi));
+        tv = (unsigned long long)tlo | ((unsigned long long)thi << 32);
+        if (lane == 0) topin[s & topmask] = kNotReady;       // consumed: the slot is free for column s + ring size (columns >= LS are never produced)
+      }
+      prev = fin;   // "no pixel" steps (gate < 0) hand on their zero record: never used as a neighbour (masked / outside the image)
       // ---- publish: next wave's top ring first (latency critical), then the result ring ----
       if (feedsNext && ia >= 0 && ia < LS) topout[ia & (kTS - 1)] = pack2(fin);
       if (k == 0) sm.out[w][s % kOS][r] = fin;
@@ -420,7 +448,7 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
   __syncthreads();
   const int wg = sm.wg;
   const int LS = transposed ? H : W, LB = transposed ? W : H;   // extent along the step axis / across the bands
-  const int nsteps = LS + kRows - 1;
+  const int nsteps = nstepsPad;   // LS + kRows - 1 rounded up to whole chunks: the padding steps carry "no pixel" records
   const int band0 = wg * kWaves;
   const int nact = (nbands - band0) < kWaves ? (nbands - band0) : kWaves;  // active compute waves in this workgroup
   const int lastRowOfWG = band0 * kRows + kWaves * kRows - 1;
