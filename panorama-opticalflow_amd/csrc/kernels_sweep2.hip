@@ -30,7 +30,6 @@ constexpr int kWaves = 4;    // compute waves per workgroup (2 per SIMD: a lone 
 constexpr int kRS = 16;      // record ring (steps)
 constexpr int kOS = 32;      // result ring (steps)
 constexpr int kBS = 256;     // boundary ring (columns)
-constexpr int kTS = 64;      // wave-to-wave top ring (columns); > kOS + 2*kRows so a producer can never lap its consumer
 constexpr int kChunk = 8;    // steps streamed per helper iteration and wave
 constexpr int kRad = 8;      // LDS window of the gathered plane: +-kRad texels around the band
 constexpr int kWA = kRows + 2 * kRad + 1;   // window extent across the band (25)
@@ -202,8 +201,7 @@ struct Smem {
   float4 rec[kWaves][kRS][kRows][3];
   float2 out[kWaves][kOS][kRows];
   float2 win[kWaves][kWA][kWC];           // (I1x,I1y) texels around each band, sweep-order coordinates, ring along the step axis
-  unsigned long long bnd[kBS];            // granules of the previous workgroup's last row (poller -> wave 0); data is its own flag
-  unsigned long long topq[kWaves][kTS];   // last row of wave w-1 -> wave w, indexed by column; data is its own flag
+  unsigned long long bnd[kBS];            // granules of the previous workgroup's last row (poller -> wave 0), valid below bndHead
   int recHead[kWaves];   // steps of records available to wave w        (stream helper -> compute)
   int outHead[kWaves];   // steps completed by wave w                    (compute -> helpers, next wave)
   int outTail[kWaves];   // steps of wave w written to the flow plane    (stream helper -> compute)
@@ -211,6 +209,7 @@ struct Smem {
   int bndHead;           // boundary columns available to wave 0        (granule helper -> compute)
   int abort;
   int wg;
+  int statHits, statSpins;   // -DPF_SWEEP_STATS only
 };
 
 // LDS counters: a wave's LDS operations are executed in issue order by the CU's LDS unit, so "write data,
@@ -241,7 +240,10 @@ __device__ __forceinline__ bool wait_ge(const int* cnt, int need, int& cached, c
 }
 
 // One compute wave: a band of 8 rows, lane = 8*row + role.  TOP: 0 = image border above, 1 = previous wave
-// of this workgroup (LDS result ring), 2 = previous workgroup (granule ring filled by the poller wave).
+// of this workgroup (its LDS result ring), 2 = previous workgroup (granule ring filled by the poller wave).
+// Hand-off protocol: the producer writes its result, then its step counter; the consumer reads the counter,
+// then the value (one wave's LDS operations execute in issue order), one step ahead of use.  The counter is
+// wave-uniform, so the per-step "is my top neighbour there" test is two scalar instructions.
 template <int TOP, bool TR, bool FWD, bool SPARSE>
 __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict__ g1, int W, int H, int nsteps, int w, int band,
                                              int nact, bool publishes, float rW, float rEps) {
@@ -259,66 +261,91 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   const float addx = (kk == 1) ? kGradEpsilon : 0.0f, addy = (kk == 2) ? kGradEpsilon : 0.0f;
   const bool lastPub = publishes && (w == kWaves - 1);
   const bool hasNext = (w + 1 < nact);
-  const bool feedsNext = hasNext && (lane == (kRows - 1) * 8);   // lane 0 of the band's last row
-  unsigned long long* topin = (TOP == 1) ? &sm.topq[w][0] : &sm.bnd[0];
-  const int topmask = (TOP == 1) ? (kTS - 1) : (kBS - 1);
-  unsigned long long* topout = &sm.topq[hasNext ? w + 1 : w][0];
+  // where row 0's top neighbour of column c lives, and the counter that says how many columns are there
+  const int wp = (w > 0) ? w - 1 : 0;
+  const int* topHead = (TOP == 1) ? &sm.outHead[wp] : &sm.bndHead;
+  constexpr int kBias = (TOP == 1) ? kRows - 1 : 0;   // TOP==1: column c is the producer's step c + kRows - 1
+  auto top_slot = [&](int c) -> const unsigned long long* {
+    return (TOP == 1) ? reinterpret_cast<const unsigned long long*>(&sm.out[wp][(c + kRows - 1) % kOS][kRows - 1]) : &sm.bnd[c & (kBS - 1)];
+  };
   float2 prev = make_float2(0.f, 0.f);
-  int recAvail = 0;
   bool dead = false;
-  unsigned long long tv = kNotReady;   // raw top value for the current step (prefetched during the previous one)
-  if (TOP != 0) {
-    tv = topin[0];
-    unsigned tlo = unsigned(tv), thi = unsigned(tv >> 32);
-    asm volatile("" : "+v"(tlo), "+v"(thi));
-    tv = (unsigned long long)tlo | ((unsigned long long)thi << 32);
-  }
+#ifdef PF_SWEEP_STATS
+  int statHits = 0, statSpins = 0;
+  long long statT0 = 0, statWait = 0;
+#endif
+  int avail = 0;                       // columns [0, avail) of the row above are known to be in the ring
+  unsigned long long tv = 0;           // raw top value for the current step (read during the previous one)
+  // flow-control counters for the NEXT chunk, read one chunk ahead (they only grow, a stale value is conservative)
+  int fcRec = 0, fcTail = 0, fcPub = 0, fcNext = 0;
   for (int s0 = 0; s0 < nsteps; s0 += kChunk) {
     // ---- once per 8 steps: records of the chunk present, result-ring slots of the chunk free ----
     if (dead) return false;
-    if (!wait_ge(&sm.recHead[w], s0 + kChunk, recAvail, &sm.abort)) return false;
+#ifdef PF_SWEEP_STATS
+    const long long tw0 = __builtin_readcyclecounter();
+    if (s0 == 0) statT0 = tw0;
+#endif
     {
       int spins = 0;
       for (;;) {   // slot t%kOS may be reused once step t-kOS was written out, published and consumed by the next wave
-        int lim = ld_cnt(&sm.outTail[w]) + kOS;
-        if (lastPub) { const int c1 = ld_cnt(&sm.pubTail) + kOS; lim = lim < c1 ? lim : c1; }
-        if (hasNext) { const int c2 = ld_cnt(&sm.outHead[w + 1]) + kOS + kRows - 1; lim = lim < c2 ? lim : c2; }
-        if (lim >= s0 + kChunk) break;
-        __builtin_amdgcn_s_sleep(1);
+        const int rec = __builtin_amdgcn_readfirstlane(fcRec);
+        int lim = __builtin_amdgcn_readfirstlane(fcTail) + kOS;
+        if (lastPub) { const int c1 = __builtin_amdgcn_readfirstlane(fcPub) + kOS; lim = lim < c1 ? lim : c1; }
+        if (hasNext) { const int c2 = __builtin_amdgcn_readfirstlane(fcNext) + kOS + kRows - 1; lim = lim < c2 ? lim : c2; }
+        if (rec >= s0 + kChunk && lim >= s0 + kChunk) break;
+        if (spins) __builtin_amdgcn_s_sleep(1);
+        fcRec = ld_cnt(&sm.recHead[w]); fcTail = ld_cnt(&sm.outTail[w]);
+        if (lastPub) fcPub = ld_cnt(&sm.pubTail);
+        if (hasNext) fcNext = ld_cnt(&sm.outHead[w + 1]);
         if (++spins > kSpinLimit2 || (((spins & 255) == 0) && ld_cnt(&sm.abort))) return false;
       }
     }
+    // read the counters again for the next chunk; the loads complete in the shadow of this chunk's steps
+    fcRec = ld_cnt(&sm.recHead[w]); fcTail = ld_cnt(&sm.outTail[w]);
+    if (lastPub) fcPub = ld_cnt(&sm.pubTail);
+    if (hasNext) fcNext = ld_cnt(&sm.outHead[w + 1]);
+#ifdef PF_SWEEP_STATS
+    statWait += __builtin_readcyclecounter() - tw0;
+#endif
     const int send = s0 + kChunk;   // nsteps is a whole number of chunks
     const float4* rp0 = &sm.rec[w][s0 % kRS][r][0];
     float4 ra = rp0[0], rb = rp0[1], rc = rp0[2];
 #pragma unroll PF_SWEEP_UNROLL
     for (int s = s0; s < send; ++s) {
-      // ---- top neighbour: row r-1's result of the previous step (DPP); row 0 from the ring ----
-      float2 up;
-      up.x = dpp<0x118, 0xF, 0xC>(prev.x, prev.x);           // row_shr:8 into lanes 8-15 of each row of 16
-      up.y = dpp<0x118, 0xF, 0xC>(prev.y, prev.y);
+      // ---- top neighbour: row r-1's result of the previous step (DPP); row 0 of the band from the ring ----
+      float2 up = prev;   // lanes the two DPP moves do not write (row 0 of the band) keep this: the ring value when there is one
+      if (TOP != 0) {
+        if (__builtin_expect(s >= avail, 0)) {
+          if (s < LS) {
+            // at the edge of the producer: wait for this column and the next one, i.e. fall one more column behind,
+            // so that the following steps find their top value already read (one LDS round trip less per step).
+            // No early exit from the hot loop: a timeout only marks the band dead (checked once per chunk).
+            const int need = (s + 2 < LS) ? s + 2 : LS;
+            int spins = 0;
+#ifdef PF_SWEEP_STATS
+            ++statHits;
+#endif
+            for (;;) {
+              avail = __builtin_amdgcn_readfirstlane(ld_cnt(topHead)) - kBias;
+              if (avail >= need) break;
+              if (++spins > kSpinLimit2 || (((spins & 255) == 0) && ld_cnt(&sm.abort))) { dead = true; avail = 0x7fffffff; break; }
+            }
+#ifdef PF_SWEEP_STATS
+            statSpins += spins;
+#endif
+            tv = __hip_atomic_load(top_slot(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // leave nothing in flight at the join with the fast path (the compiler would wait there on every step)
+            unsigned tlo = unsigned(tv), thi = unsigned(tv >> 32);
+            asm volatile("" : "+v"(tlo), "+v"(thi));
+            tv = (unsigned long long)tlo | ((unsigned long long)thi << 32);
+          }
+        }
+        up = unpack2(tv);
+      }
+      up.x = dpp<0x118, 0xF, 0xC>(up.x, prev.x);             // row_shr:8 into lanes 8-15 of each row of 16
+      up.y = dpp<0x118, 0xF, 0xC>(up.y, prev.y);
       up.x = dpp<0x142, 0xE, 0x3>(up.x, prev.x);             // row_bcast:15 -> lanes 0-7 of rows 1..3 (lane 15 of the row above)
       up.y = dpp<0x142, 0xE, 0x3>(up.y, prev.y);
-      if (TOP != 0) {   // steps s >= LS keep the last valid tv (no prefetch below), row 0 has no pixel there
-        if (__builtin_expect(tv == kNotReady, 0)) {
-          // at the edge of the producer: wait for this column, then fall one more column behind so that
-          // the following steps find their top value already prefetched (one LDS round trip less per step).
-          // No early exit from the hot loop: a timeout only marks the band dead (checked once per chunk).
-          const int last = (s + 1 < LS) ? s + 1 : LS - 1;
-          int spins = 0;
-          unsigned long long nx;
-          do {
-            tv = __hip_atomic_load(&topin[s & topmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            nx = __hip_atomic_load(&topin[last & topmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (++spins > kSpinLimit2 || (((spins & 255) == 0) && ld_cnt(&sm.abort))) { dead = true; break; }
-          } while (tv == kNotReady || nx == kNotReady);
-          // leave nothing in flight at the join with the fast path (the compiler would wait there on every step)
-          unsigned tlo = unsigned(tv), thi = unsigned(tv >> 32);
-          asm volatile("" : "+v"(tlo), "+v"(thi) : "v"(unsigned(nx)), "v"(unsigned(nx >> 32)));
-          tv = (unsigned long long)tlo | ((unsigned long long)thi << 32);
-        }
-        if (r == 0) up = unpack2(tv);
-      }
       // ---- the six proposal evaluations, one per lane ----
       const int ia = s - r;                          // index along the step axis
       const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;
@@ -326,10 +353,10 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       const float2 C = make_float2(rb.x, rb.y);
       const float eC = rb.z, exC = rb.w, eyC = rc.x, gatev = rc.y;
       // previous pixel along the step axis = own result of the previous step; previous pixel across = DPP/ring.
-      // Reference order is always "previous column, then previous row" (PixFlow.hpp:319-320 / :332-333);
-      // a missing neighbour proposes the current flow, which can never be strictly better.
+      // Reference order is always "previous column, then previous row" (PixFlow.hpp:319-320 / :332-333).
       float2 fin = C;
       float4 na = ra, nb = rb, nc = rc;
+      int hN = 0; unsigned long long tvN = tv;
       // Sparse overlap (full-canvas inputs, CPU/StitchTool.cpp:17-33): when no pixel of this anti-diagonal is gated
       // the whole step is bookkeeping only (wave-uniform branch; an ungated pixel keeps its flow, PixFlow.hpp:317).
       if (!SPARSE || __any(gatev > 0.0f)) {
@@ -340,9 +367,9 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       const bool okL = transposed ? hasCross : hasAlong, okT = transposed ? hasAlong : hasCross;
       const float2 cand = candIsT ? T : L;
       const float e = d_error_fast<TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, x, y, ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
-      // ---- prefetch next step's inputs (LDS) behind the gather ----
+      // ---- next step's inputs (LDS) behind the gather: records, producer counter, then the top value ----
       if (s + 1 < send) { const float4* rp = &sm.rec[w][(s + 1) % kRS][r][0]; na = rp[0]; nb = rp[1]; nc = rp[2]; }
-      if (TOP != 0 && s + 1 < LS) tv = topin[(s + 1) & topmask];   // plain load; a stale 'not ready' only takes the slow path
+      if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(top_slot(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
       // gather the group's six values in its lane 0 (row_shl:n reads lane+n)
       const float eL = e, exL = dpp_shl0<1>(e), eyL = dpp_shl0<2>(e), eT = dpp_shl0<3>(e), exT = dpp_shl0<4>(e), eyT = dpp_shl0<5>(e);
       // selection in the reference's order: current, then L, then T, strict '<'
@@ -366,26 +393,31 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       if (!(gatev > 0.0f)) fin = C;
       fin.x = bcast8(fin.x); fin.y = bcast8(fin.y);
       } else {
-      // ---- prefetch next step's inputs (LDS) behind the gather ----
       if (s + 1 < send) { const float4* rp = &sm.rec[w][(s + 1) % kRS][r][0]; na = rp[0]; nb = rp[1]; nc = rp[2]; }
-      if (TOP != 0 && s + 1 < LS) tv = topin[(s + 1) & topmask];   // plain load; a stale 'not ready' only takes the slow path
+      if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(top_slot(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
       }
       if (TOP != 0) {
-        // Touch the prefetched top value BEFORE the stores below: LDS operations return in order, so the wait for it
-        // at the top of the next step would otherwise also wait for this step's publishing stores.
-        unsigned tlo = unsigned(tv), thi = unsigned(tv >> 32);
+        // Take the values read ahead BEFORE the stores below: LDS operations return in order, so a wait for them
+        // at the top of the next step would also wait for this step's publishing stores.
+        avail = __builtin_amdgcn_readfirstlane(hN) - kBias;
+        unsigned tlo = unsigned(tvN), thi = unsigned(tvN >> 32);
         asm volatile("" : "+v"(tlo), "+v"(thi));
         tv = (unsigned long long)tlo | ((unsigned long long)thi << 32);
-        if (lane == 0) topin[s & topmask] = kNotReady;       // consumed: the slot is free for column s + ring size (columns >= LS are never produced)
       }
       prev = fin;   // "no pixel" steps (gate < 0) hand on their zero record: never used as a neighbour (masked / outside the image)
-      // ---- publish: next wave's top ring first (latency critical), then the result ring ----
-      if (feedsNext && ia >= 0 && ia < LS) topout[ia & (kTS - 1)] = pack2(fin);
-      if (k == 0) sm.out[w][s % kOS][r] = fin;
+      // ---- publish: result ring (all 8 lanes of a row store the same value to the same slot), then the step counter ----
+      sm.out[w][s % kOS][r] = fin;
       st_cnt(&sm.outHead[w], s + 1);
       ra = na; rb = nb; rc = nc;
     }
   }
+#ifdef PF_SWEEP_STATS
+  if (lane == 0) {
+    atomicAdd(&sm.statHits, statHits); atomicAdd(&sm.statSpins, statSpins);
+    if (band < 8 || band % 16 == 0) printf("band %d: %lld cycles, %lld in chunk-start waits, %d edge waits, %d spins, nsteps %d\n", band,
+           (long long)__builtin_readcyclecounter() - statT0, statWait, statHits, statSpins, nsteps);
+  }
+#endif
   return !dead;
 }
 
@@ -440,11 +472,9 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
   const int lane = tid & 63;
   if (tid == 0) {
     sm.wg = atomicAdd(&ctrl[0], 1);
-    sm.bndHead = 0; sm.abort = 0; sm.pubTail = 0;
+    sm.bndHead = 0; sm.abort = 0; sm.pubTail = 0; sm.statHits = 0; sm.statSpins = 0;
   }
   if (tid < kWaves) { sm.recHead[tid] = 0; sm.outHead[tid] = 0; sm.outTail[tid] = 0; }
-  for (int i = tid; i < kBS; i += blockDim.x) sm.bnd[i] = kNotReady;
-  for (int i = tid; i < kWaves * kTS; i += blockDim.x) (&sm.topq[0][0])[i] = kNotReady;
   __syncthreads();
   const int wg = sm.wg;
   const int LS = transposed ? H : W, LB = transposed ? W : H;   // extent along the step axis / across the bands
@@ -464,6 +494,9 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
     else if (top == 2) ok = compute_band<2, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
     else ok = compute_band<0, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
     if (!ok) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#ifdef PF_SWEEP_STATS
+    if (lane == 0) { atomicAdd(&ctrl[2], atomicExch(&sm.statHits, 0)); atomicAdd(&ctrl[3], atomicExch(&sm.statSpins, 0)); }
+#endif
     return;
   }
 

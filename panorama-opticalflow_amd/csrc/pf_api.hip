@@ -659,6 +659,7 @@ int pf_stage_sweep(pf_ctx* c, const float* g0, const float* g1, const float* blu
   HIPCHK(c, hipMemcpyAsync(hc, ctrl, 16, hipMemcpyDeviceToHost, sm));
   if (int e = stage_down(c, flow, df, n * 8)) return e;
   if (hc[1]) return fail(c, PF_ERR_TIMEOUT, "sweep band timed out");
+  if (getenv("PANOFLOW_SWEEP_STATS")) fprintf(stderr, "[panoflow] sweep %dx%d: edge waits %d, spin iterations %d (needs a -DPF_SWEEP_STATS build)\n", w, h, hc[2], hc[3]);
   return 0;
 }
 int pf_stage_diffusion(pf_ctx* c, const float* a0, const float* a1, float* flow, int w, int h) {
