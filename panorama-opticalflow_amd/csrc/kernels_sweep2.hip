@@ -107,19 +107,26 @@ __device__ __forceinline__ bool fast_range_ok1(float v) {
   return __builtin_amdgcn_frexp_expf(v) >= -94 && v <= 0x1p100f;
 }
 
-// errorFunction with the fast exact forms; falls back to the IEEE sequence when an operand leaves their range.
+// lane i reads lane i+N of its row of 16; lanes whose source falls outside the row read 0 (bound_ctrl), no 'old' operand to set up
+template <int N>
+__device__ __forceinline__ float dpp_shl0(float src) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(src), 0x100 + N, 0xF, 0xF, true));
+}
+// errorFunction with the fast exact forms.  They are only exact inside a range (see sqrt_core / div_core): instead of
+// branching at every use, the caller keeps a running (min exponent, max magnitude) of every operand that went through
+// them and redoes the whole step with the IEEE sequence if the range was ever left (practically never).
 // The four bilinear texels come from the band's LDS window (filled by the loader wave) when the proposal points
 // within +-(kRad-1) texels of the pixel, otherwise from HBM.  Scheduled in three phases: (A) addresses + issue of
 // the texel reads, (B) every term that does not need the texels (smoothness, the two regularisers) in the shadow
 // of their latency, (C) bilinear + data term.  sched_barrier keeps the compiler from sinking B below the wait.
 template <bool TR, bool FWD>
 __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, const float2* __restrict__ win, int ob, int W, int H, float wm2, float hm2,
-                                              float fW, float rW, int x, int y, float i0x, float i0y, float bx, float by, float fdx, float fdy) {
+                                              float fW, float rW, float fx, float fy, float i0x, float i0y, float bx, float by, float fdx, float fdy,
+                                              int& emin, float& vmax) {
   // ---- A ----
-  const float fx = float(x), fy = float(y);
   const float matchX = fx + fdx, matchY = fy + fdy;
-  const float cx = __builtin_fminf(__builtin_fmaxf(matchX, 0.0f), wm2);   // min(w-2, max(0, v)), std::min/max semantics (NaN -> 0)
-  const float cy = __builtin_fminf(__builtin_fmaxf(matchY, 0.0f), hm2);
+  const float cx = __builtin_amdgcn_fmed3f(matchX, 0.0f, wm2);   // min(w-2, max(0, v)) incl. NaN -> 0 (med3 with a NaN input returns min3)
+  const float cy = __builtin_amdgcn_fmed3f(matchY, 0.0f, hm2);
   const int x0 = int(cx), y0 = int(cy);
   const bool inwin = (fabsf(cx - fx) <= float(kRad - 1)) && (fabsf(cy - fy) <= float(kRad - 1));
   // sweep-order coordinates of texel (x0,y0): u along the step axis, v across the bands
@@ -149,12 +156,9 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, con
   const float dfx = bx - fdx, dfy = by - fdy;
   const float s2 = dfx * dfx + dfy * dfy;
   const float av = kVerticalRegularizationCoef * fabsf(fdy), ah = kHorizontalRegularizationCoef * fabsf(fdx);
-  float sm, rv, rh;
-  if (__builtin_expect(fast_range_ok(s2, av, ah, 1.0f), 1)) {
-    sm = sqrt_core(s2) * kSmoothnessCoef; rv = div_core(av, fW, rW); rh = div_core(ah, fW, rW);
-  } else {
-    sm = sqrtf(s2) * kSmoothnessCoef; rv = av / fW; rh = ah / fW;
-  }
+  const float sm = sqrt_core(s2) * kSmoothnessCoef, rv = div_core(av, fW, rW), rh = div_core(ah, fW, rW);
+  emin = min(min(__builtin_amdgcn_frexp_expf(s2), __builtin_amdgcn_frexp_expf(av)), __builtin_amdgcn_frexp_expf(ah));   // 0 for a zero operand
+  vmax = __builtin_fmaxf(__builtin_fmaxf(s2, av), ah);
   __builtin_amdgcn_sched_barrier(0);
   // ---- C ----
   float i1x, i1y;
@@ -169,9 +173,36 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, con
     i1y = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
   }
   const float d2 = (i0x - i1x) * (i0x - i1x) + (i0y - i1y) * (i0y - i1y);
-  float dt = sqrt_core(d2);                                   // speculative: the range guard runs beside it, off the dependency chain
-  if (__builtin_expect(!fast_range_ok1(d2), 0)) dt = sqrtf(d2);
-  return dt + sm + rv + rh;
+  emin = min(emin, __builtin_amdgcn_frexp_expf(d2));
+  vmax = __builtin_fmaxf(vmax, d2);
+  return sqrt_core(d2) + sm + rv + rh;
+}
+
+// The tail of a step for the lane that owns the pixel (lane 0 of its group of 8): gather the six values, select in the
+// reference's order (current, then L, then T, strict '<'), forward-difference gradient step.  FAST uses div_core and
+// extends the running range guard; !FAST is the IEEE sequence.
+template <bool FAST>
+__device__ __forceinline__ float2 select_step(float e, float eC, float exC, float eyC, float2 C, float2 L, float2 T, bool okL, bool okT, float rEps,
+                                              int& emin, float& vmax) {
+  // gather the group's six values in its lane 0 (row_shl:n reads lane+n)
+  const float eL = e, exL = dpp_shl0<1>(e), eyL = dpp_shl0<2>(e), eT = dpp_shl0<3>(e), exT = dpp_shl0<4>(e), eyT = dpp_shl0<5>(e);
+  const bool pickL = okL && (eL < eC);
+  float cur = pickL ? eL : eC, ex = pickL ? exL : exC, ey = pickL ? eyL : eyC;
+  float2 f; f.x = pickL ? L.x : C.x; f.y = pickL ? L.y : C.y;
+  const bool pickT = okT && (eT < cur);
+  cur = pickT ? eT : cur; ex = pickT ? exT : ex; ey = pickT ? eyT : ey;
+  f.x = pickT ? T.x : f.x; f.y = pickT ? T.y : f.y;
+  const float dgx = ex - cur, dgy = ey - cur;
+  float gx, gy;
+  if (FAST) {
+    const float ax = fabsf(dgx), ay = fabsf(dgy);
+    gx = div_core(dgx, kGradEpsilon, rEps); gy = div_core(dgy, kGradEpsilon, rEps);
+    emin = min(emin, min(__builtin_amdgcn_frexp_expf(ax), __builtin_amdgcn_frexp_expf(ay)));
+    vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(ax, ay));
+  } else {
+    gx = dgx / kGradEpsilon; gy = dgy / kGradEpsilon;
+  }
+  return make_float2(f.x - kGradientStepSize * gx, f.y - kGradientStepSize * gy);
 }
 
 __device__ __forceinline__ unsigned long long pack2(float2 f) {
@@ -185,11 +216,6 @@ __device__ __forceinline__ float2 unpack2(unsigned long long v) {
 template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
 __device__ __forceinline__ float dpp(float old, float src) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, BANK_MASK, false));
-}
-// lane i reads lane i+N of its row of 16; lanes whose source falls outside the row read 0 (bound_ctrl), no 'old' operand to set up
-template <int N>
-__device__ __forceinline__ float dpp_shl0(float src) {
-  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(src), 0x100 + N, 0xF, 0xF, true));
 }
 // value of lane (8*g) broadcast to the 8 lanes of group g
 __device__ __forceinline__ float bcast8(float v) {
@@ -274,6 +300,11 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   int statHits = 0, statSpins = 0;
   long long statT0 = 0, statWait = 0;
 #endif
+  // image coordinates of this lane's pixel: across the bands (constant) and along the step axis (s - r in sweep order)
+  const int LBx = transposed ? W : H;
+  const float fcross = float(forward ? ib : LBx - 1 - ib);
+  const float fLast = float(LS - 1);
+  float fpos = forward ? float(-r) : float(LS - 1 + r);
   int avail = 0;                       // columns [0, avail) of the row above are known to be in the ring
   unsigned long long tv = 0;           // raw top value for the current step (read during the previous one)
   // flow-control counters for the NEXT chunk, read one chunk ahead (they only grow, a stale value is conservative)
@@ -347,55 +378,44 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       up.x = dpp<0x142, 0xE, 0x3>(up.x, prev.x);             // row_bcast:15 -> lanes 0-7 of rows 1..3 (lane 15 of the row above)
       up.y = dpp<0x142, 0xE, 0x3>(up.y, prev.y);
       // ---- the six proposal evaluations, one per lane ----
-      const int ia = s - r;                          // index along the step axis
-      const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;
-      const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;   // only used when the record says the pixel exists
+      // fpos = this pixel's image coordinate along the step axis (exact small integers in fp32), +-1 per step
+      const float fx = transposed ? fcross : fpos, fy = transposed ? fpos : fcross;
       const float2 C = make_float2(rb.x, rb.y);
       const float eC = rb.z, exC = rb.w, eyC = rc.x, gatev = rc.y;
       // previous pixel along the step axis = own result of the previous step; previous pixel across = DPP/ring.
       // Reference order is always "previous column, then previous row" (PixFlow.hpp:319-320 / :332-333).
       float2 fin = C;
-      float4 na = ra, nb = rb, nc = rc;
+      float4 na, nb, nc;
       int hN = 0; unsigned long long tvN = tv;
+      // next step's inputs (LDS): records (unconditional: past the chunk it reads a slot that is reloaded at the chunk
+      // start anyway), producer counter, then the top value.  Issued behind the gather inside the evaluation below.
+      const float4* rpn = &sm.rec[w][(s + 1) % kRS][r][0];
       // Sparse overlap (full-canvas inputs, CPU/StitchTool.cpp:17-33): when no pixel of this anti-diagonal is gated
       // the whole step is bookkeeping only (wave-uniform branch; an ungated pixel keeps its flow, PixFlow.hpp:317).
       if (!SPARSE || __any(gatev > 0.0f)) {
       // a missing neighbour is evaluated anyway (its slot holds a finite stale flow) and masked out of the selection
-      const bool hasAlong = ia > 0;
+      const bool hasAlong = forward ? (fpos > 0.0f) : (fpos < fLast);
       const float2 L = transposed ? up : prev;
       const float2 T = transposed ? prev : up;
       const bool okL = transposed ? hasCross : hasAlong, okT = transposed ? hasAlong : hasCross;
       const float2 cand = candIsT ? T : L;
-      const float e = d_error_fast<TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, x, y, ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
-      // ---- next step's inputs (LDS) behind the gather: records, producer counter, then the top value ----
-      if (s + 1 < send) { const float4* rp = &sm.rec[w][(s + 1) % kRS][r][0]; na = rp[0]; nb = rp[1]; nc = rp[2]; }
+      int emin; float vmax;
+      float e = d_error_fast<TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, fx, fy, ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy, emin, vmax);
+      na = rpn[0]; nb = rpn[1]; nc = rpn[2];
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(top_slot(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-      // gather the group's six values in its lane 0 (row_shl:n reads lane+n)
-      const float eL = e, exL = dpp_shl0<1>(e), eyL = dpp_shl0<2>(e), eT = dpp_shl0<3>(e), exT = dpp_shl0<4>(e), eyT = dpp_shl0<5>(e);
-      // selection in the reference's order: current, then L, then T, strict '<'
-      const bool pickL = okL && (eL < eC);
-      float cur = pickL ? eL : eC, ex = pickL ? exL : exC, ey = pickL ? eyL : eyC;
-      float2 f; f.x = pickL ? L.x : C.x; f.y = pickL ? L.y : C.y;
-      const bool pickT = okT && (eT < cur);
-      cur = pickT ? eT : cur; ex = pickT ? exT : ex; ey = pickT ? eyT : ey;
-      f.x = pickT ? T.x : f.x; f.y = pickT ? T.y : f.y;
-      const float dgx = ex - cur, dgy = ey - cur;
-      float gx, gy;
-      {
-        const float ax = fabsf(dgx), ay = fabsf(dgy);
-        const int e0 = __builtin_amdgcn_frexp_expf(ax), e1 = __builtin_amdgcn_frexp_expf(ay);
-        gx = div_core(dgx, kGradEpsilon, rEps); gy = div_core(dgy, kGradEpsilon, rEps);   // speculative, guard beside it
-        if (__builtin_expect(!(min(e0, e1) >= -94 && __builtin_fmaxf(ax, ay) <= 0x1p100f), 0)) {
-          gx = dgx / kGradEpsilon; gy = dgy / kGradEpsilon;
-        }
+      fin = select_step<true>(e, eC, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
+      if (__builtin_expect(__any(emin < -94 || !(vmax <= 0x1p100f)), 0)) {
+        // an operand left the range where the fast forms are exact: the whole wave redoes the step with IEEE sqrt and division
+        e = d_error2(g1, W, wm2, hm2, fW, int(fx), int(fy), ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
+        fin = select_step<false>(e, eC, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
       }
-      fin = make_float2(f.x - kGradientStepSize * gx, f.y - kGradientStepSize * gy);
       if (!(gatev > 0.0f)) fin = C;
       fin.x = bcast8(fin.x); fin.y = bcast8(fin.y);
       } else {
-      if (s + 1 < send) { const float4* rp = &sm.rec[w][(s + 1) % kRS][r][0]; na = rp[0]; nb = rp[1]; nc = rp[2]; }
+      na = rpn[0]; nb = rpn[1]; nc = rpn[2];
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(top_slot(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
       }
+      fpos += forward ? 1.0f : -1.0f;
       if (TOP != 0) {
         // Take the values read ahead BEFORE the stores below: LDS operations return in order, so a wait for them
         // at the top of the next step would also wait for this step's publishing stores.

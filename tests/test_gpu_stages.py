@@ -176,3 +176,26 @@ def test_sweep_large_flows_use_global_fallback(ctx, orc, w, h):
         ref = orc.sweep(g0[..., 0], g0[..., 1], g1[..., 0], g1[..., 1], blurred, a, a, flow, fwd)
         got = ctx.stage_sweep(g0, g1, blurred, a, a, flow, fwd)
         assert np.array_equal(got, ref), "mismatches %d" % (got != ref).sum()
+
+
+@pytest.mark.parametrize("w,h", [(96, 40), (40, 96)])
+def test_sweep_operands_outside_fast_math_range(ctx, orc, w, h):
+    """The sweep kernel's cheap exact sqrt/division are only valid for operands that are 0 or in [2^-95, 2^100]; any
+    step that sees something else must be redone with the IEEE sequence.  Plant tiny (1e-33 .. 1e-40, incl. denormal)
+    and huge (1e31) flow components and flow/blurred differences and demand bit-equality with the oracle."""
+    r = np.random.default_rng(11 + w)
+    img0 = r.random((h, w)).astype(np.float32); img1 = r.random((h, w)).astype(np.float32)
+    g0 = np.stack(orc.gradients(img0), -1); g1 = np.stack(orc.gradients(img1), -1)
+    flow = (r.standard_normal((h, w, 2)) * 1.5).astype(np.float32)
+    blurred = orc.gaussian_blur(flow, 15, 8.0)
+    flow[3::11, 2::7, 1] = np.float32(1e-33)            # regulariser operand 0.01*|f.y| ~ 1e-35 < 2^-95
+    flow[5::13, 1::9, 0] = np.float32(-3e-39)           # denormal
+    flow[7::17, 4::10, :] = np.float32(1e31)            # > 2^100
+    blurred[2::9, 3::8, :] = flow[2::9, 3::8, :] + np.float32(1e-20)   # smoothness operand ~ 1e-40
+    g0[1::6, 5::12, :] = g1[1::6, 5::12, :] + np.float32(1e-25)        # data-term operand ~ 1e-50 where the flow is ~0
+    flow[1::6, 5::12, :] = 0.0
+    a = np.ones((h, w), np.float32)
+    for fwd in (1, 0):
+        ref = orc.sweep(g0[..., 0], g0[..., 1], g1[..., 0], g1[..., 1], blurred, a, a, flow, fwd)
+        got = ctx.stage_sweep(g0, g1, blurred, a, a, flow, fwd)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "mismatches %d" % (got.view(np.uint32) != ref.view(np.uint32)).sum()
