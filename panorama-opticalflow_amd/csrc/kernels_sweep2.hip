@@ -309,6 +309,8 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   unsigned long long tv = 0;           // raw top value for the current step (read during the previous one)
   // flow-control counters for the NEXT chunk, read one chunk ahead (they only grow, a stale value is conservative)
   int fcRec = 0, fcTail = 0, fcPub = 0, fcNext = 0;
+  float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;   // this step's record (read one step ahead)
+  float2 rc = make_float2(0.f, 0.f);                          // only the first half of the record's third quad is used
   for (int s0 = 0; s0 < nsteps; s0 += kChunk) {
     // ---- once per 8 steps: records of the chunk present, result-ring slots of the chunk free ----
     if (dead) return false;
@@ -323,12 +325,19 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
         int lim = __builtin_amdgcn_readfirstlane(fcTail) + kOS;
         if (lastPub) { const int c1 = __builtin_amdgcn_readfirstlane(fcPub) + kOS; lim = lim < c1 ? lim : c1; }
         if (hasNext) { const int c2 = __builtin_amdgcn_readfirstlane(fcNext) + kOS + kRows - 1; lim = lim < c2 ? lim : c2; }
-        if (rec >= s0 + kChunk && lim >= s0 + kChunk) break;
+        if (__builtin_expect(rec >= s0 + kChunk && lim >= s0 + kChunk, 1)) break;
         if (spins) __builtin_amdgcn_s_sleep(1);
         fcRec = ld_cnt(&sm.recHead[w]); fcTail = ld_cnt(&sm.outTail[w]);
         if (lastPub) fcPub = ld_cnt(&sm.pubTail);
         if (hasNext) fcNext = ld_cnt(&sm.outHead[w + 1]);
         if (++spins > kSpinLimit2 || (((spins & 255) == 0) && ld_cnt(&sm.abort))) return false;
+      }
+      if (__builtin_expect(spins != 0, 0)) {
+        // The last step of the previous chunk read this chunk's first record ahead; that read was only good if the
+        // record was already there, which the one-chunk-old counter just confirmed unless we had to wait.
+        const float4* rp0 = &sm.rec[w][s0 % kRS][r][0];
+        ra = rp0[0]; rb = rp0[1]; rc = *reinterpret_cast<const float2*>(rp0 + 2);
+        asm volatile("" : "+v"(ra.x), "+v"(ra.y), "+v"(ra.z), "+v"(ra.w), "+v"(rb.x), "+v"(rb.y), "+v"(rb.z), "+v"(rb.w), "+v"(rc.x), "+v"(rc.y));
       }
     }
     // read the counters again for the next chunk; the loads complete in the shadow of this chunk's steps
@@ -339,8 +348,6 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
     statWait += __builtin_readcyclecounter() - tw0;
 #endif
     const int send = s0 + kChunk;   // nsteps is a whole number of chunks
-    const float4* rp0 = &sm.rec[w][s0 % kRS][r][0];
-    float4 ra = rp0[0], rb = rp0[1], rc = rp0[2];
 #pragma unroll PF_SWEEP_UNROLL
     for (int s = s0; s < send; ++s) {
       // ---- top neighbour: row r-1's result of the previous step (DPP); row 0 of the band from the ring ----
@@ -385,7 +392,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       // previous pixel along the step axis = own result of the previous step; previous pixel across = DPP/ring.
       // Reference order is always "previous column, then previous row" (PixFlow.hpp:319-320 / :332-333).
       float2 fin = C;
-      float4 na, nb, nc;
+      float4 na, nb; float2 nc;
       int hN = 0; unsigned long long tvN = tv;
       // next step's inputs (LDS): records (unconditional: past the chunk it reads a slot that is reloaded at the chunk
       // start anyway), producer counter, then the top value.  Issued behind the gather inside the evaluation below.
@@ -401,7 +408,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       const float2 cand = candIsT ? T : L;
       int emin; float vmax;
       float e = d_error_fast<TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, fx, fy, ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy, emin, vmax);
-      na = rpn[0]; nb = rpn[1]; nc = rpn[2];
+      na = rpn[0]; nb = rpn[1]; nc = *reinterpret_cast<const float2*>(rpn + 2);
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(top_slot(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
       fin = select_step<true>(e, eC, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
       if (__builtin_expect(__any(emin < -94 || !(vmax <= 0x1p100f)), 0)) {
@@ -412,7 +419,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       if (!(gatev > 0.0f)) fin = C;
       fin.x = bcast8(fin.x); fin.y = bcast8(fin.y);
       } else {
-      na = rpn[0]; nb = rpn[1]; nc = rpn[2];
+      na = rpn[0]; nb = rpn[1]; nc = *reinterpret_cast<const float2*>(rpn + 2);
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(top_slot(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
       }
       fpos += forward ? 1.0f : -1.0f;
