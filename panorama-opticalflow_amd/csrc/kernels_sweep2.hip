@@ -93,6 +93,16 @@ __device__ __forceinline__ float div_core(float a, float c, float y) {
   const float r1 = __builtin_fmaf(-q1, c, a);
   return __builtin_fmaf(r1, y, q1);
 }
+// two quotients by the same constant at once (packed fp32 FMA)
+typedef float f2p __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2p div_core2(f2p a, float c, float y) {
+  const f2p cc = {c, c}, yy = {y, y};
+  const f2p q0 = a * yy;
+  const f2p r0 = __builtin_elementwise_fma(-q0, cc, a);
+  const f2p q1 = __builtin_elementwise_fma(r0, yy, q0);
+  const f2p r1 = __builtin_elementwise_fma(-q1, cc, a);
+  return __builtin_elementwise_fma(r1, yy, q1);
+}
 // all of v0..v3 (>= 0) are zero or inside [2^-95, 2^100]: the range where sqrt_core/div_core are exact
 __device__ __forceinline__ bool fast_range_ok(float v0, float v1, float v2, float v3) {
   const int e0 = __builtin_amdgcn_frexp_expf(v0), e1 = __builtin_amdgcn_frexp_expf(v1), e2 = __builtin_amdgcn_frexp_expf(v2),
@@ -156,7 +166,8 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, con
   const float dfx = bx - fdx, dfy = by - fdy;
   const float s2 = dfx * dfx + dfy * dfy;
   const float av = kVerticalRegularizationCoef * fabsf(fdy), ah = kHorizontalRegularizationCoef * fabsf(fdx);
-  const float sm = sqrt_core(s2) * kSmoothnessCoef, rv = div_core(av, fW, rW), rh = div_core(ah, fW, rW);
+  const f2p reg = div_core2(f2p{av, ah}, fW, rW);
+  const float sm = sqrt_core(s2) * kSmoothnessCoef, rv = reg.x, rh = reg.y;
   emin = min(min(__builtin_amdgcn_frexp_expf(s2), __builtin_amdgcn_frexp_expf(av)), __builtin_amdgcn_frexp_expf(ah));   // 0 for a zero operand
   vmax = __builtin_fmaxf(__builtin_fmaxf(s2, av), ah);
   __builtin_amdgcn_sched_barrier(0);
@@ -196,7 +207,8 @@ __device__ __forceinline__ float2 select_step(float e, float eC, float exC, floa
   float gx, gy;
   if (FAST) {
     const float ax = fabsf(dgx), ay = fabsf(dgy);
-    gx = div_core(dgx, kGradEpsilon, rEps); gy = div_core(dgy, kGradEpsilon, rEps);
+    const f2p g2 = div_core2(f2p{dgx, dgy}, kGradEpsilon, rEps);
+    gx = g2.x; gy = g2.y;
     emin = min(emin, min(__builtin_amdgcn_frexp_expf(ax), __builtin_amdgcn_frexp_expf(ay)));
     vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(ax, ay));
   } else {
