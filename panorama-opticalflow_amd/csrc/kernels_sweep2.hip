@@ -11,13 +11,18 @@
 //     Selection follows the reference order (current, then L, then T, strict '<'), the finite-difference
 //     gradient of the winner is already there.  Same arithmetic, same order => bit-identical.
 //   * one compute wave = a band of 8 rows (lane = 8*row + role).  Four compute waves (one per SIMD)
-//     + one I/O helper wave form a workgroup = 32 rows.  Rows inside a wave hand their result to the
-//     next row by cross-lane moves, waves inside a workgroup through an LDS ring, workgroups through
-//     8-byte data-is-flag granules in HBM (agent-scope relaxed atomics; cdna_hip_programming.md G16/R2).
-//   * compute waves never touch HBM except for the bilinear gather of (I1x,I1y): the helper wave
-//     streams records HBM->LDS ahead of the wavefront, drains results LDS->HBM, publishes the granules
-//     and polls the previous workgroup's granules, so the long-latency traffic sits in ITS in-order
-//     memory queue, not in the compute waves'.
+//     + four helper waves (loader, publisher, poller, drainer) form a workgroup = 32 rows.  Rows inside a
+//     wave hand their result to the next row by DPP moves; waves inside a workgroup through the LDS result
+//     ring plus a step counter (producer: value, then counter; consumer: counter, then value, both one step
+//     ahead of use -- the readiness test is two scalar instructions); workgroups through 8-byte
+//     data-is-flag granules in HBM (agent-scope relaxed atomics; cdna_hip_programming.md G16/R2).
+//   * compute waves never touch HBM except for the rare bilinear gather outside the LDS window: the helper
+//     waves stream records and window texels HBM->LDS ahead of the wavefront, drain results LDS->HBM,
+//     publish the granules and poll the previous workgroup's granules, so the long-latency traffic sits in
+//     THEIR in-order memory queues, not in the compute waves'.
+//   * a lone wave issues one instruction every ~6 cycles here, so the step time is the instruction count:
+//     ~170 instructions per step (packed fp32 math, one range guard per step, no per-step address
+//     arithmetic that a loop-carried register or an immediate can replace, no LDS-order stalls).
 // Workgroups take their band index from an atomic ticket (a band only waits for bands already
 // running), every spin is bounded and raises ctrl[1] instead of hanging.
 #include "pf_common.hpp"
@@ -26,7 +31,7 @@ namespace pf {
 
 namespace {
 constexpr int kRows = 8;     // rows per compute wave
-constexpr int kWaves = 4;    // compute waves per workgroup (2 per SIMD: a lone wave only uses ~1 issue slot in 4)
+constexpr int kWaves = 4;    // compute waves per workgroup, one per SIMD (two per SIMD measured slower)
 constexpr int kRS = 16;      // record ring (steps)
 constexpr int kOS = 32;      // result ring (steps)
 constexpr int kBS = 256;     // boundary ring (columns)
@@ -36,7 +41,7 @@ constexpr int kWA = kRows + 2 * kRad + 1;   // window extent across the band (25
 constexpr int kWC = 64;      // window ring along the step axis (columns)
 constexpr int kSpinLimit2 = 1 << 20;
 #ifndef PF_SWEEP_UNROLL
-#define PF_SWEEP_UNROLL 2
+#define PF_SWEEP_UNROLL 4
 #endif
 #define PF_STR2(x) #x
 #define PF_STR(x) PF_STR2(x)   // ~0.2 s of polling: a stuck band raises ctrl[1] instead of hanging the GPU
@@ -265,18 +270,6 @@ __device__ __forceinline__ void st_cnt(int* p, int v) {
 
 }  // namespace
 
-// wait until *cnt >= need (wave-uniform); false on timeout / abort
-__device__ __forceinline__ bool wait_ge(const int* cnt, int need, int& cached, const int* abortp) {
-  if (__builtin_expect(cached >= need, 1)) return true;
-  int spins = 0;
-  for (;;) {
-    cached = ld_cnt(cnt);
-    if (cached >= need) return true;
-    __builtin_amdgcn_s_sleep(1);
-    if (++spins > kSpinLimit2 || (((spins & 255) == 0) && ld_cnt(abortp))) return false;
-  }
-}
-
 // One compute wave: a band of 8 rows, lane = 8*row + role.  TOP: 0 = image border above, 1 = previous wave
 // of this workgroup (its LDS result ring), 2 = previous workgroup (granule ring filled by the poller wave).
 // Hand-off protocol: the producer writes its result, then its step counter; the consumer reads the counter,
@@ -310,7 +303,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   bool dead = false;
 #ifdef PF_SWEEP_STATS
   int statHits = 0, statSpins = 0;
-  long long statT0 = 0, statWait = 0;
+  long long statT0 = 0, statWait = 0, statR8 = 0;
 #endif
   // image coordinates of this lane's pixel: across the bands (constant) and along the step axis (s - r in sweep order)
   const int LBx = transposed ? W : H;
@@ -358,6 +351,9 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
     if (hasNext) fcNext = ld_cnt(&sm.outHead[w + 1]);
 #ifdef PF_SWEEP_STATS
     statWait += __builtin_readcyclecounter() - tw0;
+#endif
+#ifdef PF_SWEEP_STATS
+    if (s0 == 8) statR8 = wall_clock64();
 #endif
     const int send = s0 + kChunk;   // nsteps is a whole number of chunks
 #pragma unroll PF_SWEEP_UNROLL
@@ -453,8 +449,8 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 #ifdef PF_SWEEP_STATS
   if (lane == 0) {
     atomicAdd(&sm.statHits, statHits); atomicAdd(&sm.statSpins, statSpins);
-    if (band < 8 || band % 16 == 0) printf("band %d: %lld cycles, %lld in chunk-start waits, %d edge waits, %d spins, nsteps %d\n", band,
-           (long long)__builtin_readcyclecounter() - statT0, statWait, statHits, statSpins, nsteps);
+    if (band % 4 == 0 || band % 4 == 3) printf("band %d xcc %d: %lld cycles, %lld in chunk-start waits, %d edge waits, %d spins, nsteps %d, step8 at %lld, end at %lld (10ns)\n", band, (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF),
+           (long long)__builtin_readcyclecounter() - statT0, statWait, statHits, statSpins, nsteps, statR8, (long long)wall_clock64());
   }
 #endif
   return !dead;
@@ -669,7 +665,7 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
         st_cnt(&sm.pubTail, pt);
         idle = 0;
       } else {
-        __builtin_amdgcn_s_sleep(6);
+        __builtin_amdgcn_s_sleep(1);
         if (++idle > kSpinLimit2 || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
     }
@@ -696,7 +692,7 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
           idle = 0;
           continue;
         }
-        __builtin_amdgcn_s_sleep(6);
+        __builtin_amdgcn_s_sleep(1);
       } else {
         __builtin_amdgcn_s_sleep(8);
       }
