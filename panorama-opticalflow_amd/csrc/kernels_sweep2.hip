@@ -43,6 +43,9 @@ constexpr int kSpinLimit2 = 1 << 20;
 #ifndef PF_SWEEP_UNROLL
 #define PF_SWEEP_UNROLL 4
 #endif
+#ifndef PF_MARGIN
+#define PF_MARGIN(top) ((top) == 2 ? 1 : 0)   // extra columns to fall behind after catching up with the producer (measured: 0 inside a workgroup, 1 across)
+#endif
 #define PF_STR2(x) #x
 #define PF_STR(x) PF_STR2(x)   // ~0.2 s of polling: a stuck band raises ctrl[1] instead of hanging the GPU
 
@@ -363,10 +366,10 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       if (TOP != 0) {
         if (__builtin_expect(s >= avail, 0)) {
           if (s < LS) {
-            // at the edge of the producer: wait for this column and the next one, i.e. fall one more column behind,
-            // so that the following steps find their top value already read (one LDS round trip less per step).
+            // at the edge of the producer: wait for this column (across workgroups: and the next one, i.e. fall one more
+            // column behind, so that the following steps find their top value already read despite the HBM hop's jitter).
             // No early exit from the hot loop: a timeout only marks the band dead (checked once per chunk).
-            const int need = (s + 2 < LS) ? s + 2 : LS;
+            const int need = (s + 1 + PF_MARGIN(TOP) < LS) ? s + 1 + PF_MARGIN(TOP) : LS;
             int spins = 0;
 #ifdef PF_SWEEP_STATS
             ++statHits;
