@@ -32,7 +32,8 @@ namespace pf {
 namespace {
 constexpr int kRows = 8;     // rows per compute wave
 constexpr int kWaves = 4;    // compute waves per workgroup, one per SIMD (two per SIMD measured slower)
-constexpr int kRS = 16;      // record ring (steps)
+constexpr int kRS = 32;      // record ring (steps): the loader runs up to three chunks ahead
+constexpr int kLoadAhead = 2; // chunks per wave the loader fetches in one round when the ring has room
 constexpr int kOS = 32;      // result ring (steps)
 constexpr int kBS = 256;     // boundary ring (columns)
 constexpr int kChunk = 8;    // steps streamed per helper iteration and wave
@@ -256,6 +257,7 @@ struct Smem {
   int abort;
   int wg;
   int statHits, statSpins;   // -DPF_SWEEP_STATS only
+  long long statEntry;
 };
 
 // LDS counters: a wave's LDS operations are executed in issue order by the CU's LDS unit, so "write data,
@@ -306,7 +308,8 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   bool dead = false;
 #ifdef PF_SWEEP_STATS
   int statHits = 0, statSpins = 0;
-  long long statT0 = 0, statWait = 0, statR8 = 0;
+  long long statT0 = 0, statWait = 0, statR8 = 0, statC0 = 0;
+  const long long statB = wall_clock64();
 #endif
   // image coordinates of this lane's pixel: across the bands (constant) and along the step axis (s - r in sweep order)
   const int LBx = transposed ? W : H;
@@ -357,6 +360,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 #endif
 #ifdef PF_SWEEP_STATS
     if (s0 == 8) statR8 = wall_clock64();
+    if (s0 == 0) statC0 = wall_clock64();
 #endif
     const int send = s0 + kChunk;   // nsteps is a whole number of chunks
 #pragma unroll PF_SWEEP_UNROLL
@@ -453,8 +457,8 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 #ifdef PF_SWEEP_STATS
   if (lane == 0) {
     atomicAdd(&sm.statHits, statHits); atomicAdd(&sm.statSpins, statSpins);
-    if (band % 4 == 0 || band % 4 == 3) printf("band %d xcc %d: %lld cycles, %lld in chunk-start waits, %d edge waits, %d spins, nsteps %d, step8 at %lld, end at %lld (10ns)\n", band, (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF),
-           (long long)__builtin_readcyclecounter() - statT0, statWait, statHits, statSpins, nsteps, statR8, (long long)wall_clock64());
+    if (band == 0 || (!hasNext && !publishes)) printf("band %d xcc %d: %lld cycles, %lld in chunk-start waits, %d edge waits, %d spins, nsteps %d, step8 at %lld, end at %lld; since kernel entry: band start %lld, first chunk %lld, end %lld (10ns)\n", band, (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF),
+           (long long)__builtin_readcyclecounter() - statT0, statWait, statHits, statSpins, nsteps, statR8, (long long)wall_clock64(), statB - sm.statEntry, statC0 - sm.statEntry, (long long)wall_clock64() - sm.statEntry);
   }
 #endif
   return !dead;
@@ -509,6 +513,9 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
+#ifdef PF_SWEEP_STATS
+  const long long tEntry = wall_clock64();
+#endif
   if (tid == 0) {
     sm.wg = atomicAdd(&ctrl[0], 1);
     sm.bndHead = 0; sm.abort = 0; sm.pubTail = 0; sm.statHits = 0; sm.statSpins = 0;
@@ -527,6 +534,9 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
     // ======================= compute wave: band of 8 rows =======================
     if (wave >= nact) return;
     __builtin_amdgcn_s_setprio(3);   // the helper waves share SIMDs with compute waves: compute wins issue arbitration
+#ifdef PF_SWEEP_STATS
+    sm.statEntry = tEntry;
+#endif
     const int top = (wave > 0) ? 1 : (wg > 0 ? 2 : 0);   // where row 0's top neighbour comes from
     bool ok;
     if (top == 1) ok = compute_band<1, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
@@ -553,49 +563,75 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
       const int x = FWD ? cxc : W - 1 - cxc, y = FWD ? cyc : H - 1 - cyc;
       return g1 + (y * W + x);
     };
-    for (int w = 0; w < nact; ++w)
-      for (int b = 2; b <= 3; ++b)
-        for (int k = 0; k < 4; ++k) {
-          int slot; const float2* q = win_addr(w, b, lane + 64 * k, slot);
-          if (q) (&sm.win[w][0][0])[slot] = *q;
-        }
+    {   // prologue: batches 2 and 3 of every active wave, all loads in flight together (one HBM round trip, not 32)
+      float2 pv[kWaves][2][4]; int ps[kWaves][2][4]; bool pk[kWaves][2][4];
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float2* q = (w < nact) ? win_addr(w, b + 2, lane + 64 * k, ps[w][b][k]) : nullptr;
+            pk[w][b][k] = q != nullptr;
+            pv[w][b][k] = pk[w][b][k] ? *q : make_float2(0.f, 0.f);
+          }
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (pk[w][b][k]) (&sm.win[w][0][0])[ps[w][b][k]] = pv[w][b][k];
+    }
     int idle = 0;
     for (;;) {
+      // One round = up to kLoadAhead chunks per wave: all loads first, one wait, then registers -> LDS.  Loading two
+      // chunks when the ring has room halves the number of exposed HBM round trips per step.
       bool progress = false, done = true;
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 va[kWaves], vb[kWaves], vc[kWaves];
-      float2 wv[kWaves][4]; int ws[kWaves][4]; bool wok[kWaves][4];
-      int rh[kWaves]; bool ld[kWaves];
+      float4 va[kWaves][kLoadAhead], vb[kWaves][kLoadAhead], vc[kWaves][kLoadAhead];
+      float2 wv[kWaves][kLoadAhead][4]; int ws[kWaves][kLoadAhead][4]; bool wok[kWaves][kLoadAhead][4];
+      int rh[kWaves]; bool ld[kWaves][kLoadAhead];
 #pragma unroll
       for (int w = 0; w < kWaves; ++w) {
-        va[w] = z4; vb[w] = z4; vc[w] = z4; ld[w] = false; rh[w] = 0;
+        rh[w] = 0;
+#pragma unroll
+        for (int c = 0; c < kLoadAhead; ++c) { va[w][c] = z4; vb[w][c] = z4; vc[w][c] = z4; ld[w][c] = false; }
         if (w < nact) {
           rh[w] = sm.recHead[w];
           const int oh = ld_cnt(&sm.outHead[w]);
-          ld[w] = rh[w] < nsteps && (rh[w] + kChunk - oh <= kRS);
           if (rh[w] < nsteps) done = false;
-          if (ld[w]) {
-            const float4* src = rec + (size_t(band0 + w) * nstepsPad + rh[w]) * (kRows * 3);
-            va[w] = src[lane]; vb[w] = src[lane + 64]; vc[w] = src[lane + 128];
-            const int b = rh[w] / kChunk + 4;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const float2* q = win_addr(w, b, lane + 64 * k, ws[w][k]);
-              wok[w][k] = q != nullptr;
-              wv[w][k] = wok[w][k] ? *q : make_float2(0.f, 0.f);
+          for (int c = 0; c < kLoadAhead; ++c) {
+            const int r0 = rh[w] + c * kChunk;
+            ld[w][c] = r0 < nsteps && (r0 + kChunk - oh <= kRS);
+            if (ld[w][c]) {
+              const float4* src = rec + (size_t(band0 + w) * nstepsPad + r0) * (kRows * 3);
+              va[w][c] = src[lane]; vb[w][c] = src[lane + 64]; vc[w][c] = src[lane + 128];
+              const int b = r0 / kChunk + 4;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const float2* q = win_addr(w, b, lane + 64 * k, ws[w][c][k]);
+                wok[w][c][k] = q != nullptr;
+                wv[w][c][k] = wok[w][c][k] ? *q : make_float2(0.f, 0.f);
+              }
             }
           }
         }
       }
 #pragma unroll
       for (int w = 0; w < kWaves; ++w) {
-        if (ld[w]) {
-          float4* dst = &sm.rec[w][rh[w] % kRS][0][0];
-          dst[lane] = va[w]; dst[lane + 64] = vb[w]; dst[lane + 128] = vc[w];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) if (wok[w][k]) (&sm.win[w][0][0])[ws[w][k]] = wv[w][k];
-          st_cnt(&sm.recHead[w], rh[w] + kChunk);
-          progress = true;
+        for (int c = 0; c < kLoadAhead; ++c) {
+          if (ld[w][c]) {
+            const int r0 = rh[w] + c * kChunk;
+            float4* dst = &sm.rec[w][r0 % kRS][0][0];
+            dst[lane] = va[w][c]; dst[lane + 64] = vb[w][c]; dst[lane + 128] = vc[w][c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (wok[w][c][k]) (&sm.win[w][0][0])[ws[w][c][k]] = wv[w][c][k];
+            st_cnt(&sm.recHead[w], r0 + kChunk);
+            progress = true;
+          }
         }
       }
       if (done) break;
