@@ -11,7 +11,7 @@
 //     Selection follows the reference order (current, then L, then T, strict '<'), the finite-difference
 //     gradient of the winner is already there.  Same arithmetic, same order => bit-identical.
 //   * one compute wave = a band of 8 rows (lane = 8*row + role).  Four compute waves (one per SIMD)
-//     + four helper waves (loader, publisher, poller, drainer) form a workgroup = 32 rows.  Rows inside a
+//     + seven helper waves (four loaders, publisher, poller, drainer) form a workgroup = 32 rows.  Rows inside a
 //     wave hand their result to the next row by DPP moves; waves inside a workgroup through the LDS result
 //     ring plus a step counter (producer: value, then counter; consumer: counter, then value, both one step
 //     ahead of use -- the readiness test is two scalar instructions); workgroups through 8-byte
@@ -309,6 +309,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 #ifdef PF_SWEEP_STATS
   int statHits = 0, statSpins = 0;
   long long statT0 = 0, statWait = 0, statR8 = 0, statC0 = 0;
+  int statSlowChunks = 0, statChunkSpins = 0, statFailRec = 0, statFailTail = 0, statFailPub = 0, statFailNext = 0;
   const long long statB = wall_clock64();
 #endif
   // image coordinates of this lane's pixel: across the bands (constant) and along the step axis (s - r in sweep order)
@@ -337,12 +338,23 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
         if (lastPub) { const int c1 = __builtin_amdgcn_readfirstlane(fcPub) + kOS; lim = lim < c1 ? lim : c1; }
         if (hasNext) { const int c2 = __builtin_amdgcn_readfirstlane(fcNext) + kOS + kRows - 1; lim = lim < c2 ? lim : c2; }
         if (__builtin_expect(rec >= s0 + kChunk && lim >= s0 + kChunk, 1)) break;
+#ifdef PF_SWEEP_STATS
+        if (spins == 0) {
+          if (rec < s0 + kChunk) ++statFailRec;
+          if (__builtin_amdgcn_readfirstlane(fcTail) + kOS < s0 + kChunk) ++statFailTail;
+          if (lastPub && __builtin_amdgcn_readfirstlane(fcPub) + kOS < s0 + kChunk) ++statFailPub;
+          if (hasNext && __builtin_amdgcn_readfirstlane(fcNext) + kOS + kRows - 1 < s0 + kChunk) ++statFailNext;
+        }
+#endif
         if (spins) __builtin_amdgcn_s_sleep(1);
         fcRec = ld_cnt(&sm.recHead[w]); fcTail = ld_cnt(&sm.outTail[w]);
         if (lastPub) fcPub = ld_cnt(&sm.pubTail);
         if (hasNext) fcNext = ld_cnt(&sm.outHead[w + 1]);
         if (++spins > kSpinLimit2 || (((spins & 255) == 0) && ld_cnt(&sm.abort))) return false;
       }
+#ifdef PF_SWEEP_STATS
+      if (spins) { ++statSlowChunks; statChunkSpins += spins; }
+#endif
       if (__builtin_expect(spins != 0, 0)) {
         // The last step of the previous chunk read this chunk's first record ahead; that read was only good if the
         // record was already there, which the one-chunk-old counter just confirmed unless we had to wait.
@@ -457,8 +469,8 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 #ifdef PF_SWEEP_STATS
   if (lane == 0) {
     atomicAdd(&sm.statHits, statHits); atomicAdd(&sm.statSpins, statSpins);
-    if (band == 0 || (!hasNext && !publishes)) printf("band %d xcc %d: %lld cycles, %lld in chunk-start waits, %d edge waits, %d spins, nsteps %d, step8 at %lld, end at %lld; since kernel entry: band start %lld, first chunk %lld, end %lld (10ns)\n", band, (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF),
-           (long long)__builtin_readcyclecounter() - statT0, statWait, statHits, statSpins, nsteps, statR8, (long long)wall_clock64(), statB - sm.statEntry, statC0 - sm.statEntry, (long long)wall_clock64() - sm.statEntry);
+    if (band < 8 || band % 32 == 1 || (!hasNext && !publishes)) printf("band %d xcc %d: %lld cycles, %lld in chunk-start waits, %d edge waits, %d spins, nsteps %d, slow chunk starts %d (%d spins; first check failed on rec %d tail %d pub %d next %d), step8 at %lld, end at %lld; since kernel entry: band start %lld, first chunk %lld, end %lld (10ns)\n", band, (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF),
+           (long long)__builtin_readcyclecounter() - statT0, statWait, statHits, statSpins, nsteps, statSlowChunks, statChunkSpins, statFailRec, statFailTail, statFailPub, statFailNext, statR8, (long long)wall_clock64(), statB - sm.statEntry, statC0 - sm.statEntry, (long long)wall_clock64() - sm.statEntry);
   }
 #endif
   return !dead;
@@ -501,11 +513,13 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
 }
 
 // ------------------------------------------------------------------------------------------------
-// 512 threads: waves 0-3 compute (one band of 8 rows each), wave 4 loads records, wave 5 publishes the
-// workgroup's last row as granules, wave 6 polls the previous workgroup's granules, wave 7 drains results.
+// 704 threads: waves 0-3 compute (one band of 8 rows each), waves 4-7 load records and window texels (one per
+// compute wave), wave 8 publishes the workgroup's last row as granules, wave 9 polls the previous workgroup's
+// granules, wave 10 drains results.  Waves land on SIMD (wave % 4): every compute wave shares its SIMD with its
+// own loader; three waves per SIMD cap the kernel at 168 VGPRs.
 // ------------------------------------------------------------------------------------------------
 template <bool TR, bool FWD, bool SPARSE>
-__global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
+__global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
                                                 unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H,
                                                 int nstepsPad, int nbands, float rW, float rEps) {
   constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0;
@@ -549,102 +563,102 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
     return;
   }
 
-  if (wave == kWaves) {
-    // ======================= loader: records + gather window HBM -> LDS, up to kRS steps ahead of each compute wave =======================
+  if (wave >= kWaves && wave < 2 * kWaves) {
+    // ======================= loader of compute wave w: records + gather window HBM -> LDS, up to kRS steps ahead =======================
     // Window batch b = the 8 texel columns (along the step axis) [8b-16, 8b-8) x kWA texels across the band.
     // A compute wave working on chunk j (steps 8j..8j+7) reads columns [8j-15, 8j+16], i.e. batches j..j+4,
-    // so chunk j is published only after batch j+4 has landed (batches 2..4 in the prologue).
-    auto win_addr = [&](int w, int b, int t, int& slot) -> const float2* {   // texel t (0..8*kWA-1) of batch b of wave w
-      const int c = TR ? t / kWA : (t & 7), a = TR ? t % kWA : (t >> 3);
-      const int u = 8 * b - 16 + c, v = (band0 + w) * kRows - kRad + a;
-      slot = a * kWC + (u & (kWC - 1));
-      if (t >= 8 * kWA || u < 0 || u >= LS || v < 0 || v >= LB) return nullptr;
+    // so chunk j is published only after batch j+4 has landed (batches 2..3 in the prologue, batch j+4 with chunk j).
+    // One loader per compute wave: its in-order memory queue holds nothing but this band's loads, and a round
+    // (issue up to kLoadAhead chunks, wait once, registers -> LDS, publish) costs one HBM round trip.
+    const int w = wave - kWaves;
+    if (w >= nact) return;
+    // texel t = lane + 64k (k = 0..3) of a batch: position c along the step axis, a across the band -- loop invariant
+    int tc[4], ta[4]; bool tvalid[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = lane + 64 * k;
+      tc[k] = TR ? t / kWA : (t & 7); ta[k] = TR ? t % kWA : (t >> 3); tvalid[k] = t < 8 * kWA;
+    }
+    float2* winw = &sm.win[w][0][0];
+    auto win_addr = [&](int b, int k, int& slot) -> const float2* {   // texel k of this lane in batch b
+      const int u = 8 * b - 16 + tc[k], v = (band0 + w) * kRows - kRad + ta[k];
+      slot = ta[k] * kWC + (u & (kWC - 1));
+      if (!tvalid[k] || u < 0 || u >= LS || v < 0 || v >= LB) return nullptr;
       const int cxc = TR ? v : u, cyc = TR ? u : v;
       const int x = FWD ? cxc : W - 1 - cxc, y = FWD ? cyc : H - 1 - cyc;
       return g1 + (y * W + x);
     };
-    {   // prologue: batches 2 and 3 of every active wave, all loads in flight together (one HBM round trip, not 32)
-      float2 pv[kWaves][2][4]; int ps[kWaves][2][4]; bool pk[kWaves][2][4];
+    const float4* recw = rec + size_t(band0 + w) * nstepsPad * (kRows * 3);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int rh = 0, idle = 0;
+    bool first = true;
+    for (;;) {
+      const int oh = first ? 0 : ld_cnt(&sm.outHead[w]);
+      float4 va[kLoadAhead], vb[kLoadAhead], vc[kLoadAhead];
+      float2 wv[kLoadAhead][4]; int ws[kLoadAhead][4]; bool wok[kLoadAhead][4]; bool ld[kLoadAhead];
+      float2 pv[2][4]; int ps[2][4]; bool pk[2][4];   // first round only: batches 2 and 3
 #pragma unroll
-      for (int w = 0; w < kWaves; ++w)
+      for (int c = 0; c < kLoadAhead; ++c) {
+        const int r0 = rh + c * kChunk;
+        va[c] = z4; vb[c] = z4; vc[c] = z4;
+        ld[c] = r0 < nsteps && (r0 + kChunk - oh <= kRS);
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int k = 0; k < 4; ++k) { wv[c][k] = make_float2(0.f, 0.f); ws[c][k] = 0; wok[c][k] = false; }
+        if (ld[c]) {
+          const float4* src = recw + size_t(r0) * (kRows * 3);
+          va[c] = src[lane]; vb[c] = src[lane + 64]; vc[c] = src[lane + 128];
+          const int b = r0 / kChunk + 4;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const float2* q = (w < nact) ? win_addr(w, b + 2, lane + 64 * k, ps[w][b][k]) : nullptr;
-            pk[w][b][k] = q != nullptr;
-            pv[w][b][k] = pk[w][b][k] ? *q : make_float2(0.f, 0.f);
+            const float2* q = win_addr(b, k, ws[c][k]);
+            wok[c][k] = q != nullptr;
+            if (wok[c][k]) wv[c][k] = *q;
           }
+        }
+      }
 #pragma unroll
-      for (int w = 0; w < kWaves; ++w)
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          pv[b][k] = make_float2(0.f, 0.f); ps[b][k] = 0; pk[b][k] = false;
+          if (first) {
+            const float2* q = win_addr(b + 2, k, ps[b][k]);
+            pk[b][k] = q != nullptr;
+            if (pk[b][k]) pv[b][k] = *q;
+          }
+        }
+      if (first) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-            if (pk[w][b][k]) (&sm.win[w][0][0])[ps[w][b][k]] = pv[w][b][k];
-    }
-    int idle = 0;
-    for (;;) {
-      // One round = up to kLoadAhead chunks per wave: all loads first, one wait, then registers -> LDS.  Loading two
-      // chunks when the ring has room halves the number of exposed HBM round trips per step.
-      bool progress = false, done = true;
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 va[kWaves][kLoadAhead], vb[kWaves][kLoadAhead], vc[kWaves][kLoadAhead];
-      float2 wv[kWaves][kLoadAhead][4]; int ws[kWaves][kLoadAhead][4]; bool wok[kWaves][kLoadAhead][4];
-      int rh[kWaves]; bool ld[kWaves][kLoadAhead];
+            if (pk[b][k]) winw[ps[b][k]] = pv[b][k];
+        first = false;
+      }
+      bool progress = false;
 #pragma unroll
-      for (int w = 0; w < kWaves; ++w) {
-        rh[w] = 0;
+      for (int c = 0; c < kLoadAhead; ++c) {
+        if (ld[c]) {
+          float4* dst = &sm.rec[w][rh % kRS][0][0];
+          dst[lane] = va[c]; dst[lane + 64] = vb[c]; dst[lane + 128] = vc[c];
 #pragma unroll
-        for (int c = 0; c < kLoadAhead; ++c) { va[w][c] = z4; vb[w][c] = z4; vc[w][c] = z4; ld[w][c] = false; }
-        if (w < nact) {
-          rh[w] = sm.recHead[w];
-          const int oh = ld_cnt(&sm.outHead[w]);
-          if (rh[w] < nsteps) done = false;
-#pragma unroll
-          for (int c = 0; c < kLoadAhead; ++c) {
-            const int r0 = rh[w] + c * kChunk;
-            ld[w][c] = r0 < nsteps && (r0 + kChunk - oh <= kRS);
-            if (ld[w][c]) {
-              const float4* src = rec + (size_t(band0 + w) * nstepsPad + r0) * (kRows * 3);
-              va[w][c] = src[lane]; vb[w][c] = src[lane + 64]; vc[w][c] = src[lane + 128];
-              const int b = r0 / kChunk + 4;
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                const float2* q = win_addr(w, b, lane + 64 * k, ws[w][c][k]);
-                wok[w][c][k] = q != nullptr;
-                wv[w][c][k] = wok[w][c][k] ? *q : make_float2(0.f, 0.f);
-              }
-            }
-          }
+          for (int k = 0; k < 4; ++k) if (wok[c][k]) winw[ws[c][k]] = wv[c][k];
+          rh += kChunk;
+          st_cnt(&sm.recHead[w], rh);
+          progress = true;
         }
       }
-#pragma unroll
-      for (int w = 0; w < kWaves; ++w) {
-#pragma unroll
-        for (int c = 0; c < kLoadAhead; ++c) {
-          if (ld[w][c]) {
-            const int r0 = rh[w] + c * kChunk;
-            float4* dst = &sm.rec[w][r0 % kRS][0][0];
-            dst[lane] = va[w][c]; dst[lane + 64] = vb[w][c]; dst[lane + 128] = vc[w][c];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (wok[w][c][k]) (&sm.win[w][0][0])[ws[w][c][k]] = wv[w][c][k];
-            st_cnt(&sm.recHead[w], r0 + kChunk);
-            progress = true;
-          }
-        }
-      }
-      if (done) break;
+      if (rh >= nsteps) break;
       if (progress) idle = 0;
       else {
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(4);
         if (++idle > kSpinLimit2 || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
     }
     return;
   }
 
-  if (wave == kWaves + 3) {
+  if (wave == 2 * kWaves + 2) {
     // ======================= drainer: results LDS ring -> flow plane (stores only: never waits on HBM) =======================
     int idle = 0;
     for (;;) {
@@ -684,7 +698,7 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
     return;
   }
 
-  if (wave == kWaves + 1) {
+  if (wave == 2 * kWaves) {
     // ======================= publisher: last row of the workgroup -> granules in HBM (tight loop, never waits on HBM) =======================
     if (!publishes) return;
     unsigned long long* bnd_out = boundary + size_t(wg) * LS;
@@ -714,7 +728,7 @@ __global__ __launch_bounds__(512) void k_sweep2(const float4* __restrict__ rec, 
 
   // ======================= poller: previous workgroup's granules HBM -> LDS ring =======================
   {
-    if (wg == 0 || wave != kWaves + 2) return;
+    if (wg == 0 || wave != 2 * kWaves + 1) return;
     const unsigned long long* bnd_in = boundary + size_t(wg - 1) * LS;
     int bh = 0, idle = 0;
     while (bh < LS) {
@@ -764,7 +778,7 @@ void launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
   const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
   hipLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.g0, a.g1, a.blurred, a.gate, a.flow, a.W, a.H, a.forward, tr,
                      nstepsPad, nbandsPad, reinterpret_cast<float4*>(rec));
-  const dim3 grid(nwg), block(64 * (kWaves + 4));
+  const dim3 grid(nwg), block(64 * (2 * kWaves + 3));
   const float rW = (float)(1.0 / (double)(float)a.W), rEps = (float)(1.0 / (double)kGradEpsilon);
   const float4* r4 = reinterpret_cast<const float4*>(rec);
 #define PF_LAUNCH_SWEEP2(TRV, FWV) do { if (a.sparse) hipLaunchKernelGGL((k_sweep2<TRV, FWV, true>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps); \
