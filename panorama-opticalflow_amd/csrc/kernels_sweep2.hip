@@ -33,7 +33,7 @@ namespace {
 constexpr int kRows = 8;     // rows per compute wave
 constexpr int kWaves = 4;    // compute waves per workgroup, one per SIMD (two per SIMD measured slower)
 constexpr int kRS = 32;      // record ring (steps): the loader runs up to three chunks ahead
-constexpr int kLoadAhead = 2; // chunks per wave the loader fetches in one round when the ring has room
+constexpr int kLoadAhead = 3; // chunks per wave the loader fetches in one round when the ring has room
 constexpr int kOS = 32;      // result ring (steps)
 constexpr int kBS = 256;     // boundary ring (columns)
 constexpr int kChunk = 8;    // steps streamed per helper iteration and wave
