@@ -91,7 +91,7 @@ int prof_id(pf_ctx* c, const char* name) {
 }
 hipEvent_t prof_event(pf_ctx* c) {
   if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
-  hipEvent_t e; hipEventCreate(&e); return e;
+  hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableSystemFence); return e;   // timing only: no system-scope release at the marker
 }
 struct ProfScope {
   pf_ctx* c; hipStream_t st; ProfPending p; bool on;
