@@ -126,6 +126,38 @@ __device__ __forceinline__ bool fast_range_ok1(float v) {
   return __builtin_amdgcn_frexp_expf(v) >= -94 && v <= 0x1p100f;
 }
 
+// errorFunction for the prepass: identical values to d_error2, with the two square roots and two divisions in their
+// cheap exact forms whenever every operand is inside the valid range (per-thread test; otherwise the IEEE sequence).
+__device__ __forceinline__ float d_error2g(const float2* __restrict__ g1, int W, float wm2, float hm2, float fW, float rW, int x, int y, float i0x,
+                                           float i0y, float bx, float by, float fdx, float fdy) {
+  const float matchX = float(x) + fdx, matchY = float(y) + fdy;
+  float cx = (0.0f < matchX) ? matchX : 0.0f; cx = (cx < wm2) ? cx : wm2;
+  float cy = (0.0f < matchY) ? matchY : 0.0f; cy = (cy < hm2) ? cy : hm2;
+  const int x0 = int(cx), y0 = int(cy);
+  const float xR = cx - float(x0), yR = cy - float(y0);
+  const float2* p = g1 + size_t(y0) * W + x0;
+  const F2x2 t0 = *reinterpret_cast<const F2x2*>(p);
+  const F2x2 t1 = *reinterpret_cast<const F2x2*>(p + W);
+  float i1x, i1y;
+  {
+    const float f00 = t0.a, f10 = t0.c, f01 = t1.a, f11 = t1.c;
+    const float a1 = f00, a2 = f10 - f00, a3 = f01 - f00, a4 = f00 + f11 - f10 - f01;
+    i1x = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
+  }
+  {
+    const float f00 = t0.b, f10 = t0.d, f01 = t1.b, f11 = t1.d;
+    const float a1 = f00, a2 = f10 - f00, a3 = f01 - f00, a4 = f00 + f11 - f10 - f01;
+    i1y = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
+  }
+  const float dfx = bx - fdx, dfy = by - fdy;
+  const float s2 = dfx * dfx + dfy * dfy;
+  const float d2 = (i0x - i1x) * (i0x - i1x) + (i0y - i1y) * (i0y - i1y);
+  const float av = kVerticalRegularizationCoef * fabsf(fdy), ah = kHorizontalRegularizationCoef * fabsf(fdx);
+  if (fast_range_ok(s2, d2, av, ah))
+    return sqrt_core(d2) + sqrt_core(s2) * kSmoothnessCoef + div_core(av, fW, rW) + div_core(ah, fW, rW);
+  return sqrtf(d2) + sqrtf(s2) * kSmoothnessCoef + av / fW + ah / fW;
+}
+
 // lane i reads lane i+N of its row of 16; lanes whose source falls outside the row read 0 (bound_ctrl), no 'old' operand to set up
 template <int N>
 __device__ __forceinline__ float dpp_shl0(float src) {
@@ -483,7 +515,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g0, const float2* __restrict__ g1, const float2* __restrict__ blurred,
                                                     const uint8_t* __restrict__ gate, const float2* __restrict__ flow, int W, int H, int forward,
-                                                    int transposed, int nstepsPad, int nbandsPad, float4* __restrict__ rec) {
+                                                    int transposed, int nstepsPad, int nbandsPad, float rW, float4* __restrict__ rec) {
   const size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
   if (tid >= total) return;
@@ -503,9 +535,9 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
       const float2 g = g0[idx], bl = blurred[idx];
       const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
       a = make_float4(g.x, g.y, bl.x, bl.y);
-      b.z = d_error2(g1, W, wm2, hm2, fW, x, y, g.x, g.y, bl.x, bl.y, f.x, f.y);
-      b.w = d_error2(g1, W, wm2, hm2, fW, x, y, g.x, g.y, bl.x, bl.y, f.x + kGradEpsilon, f.y + 0.0f);
-      c.x = d_error2(g1, W, wm2, hm2, fW, x, y, g.x, g.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
+      b.z = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x, f.y);
+      b.w = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x + kGradEpsilon, f.y + 0.0f);
+      c.x = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
       c.y = 1.0f;
     }
   }
@@ -776,10 +808,10 @@ void launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
   const int nbands = (LB + kRows - 1) / kRows, nwg = wgs_for(LB), nbandsPad = nwg * kWaves;
   const int nstepsPad = steps_pad(LS);
   const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
-  hipLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.g0, a.g1, a.blurred, a.gate, a.flow, a.W, a.H, a.forward, tr,
-                     nstepsPad, nbandsPad, reinterpret_cast<float4*>(rec));
-  const dim3 grid(nwg), block(64 * (2 * kWaves + 3));
   const float rW = (float)(1.0 / (double)(float)a.W), rEps = (float)(1.0 / (double)kGradEpsilon);
+  hipLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.g0, a.g1, a.blurred, a.gate, a.flow, a.W, a.H, a.forward, tr,
+                     nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec));
+  const dim3 grid(nwg), block(64 * (2 * kWaves + 3));
   const float4* r4 = reinterpret_cast<const float4*>(rec);
 #define PF_LAUNCH_SWEEP2(TRV, FWV) do { if (a.sparse) hipLaunchKernelGGL((k_sweep2<TRV, FWV, true>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps); \
     else hipLaunchKernelGGL((k_sweep2<TRV, FWV, false>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps); } while (0)
