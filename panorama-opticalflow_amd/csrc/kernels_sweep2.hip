@@ -471,7 +471,9 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(top_slot(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
       fin = select_step<true>(e, eC, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
       asm volatile("" : "+v"(fin.x), "+v"(fin.y));   // finish the fast result before the branch: the range test then runs beside the division, not before it
-      if (__builtin_expect(__any(emin < -94 || !(vmax <= 0x1p100f)), 0)) {
+      // Only pixels that will be updated count: the lanes of a pixel without data (gate <= 0) still run the arithmetic, and
+      // there the inputs are blur tails of black borders (operands ~1e-40) -- their result is discarded two lines below.
+      if (__builtin_expect(__any((emin < -94 || !(vmax <= 0x1p100f)) && gatev > 0.0f), 0)) {
         // an operand left the range where the fast forms are exact: the whole wave redoes the step with IEEE sqrt and division
         e = d_error2(g1, W, wm2, hm2, fW, int(fx), int(fy), ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
         fin = select_step<false>(e, eC, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
