@@ -179,7 +179,10 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, con
   const float cx = __builtin_amdgcn_fmed3f(matchX, 0.0f, wm2);   // min(w-2, max(0, v)) incl. NaN -> 0 (med3 with a NaN input returns min3)
   const float cy = __builtin_amdgcn_fmed3f(matchY, 0.0f, hm2);
   const int x0 = int(cx), y0 = int(cy);
-  const bool inwin = (fabsf(cx - fx) <= float(kRad - 1)) && (fabsf(cy - fy) <= float(kRad - 1));
+  // |flow| <= kRad-1 in both components keeps the four texels inside the window: the clamps only move (cx,cy) towards the
+  // pixel, and int(c), int(c)+1 then lie within [f-7, f+8].  Tested on the flow itself (known at the start of the step),
+  // not on the clamped position: one max + one compare, off the address chain.  (NaN flows compare false -> HBM path.)
+  const bool inwin = __builtin_fmaxf(fabsf(fdx), fabsf(fdy)) <= float(kRad - 1);
   // sweep-order coordinates of texel (x0,y0): u along the step axis, v across the bands
   const int cxc = FWD ? x0 : W - 1 - x0, cyc = FWD ? y0 : H - 1 - y0;
   const int u0 = TR ? cyc : cxc, v0 = TR ? cxc : cyc;
