@@ -230,7 +230,8 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   unsigned h_cnt = 0;
   HIPCHK(c, hipMemcpyAsync(&h_cnt, d_cnt, 4, hipMemcpyDeviceToHost, sm));
   HIPCHK(c, hipStreamSynchronize(sm));
-  const int sparse = (double)h_cnt < 0.5 * (double)g.ws[0] * g.hs[0] ? 1 : 0;
+  int sparse = (double)h_cnt < 0.5 * (double)g.ws[0] * g.hs[0] ? 1 : 0;
+  if (const char* e = getenv("PANOFLOW_SPARSE")) sparse = atoi(e) ? 1 : 0;   // experiment switch: results are identical either way
   HIPCHK(c, hipEventRecord(c->ev_pre, sm));
 
   // --- the two directions are independent (OpticalFlow.cpp:130-139): one stream each ---
