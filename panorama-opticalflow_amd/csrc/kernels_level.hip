@@ -9,9 +9,8 @@ namespace pf {
 // BORDER_REFLECT_101 (PixFlow.hpp:281-294).  Output interleaved (Ix,Iy) so the sweep's bilinear
 // gather fetches both with one 8-byte load per texel.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gradients(const float* __restrict__ img, int w, int h, float2* __restrict__ gxy, Gauss g) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= w) return;
+// Sobel(ksize 1) + Gauss3 sigma 0.5 at one pixel (PixFlow.hpp:281-294); shared by the per-level and the all-levels kernel
+__device__ __forceinline__ float2 d_gradient_px(const float* __restrict__ img, int w, int h, int x, int y, const Gauss& g) {
   const float k0 = g.k[1], k1 = g.k[2];
   const int xm = d_reflect101(x - 1, w), xp = d_reflect101(x + 1, w);
   const int xs[3] = {xm, x, xp};
@@ -34,11 +33,37 @@ __global__ __launch_bounds__(256) void k_gradients(const float* __restrict__ img
   }
   float ox = k0 * tx[1] + 0.0f; ox += k1 * (tx[2] + tx[0]);
   float oy = k0 * ty[1] + 0.0f; oy += k1 * (ty[2] + ty[0]);
-  gxy[size_t(y) * w + x] = make_float2(ox, oy);
+  return make_float2(ox, oy);
+}
+__global__ __launch_bounds__(256) void k_gradients(const float* __restrict__ img, int w, int h, float2* __restrict__ gxy, Gauss g) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  gxy[size_t(y) * w + x] = d_gradient_px(img, w, h, x, y, g);
+}
+// All pyramid levels of both images in ONE launch (the per-level launches of the small levels are pure launch latency):
+// a thread's flat index inside the pyramid plane -> level by binary search in the offset table -> (x, y).
+__global__ __launch_bounds__(256) void k_gradients_all(const float* __restrict__ img0, const float* __restrict__ img1, float2* __restrict__ g0,
+                                                       float2* __restrict__ g1, LevelTable t, unsigned total, Gauss g) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int lo = 0, hi = t.n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (i >= t.off[mid]) lo = mid; else hi = mid - 1; }
+  const int w = t.w[lo], h = t.h[lo];
+  const unsigned local = i - t.off[lo];
+  if (local >= unsigned(w) * unsigned(h)) return;   // padding between levels
+  const int y = int(local / unsigned(w)), x = int(local - unsigned(y) * unsigned(w));
+  const float* img = (blockIdx.y ? img1 : img0) + t.off[lo];
+  float2* out = (blockIdx.y ? g1 : g0) + t.off[lo];
+  out[local] = d_gradient_px(img, w, h, x, y, g);
 }
 void launch_gradients(hipStream_t st, const float* img, int w, int h, float* gxy, const Gauss& g3) {
   dim3 grid((w + 255) / 256, h);
   hipLaunchKernelGGL(k_gradients, grid, dim3(256), 0, st, img, w, h, reinterpret_cast<float2*>(gxy), g3);
+}
+void launch_gradients_all(hipStream_t st, const float* pyr0, const float* pyr1, float* grad0, float* grad1, const LevelTable& t, size_t total,
+                          const Gauss& g3) {
+  hipLaunchKernelGGL(k_gradients_all, dim3((unsigned)((total + 255) / 256), 2), dim3(256), 0, st, pyr0, pyr1, reinterpret_cast<float2*>(grad0),
+                     reinterpret_cast<float2*>(grad1), t, (unsigned)total, g3);
 }
 
 // update gate of the sweeps (PixFlow.hpp:317,330): alpha0 > 0.9 && alpha1 > 0.9

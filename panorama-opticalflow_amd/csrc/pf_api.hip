@@ -209,11 +209,20 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
     launch_pyr_down4(sm, pyrI[0] + g.off[l - 1], pyrI[1] + g.off[l - 1], pyrA[0] + g.off[l - 1], pyrA[1] + g.off[l - 1], g.ws[l - 1], g.hs[l - 1],
                      pyrI[0] + g.off[l], pyrI[1] + g.off[l], pyrA[0] + g.off[l], pyrA[1] + g.off[l], g.ws[l], g.hs[l]);
   }
-  for (int l = 0; l < g.n; ++l) {
+  if (g.n <= kLevelTableMax && g.P < (size_t(1) << 31)) {
+    // gradients and gates of all levels in two launches (the level planes are contiguous; padding between them is skipped / harmless)
     PROF(c, sm, "gradients");
-    launch_gradients(sm, pyrI[0] + g.off[l], g.ws[l], g.hs[l], grad[0] + 2 * g.off[l], c->g3_05);
-    launch_gradients(sm, pyrI[1] + g.off[l], g.ws[l], g.hs[l], grad[1] + 2 * g.off[l], c->g3_05);
-    launch_gate(sm, pyrA[0] + g.off[l], pyrA[1] + g.off[l], g.ws[l] * g.hs[l], gate + g.off[l]);
+    LevelTable t; t.n = g.n;
+    for (int l = 0; l < g.n; ++l) { t.w[l] = g.ws[l]; t.h[l] = g.hs[l]; t.off[l] = (unsigned)g.off[l]; }
+    launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], t, g.P, c->g3_05);
+    launch_gate(sm, pyrA[0], pyrA[1], (int)g.P, gate);
+  } else {
+    for (int l = 0; l < g.n; ++l) {
+      PROF(c, sm, "gradients");
+      launch_gradients(sm, pyrI[0] + g.off[l], g.ws[l], g.hs[l], grad[0] + 2 * g.off[l], c->g3_05);
+      launch_gradients(sm, pyrI[1] + g.off[l], g.ws[l], g.hs[l], grad[1] + 2 * g.off[l], c->g3_05);
+      launch_gate(sm, pyrA[0] + g.off[l], pyrA[1] + g.off[l], g.ws[l] * g.hs[l], gate + g.off[l]);
+    }
   }
   for (int d = 0; d < ndirs; ++d) {
     PROF(c, sm, "init_handoff");

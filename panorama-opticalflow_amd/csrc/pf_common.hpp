@@ -83,6 +83,11 @@ void launch_pyr_down4(hipStream_t st, const float* s0, const float* s1, const fl
                       float* d1, float* d2, float* d3, int dw, int dh);
 // per level
 void launch_gradients(hipStream_t st, const float* img, int w, int h, float* gxy, const Gauss& g3);
+// offsets/sizes of the pyramid levels inside one pyramid plane, passed by value to kernels that cover all levels at once
+constexpr int kLevelTableMax = 96;
+struct LevelTable { int n; int w[kLevelTableMax]; int h[kLevelTableMax]; unsigned off[kLevelTableMax]; };
+void launch_gradients_all(hipStream_t st, const float* pyr0, const float* pyr1, float* grad0, float* grad1, const LevelTable& t, size_t total,
+                          const Gauss& g3);
 void launch_gate(hipStream_t st, const float* a0, const float* a1, int n, uint8_t* gate);
 void launch_count_gate(hipStream_t st, const uint8_t* gate, int n, unsigned* count /* zeroed by the caller */);
 void launch_gauss15(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const Gauss& g15);
