@@ -75,6 +75,47 @@ void launch_gate(hipStream_t st, const float* a0, const float* a1, int n, uint8_
   hipLaunchKernelGGL(k_gate, dim3((n + 255) / 256), dim3(256), 0, st, a0, a1, n, gate);
 }
 
+// Bounding box of the gated pixels of every pyramid level in one launch: box[4*l + {0,1,2,3}] = (min x, min y, max x, max y),
+// initialised by the caller to (INT_MAX, INT_MAX, -1, -1).  A block scans 16 Ki consecutive plane elements, reduces in
+// registers / LDS and issues at most four atomics per level it touched (a chunk spans at most a few of the small levels).
+__global__ __launch_bounds__(256) void k_gate_bbox(const uint8_t* __restrict__ gate, LevelTable t, unsigned total, int* __restrict__ box) {
+  __shared__ int sbox[4];
+  const unsigned base = blockIdx.x * 16384u;
+  int lvl = -1, w = 1, mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -1, mxy = -1;
+  unsigned off = 0, cnt = 0;
+  auto flush = [&]() {   // block-level reduction of one level's partial box, then the atomics
+    if (threadIdx.x < 4) sbox[threadIdx.x] = (threadIdx.x < 2) ? 0x7fffffff : -1;
+    __syncthreads();
+    if (mxx >= 0) { atomicMin(&sbox[0], mnx); atomicMin(&sbox[1], mny); atomicMax(&sbox[2], mxx); atomicMax(&sbox[3], mxy); }
+    __syncthreads();
+    if (threadIdx.x == 0 && sbox[2] >= 0) {
+      atomicMin(&box[4 * lvl + 0], sbox[0]); atomicMin(&box[4 * lvl + 1], sbox[1]);
+      atomicMax(&box[4 * lvl + 2], sbox[2]); atomicMax(&box[4 * lvl + 3], sbox[3]);
+    }
+    __syncthreads();
+    mnx = 0x7fffffff; mny = 0x7fffffff; mxx = -1; mxy = -1;
+  };
+  // all threads of the block walk the levels the chunk intersects in the same order (block-uniform control flow)
+  int l0 = 0, hi = t.n - 1;
+  while (l0 < hi) { const int mid = (l0 + hi + 1) >> 1; if (base >= t.off[mid]) l0 = mid; else hi = mid - 1; }
+  const unsigned end = (base + 16384u < total) ? base + 16384u : total;
+  for (int l = l0; l < t.n && t.off[l] < end; ++l) {
+    lvl = l; w = t.w[l]; off = t.off[l]; cnt = unsigned(t.w[l]) * unsigned(t.h[l]);
+    const unsigned lo = off > base ? off : base, hiE = (off + cnt < end) ? off + cnt : end;
+    for (unsigned i = lo + threadIdx.x; i < hiE; i += 256) {
+      if (gate[i]) {
+        const unsigned local = i - off;
+        const int y = int(local / unsigned(w)), x = int(local - unsigned(y) * unsigned(w));
+        mnx = min(mnx, x); mny = min(mny, y); mxx = max(mxx, x); mxy = max(mxy, y);
+      }
+    }
+    flush();
+  }
+}
+void launch_gate_bbox(hipStream_t st, const uint8_t* gate, const LevelTable& t, size_t total, int* box) {
+  hipLaunchKernelGGL(k_gate_bbox, dim3((unsigned)((total + 16383) / 16384)), dim3(256), 0, st, gate, t, (unsigned)total, box);
+}
+
 __global__ __launch_bounds__(256) void k_count_gate(const uint8_t* __restrict__ gate, int n, unsigned* __restrict__ count) {
   int c = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c += gate[i];

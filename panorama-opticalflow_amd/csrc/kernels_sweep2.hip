@@ -317,7 +317,7 @@ __device__ __forceinline__ void st_cnt(int* p, int v) {
 // wave-uniform, so the per-step "is my top neighbour there" test is two scalar instructions.
 template <int TOP, bool TR, bool FWD, bool SPARSE>
 __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict__ g1, int W, int H, int nsteps, int w, int band,
-                                             int nact, bool publishes, float rW, float rEps) {
+                                             int nact, bool publishes, float rW, float rEps, int uLo, int LSv) {
   constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0;
   const int lane = threadIdx.x & 63;
   const int r = lane >> 3, k = lane & 7;
@@ -351,7 +351,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   const int LBx = transposed ? W : H;
   const float fcross = float(forward ? ib : LBx - 1 - ib);
   const float fLast = float(LS - 1);
-  float fpos = forward ? float(-r) : float(LS - 1 + r);
+  float fpos = forward ? float(uLo - r) : float(LS - 1 - uLo + r);   // step s handles sweep-order column uLo + s - r
   int avail = 0;                       // columns [0, avail) of the row above are known to be in the ring
   unsigned long long tv = 0;           // raw top value for the current step (read during the previous one)
   // flow-control counters for the NEXT chunk, read one chunk ahead (they only grow, a stale value is conservative)
@@ -416,11 +416,11 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       float2 up = prev;   // lanes the two DPP moves do not write (row 0 of the band) keep this: the ring value when there is one
       if (TOP != 0) {
         if (__builtin_expect(s >= avail, 0)) {
-          if (s < LS) {
+          if (s < LSv) {
             // at the edge of the producer: wait for this column (across workgroups: and the next one, i.e. fall one more
             // column behind, so that the following steps find their top value already read despite the HBM hop's jitter).
             // No early exit from the hot loop: a timeout only marks the band dead (checked once per chunk).
-            const int need = (s + 1 + PF_MARGIN(TOP) < LS) ? s + 1 + PF_MARGIN(TOP) : LS;
+            const int need = (s + 1 + PF_MARGIN(TOP) < LSv) ? s + 1 + PF_MARGIN(TOP) : LSv;
             int spins = 0;
 #ifdef PF_SWEEP_STATS
             ++statHits;
@@ -514,23 +514,33 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// prepass: records in wavefront order.  rec[((band*nstepsPad + s)*8 + r)*3 + j], cx = s - r.
+// prepass: records in wavefront order.  rec[((band*nstepsPad + s)*8 + r)*3 + j] for the ACTIVE window of the sweep:
+// band counts from bandLo, step s handles sweep-order column uLo + s - r (columns [uLo, uHi)).
 //   j=0: (I0x, I0y, blurred.x, blurred.y)   j=1: (C.x, C.y, E(C), E(C+dx))   j=2: (E(C+dy), gate, 0, 0)
 //   gate: 1 = update (alpha0,alpha1 > 0.9), 0 = keep C, -1 = no pixel at this (step,row)
+// When the window does not start at the first band, the row above it never changes during this sweep: its flow
+// is written as the granule row the first workgroup's poller reads (top0).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g0, const float2* __restrict__ g1, const float2* __restrict__ blurred,
                                                     const uint8_t* __restrict__ gate, const float2* __restrict__ flow, int W, int H, int forward,
-                                                    int transposed, int nstepsPad, int nbandsPad, float rW, float4* __restrict__ rec) {
+                                                    int transposed, int nstepsPad, int nbandsPad, float rW, float4* __restrict__ rec, int uLo, int uHi,
+                                                    int bandLo, unsigned long long* __restrict__ top0) {
   const size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
+  const int LS = transposed ? H : W, LB = transposed ? W : H;   // extent along the step axis / across the bands
+  if (top0 != nullptr && tid < size_t(uHi - uLo)) {
+    const int ia = uLo + int(tid), ib = bandLo * kRows - 1;
+    const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;
+    const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
+    top0[tid] = pack2(flow[size_t(y) * W + x]);
+  }
   if (tid >= total) return;
   const int r = int(tid % kRows);
   const int s = int((tid / kRows) % nstepsPad);
   const int band = int(tid / (size_t(kRows) * nstepsPad));
-  const int LS = transposed ? H : W, LB = transposed ? W : H;   // extent along the step axis / across the bands
-  const int ia = s - r, ib = band * kRows + r;
+  const int ia = uLo + s - r, ib = (bandLo + band) * kRows + r;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = make_float4(0.f, -1.0f, 0.f, 0.f);
-  if (ia >= 0 && ia < LS && ib < LB) {
+  if (s - r >= 0 && ia < uHi && ia < LS && ib < LB) {
     const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;   // position in sweep order
     const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
     const size_t idx = size_t(y) * W + x;
@@ -558,7 +568,10 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
 template <bool TR, bool FWD, bool SPARSE>
 __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
                                                 unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H,
-                                                int nstepsPad, int nbands, float rW, float rEps) {
+                                                int nstepsPad, int nbands, float rW, float rEps, int uLo, int LSv, int bandLo) {
+  // Active window of this sweep (everything outside it holds pixels that are not updated and keeps its flow):
+  // nbands bands starting at band bandLo, sweep-order columns [uLo, uLo + LSv) along the step axis.  Steps, ring
+  // indices and granule columns are relative to uLo; image coordinates are formed from uLo + relative column.
   constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0;
   __shared__ Smem sm;
   const int tid = threadIdx.x;
@@ -576,10 +589,10 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
   const int wg = sm.wg;
   const int LS = transposed ? H : W, LB = transposed ? W : H;   // extent along the step axis / across the bands
   const int nsteps = nstepsPad;   // LS + kRows - 1 rounded up to whole chunks: the padding steps carry "no pixel" records
-  const int band0 = wg * kWaves;
+  const int band0 = wg * kWaves;                                          // first band of this workgroup, relative to bandLo
   const int nact = (nbands - band0) < kWaves ? (nbands - band0) : kWaves;  // active compute waves in this workgroup
-  const int lastRowOfWG = band0 * kRows + kWaves * kRows - 1;
-  const bool publishes = lastRowOfWG + 1 < LB;                            // another workgroup band follows (then nact == kWaves)
+  const bool publishes = band0 + kWaves < nbands;                         // another workgroup follows (then nact == kWaves)
+  const bool staticTop = bandLo > 0;                                      // the row above the window exists and never changes: prepass wrote it as granule row 0
 
   if (wave < kWaves) {
     // ======================= compute wave: band of 8 rows =======================
@@ -588,11 +601,12 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
 #ifdef PF_SWEEP_STATS
     sm.statEntry = tEntry;
 #endif
-    const int top = (wave > 0) ? 1 : (wg > 0 ? 2 : 0);   // where row 0's top neighbour comes from
+    const int top = (wave > 0) ? 1 : ((wg > 0 || staticTop) ? 2 : 0);   // where row 0's top neighbour comes from
+    const int band = bandLo + band0 + wave;                               // absolute band index
     bool ok;
-    if (top == 1) ok = compute_band<1, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
-    else if (top == 2) ok = compute_band<2, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
-    else ok = compute_band<0, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band0 + wave, nact, publishes, rW, rEps);
+    if (top == 1) ok = compute_band<1, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
+    else if (top == 2) ok = compute_band<2, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
+    else ok = compute_band<0, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
     if (!ok) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #ifdef PF_SWEEP_STATS
     if (lane == 0) { atomicAdd(&ctrl[2], atomicExch(&sm.statHits, 0)); atomicAdd(&ctrl[3], atomicExch(&sm.statSpins, 0)); }
@@ -604,7 +618,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
     // ======================= loader of compute wave w: records + gather window HBM -> LDS, up to kRS steps ahead =======================
     // Window batch b = the 8 texel columns (along the step axis) [8b-16, 8b-8) x kWA texels across the band.
     // A compute wave working on chunk j (steps 8j..8j+7) reads columns [8j-15, 8j+16], i.e. batches j..j+4,
-    // so chunk j is published only after batch j+4 has landed (batches 2..3 in the prologue, batch j+4 with chunk j).
+    // so chunk j is published only after batch j+4 has landed (batches 0..3 in the first round, batch j+4 with chunk j).
     // One loader per compute wave: its in-order memory queue holds nothing but this band's loads, and a round
     // (issue up to kLoadAhead chunks, wait once, registers -> LDS, publish) costs one HBM round trip.
     const int w = wave - kWaves;
@@ -618,7 +632,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
     }
     float2* winw = &sm.win[w][0][0];
     auto win_addr = [&](int b, int k, int& slot) -> const float2* {   // texel k of this lane in batch b
-      const int u = 8 * b - 16 + tc[k], v = (band0 + w) * kRows - kRad + ta[k];
+      const int u = uLo + 8 * b - 16 + tc[k], v = (bandLo + band0 + w) * kRows - kRad + ta[k];   // absolute sweep-order texel
       slot = ta[k] * kWC + (u & (kWC - 1));
       if (!tvalid[k] || u < 0 || u >= LS || v < 0 || v >= LB) return nullptr;
       const int cxc = TR ? v : u, cyc = TR ? u : v;
@@ -633,7 +647,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
       const int oh = first ? 0 : ld_cnt(&sm.outHead[w]);
       float4 va[kLoadAhead], vb[kLoadAhead], vc[kLoadAhead];
       float2 wv[kLoadAhead][4]; int ws[kLoadAhead][4]; bool wok[kLoadAhead][4]; bool ld[kLoadAhead];
-      float2 pv[2][4]; int ps[2][4]; bool pk[2][4];   // first round only: batches 2 and 3
+      float2 pv[4][4]; int ps[4][4]; bool pk[4][4];   // first round only: batches 0..3 (0 and 1 lie before the window: they exist when the window does not start at the image border)
 #pragma unroll
       for (int c = 0; c < kLoadAhead; ++c) {
         const int r0 = rh + c * kChunk;
@@ -654,19 +668,19 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
         }
       }
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           pv[b][k] = make_float2(0.f, 0.f); ps[b][k] = 0; pk[b][k] = false;
           if (first) {
-            const float2* q = win_addr(b + 2, k, ps[b][k]);
+            const float2* q = win_addr(b, k, ps[b][k]);
             pk[b][k] = q != nullptr;
             if (pk[b][k]) pv[b][k] = *q;
           }
         }
       if (first) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
           for (int k = 0; k < 4; ++k)
             if (pk[b][k]) winw[ps[b][k]] = pv[b][k];
@@ -710,8 +724,8 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
             const int j = lane >> 3, r = lane & 7, t = ot + j;
             if (j < n) {
               const float2 val = sm.out[w][t % kOS][r];
-              const int ia = t - r, ib = (band0 + w) * kRows + r;
-              if (ia >= 0 && ia < LS && ib < LB) {
+              const int ia = uLo + t - r, ib = (bandLo + band0 + w) * kRows + r;
+              if (t - r >= 0 && t - r < LSv && ib < LB) {
                 const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;
                 const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
                 flow[size_t(y) * W + x] = val;
@@ -738,7 +752,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
   if (wave == 2 * kWaves) {
     // ======================= publisher: last row of the workgroup -> granules in HBM (tight loop, never waits on HBM) =======================
     if (!publishes) return;
-    unsigned long long* bnd_out = boundary + size_t(wg) * LS;
+    unsigned long long* bnd_out = boundary + size_t(wg + 1) * LSv;   // granule row 0 belongs to the static row above the window
     const int wl = kWaves - 1;
     int pt = 0, idle = 0;
     while (pt < nsteps) {
@@ -749,7 +763,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
         if (lane < n) {
           const float2 val = sm.out[wl][t % kOS][kRows - 1];
           const int cx = t - (kRows - 1);
-          if (cx >= 0 && cx < LS) __hip_atomic_store(bnd_out + cx, pack2(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (cx >= 0 && cx < LSv) __hip_atomic_store(bnd_out + cx, pack2(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         pt += n;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -765,19 +779,19 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
 
   // ======================= poller: previous workgroup's granules HBM -> LDS ring =======================
   {
-    if (wg == 0 || wave != 2 * kWaves + 1) return;
-    const unsigned long long* bnd_in = boundary + size_t(wg - 1) * LS;
+    if ((wg == 0 && !staticTop) || wave != 2 * kWaves + 1) return;
+    const unsigned long long* bnd_in = boundary + size_t(wg) * LSv;
     int bh = 0, idle = 0;
-    while (bh < LS) {
+    while (bh < LSv) {
       const int oh0 = ld_cnt(&sm.outHead[0]);
       if (bh + 64 - oh0 <= kBS) {
         unsigned long long g = kNotReady;
-        if (bh + lane < LS) g = __hip_atomic_load(bnd_in + bh + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool ready = (g != kNotReady) || (bh + lane >= LS);
+        if (bh + lane < LSv) g = __hip_atomic_load(bnd_in + bh + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ready = (g != kNotReady) || (bh + lane >= LSv);
         const unsigned long long m = __ballot(ready);
         const int n = (m == ~0ull) ? 64 : __builtin_ctzll(~m);
         if (n > 0) {
-          if (lane < n && bh + lane < LS) sm.bnd[(bh + lane) % kBS] = g;
+          if (lane < n && bh + lane < LSv) sm.bnd[(bh + lane) % kBS] = g;
           bh += n;
           st_cnt(&sm.bndHead, bh);
           idle = 0;
@@ -793,14 +807,13 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
 }
 
 // ---- host side ----
-// Bands run across the SHORTER image side (fewer band-to-band hand-offs on the critical path):
+// Bands run across the SHORTER side of the active window (fewer band-to-band hand-offs on the critical path):
 // normal = bands of 8 rows stepping along x; transposed = bands of 8 columns stepping along y.
-static inline bool sweep2_transposed(int W, int H) { return W < H; }
 static inline int wgs_for(int LB) { const int nbands = (LB + kRows - 1) / kRows; return (nbands + kWaves - 1) / kWaves; }
 static inline int steps_pad(int LS) { return ((LS + kRows - 1) + kChunk - 1) / kChunk * kChunk; }
 int sweep2_num_wgs(int H) { return wgs_for(H); }
-size_t sweep2_boundary_elems(int W, int H) {   // hand-off granules of one sweep launch, either orientation
-  const size_t a = size_t(wgs_for(H)) * W, b = size_t(wgs_for(W)) * H;
+size_t sweep2_boundary_elems(int W, int H) {   // hand-off granules of one sweep launch, either orientation (+1 row: the static row above the window)
+  const size_t a = size_t(wgs_for(H) + 1) * W, b = size_t(wgs_for(W) + 1) * H;
   return a > b ? a : b;
 }
 size_t sweep2_rec_bytes(int W, int H) {
@@ -808,18 +821,26 @@ size_t sweep2_rec_bytes(int W, int H) {
   return (a > b ? a : b) * kRows * 48;
 }
 void launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
-  const int tr = sweep2_transposed(a.W, a.H) ? 1 : 0;
-  const int LS = tr ? a.H : a.W, LB = tr ? a.W : a.H;
-  const int nbands = (LB + kRows - 1) / kRows, nwg = wgs_for(LB), nbandsPad = nwg * kWaves;
-  const int nstepsPad = steps_pad(LS);
+  // active window in image coordinates (pixels outside it are not updated by this sweep and keep their flow)
+  const int x0 = a.ax0 < 0 ? 0 : a.ax0, y0 = a.ay0 < 0 ? 0 : a.ay0, x1 = a.ax1 > a.W ? a.W : a.ax1, y1 = a.ay1 > a.H ? a.H : a.ay1;
+  if (x1 <= x0 || y1 <= y0) return;   // nothing to update: the sweep is the identity
+  const int tr = (x1 - x0) < (y1 - y0) ? 1 : 0;
+  // the same window in sweep order (mirrored for the backward sweep), as (u = along the step axis, v = across the bands)
+  const int cx0 = a.forward ? x0 : a.W - x1, cx1 = a.forward ? x1 : a.W - x0, cy0 = a.forward ? y0 : a.H - y1, cy1 = a.forward ? y1 : a.H - y0;
+  const int U0 = tr ? cy0 : cx0, U1 = tr ? cy1 : cx1, V0 = tr ? cx0 : cy0, V1 = tr ? cx1 : cy1;
+  const int uLo = U0 > 0 ? U0 - 1 : 0, uHi = U1, LSv = uHi - uLo;   // one column before the window: its (unchanged) flow is the first "previous pixel" proposal
+  const int bandLo = V0 / kRows, bandHi = (V1 + kRows - 1) / kRows, nbands = bandHi - bandLo;
+  const int nwg = (nbands + kWaves - 1) / kWaves, nbandsPad = nwg * kWaves;
+  const int nstepsPad = steps_pad(LSv);
   const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
+  const size_t prepThreads = total > size_t(LSv) ? total : size_t(LSv);
   const float rW = (float)(1.0 / (double)(float)a.W), rEps = (float)(1.0 / (double)kGradEpsilon);
-  hipLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.g0, a.g1, a.blurred, a.gate, a.flow, a.W, a.H, a.forward, tr,
-                     nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec));
+  hipLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((prepThreads + 255) / 256)), dim3(256), 0, st, a.g0, a.g1, a.blurred, a.gate, a.flow, a.W, a.H, a.forward, tr,
+                     nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo, bandLo > 0 ? a.boundary : nullptr);
   const dim3 grid(nwg), block(64 * (2 * kWaves + 3));
   const float4* r4 = reinterpret_cast<const float4*>(rec);
-#define PF_LAUNCH_SWEEP2(TRV, FWV) do { if (a.sparse) hipLaunchKernelGGL((k_sweep2<TRV, FWV, true>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps); \
-    else hipLaunchKernelGGL((k_sweep2<TRV, FWV, false>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps); } while (0)
+#define PF_LAUNCH_SWEEP2(TRV, FWV) do { if (a.sparse) hipLaunchKernelGGL((k_sweep2<TRV, FWV, true>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo); \
+    else hipLaunchKernelGGL((k_sweep2<TRV, FWV, false>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo); } while (0)
   if (tr) { if (a.forward) PF_LAUNCH_SWEEP2(true, true); else PF_LAUNCH_SWEEP2(true, false); }
   else { if (a.forward) PF_LAUNCH_SWEEP2(false, true); else PF_LAUNCH_SWEEP2(false, false); }
 #undef PF_LAUNCH_SWEEP2

@@ -147,12 +147,14 @@ int check_dims(pf_ctx* c, int cols, int rows, int pad) {
 // One level of one direction (PixFlow.hpp:272-340, gradients excluded: they are precomputed for all levels).
 // flow_a holds the incoming flow and receives the level's result (flow_b, blurred, tmp are scratch).
 struct LevelBufs { float *flow_a, *flow_b, *blurred, *tmp, *rec; };
+// box = bounding box (min x, min y, max x, max y) of the gated pixels of this level, or nullptr for "everything"
 void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, const float* a0, const float* a1, const uint8_t* gate, int w, int h, int sparse,
-               const LevelBufs& b, unsigned long long* bnd_fwd, unsigned long long* bnd_bwd, int* ctrl_fwd, int* ctrl_bwd, float** result) {
+               const int* box, const LevelBufs& b, unsigned long long* bnd_fwd, unsigned long long* bnd_bwd, int* ctrl_fwd, int* ctrl_bwd, float** result) {
   { PROF(c, st, "gauss15_blurredFlow"); launch_gauss15(st, b.flow_a, b.tmp, b.blurred, w, h, c->g15); }
   SweepArgs sa;
   sa.g0 = reinterpret_cast<const float2*>(g0); sa.g1 = reinterpret_cast<const float2*>(g1);
   sa.blurred = reinterpret_cast<const float2*>(b.blurred); sa.gate = gate; sa.W = w; sa.H = h; sa.sparse = sparse;
+  if (box) { sa.ax0 = box[0]; sa.ay0 = box[1]; sa.ax1 = box[2] + 1; sa.ay1 = box[3] + 1; }   // empty (max < min): the sweeps are the identity
   auto sweep = [&](const SweepArgs& a) { if (c->sweep_version == 1) launch_sweep(st, a); else launch_sweep2(st, a, b.rec); };
   { PROF(c, st, "sweep"); sa.flow = reinterpret_cast<float2*>(b.flow_a); sa.boundary = bnd_fwd; sa.ctrl = ctrl_fwd; sa.forward = 1; sweep(sa); }
   { PROF(c, st, "median5"); launch_median5(st, b.flow_a, b.flow_b, w, h); }
@@ -160,6 +162,19 @@ void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, cons
   { PROF(c, st, "median5"); launch_median5(st, b.flow_b, b.flow_a, w, h); }
   { PROF(c, st, "gauss15_diffusion"); launch_gauss15_mix(st, b.flow_a, b.tmp, a0, a1, w, h, c->g15, b.flow_b); }
   *result = b.flow_b;
+}
+
+// bounding boxes of the gated pixels of the levels described by t (device gate plane) -> host; one stream sync
+int gate_boxes_to_host(pf_ctx* c, hipStream_t st, const uint8_t* gate, const LevelTable& t, size_t total, std::vector<int>& box) {
+  box.assign(size_t(t.n) * 4, 0);
+  for (int l = 0; l < t.n; ++l) { box[4 * l] = 0x7fffffff; box[4 * l + 1] = 0x7fffffff; box[4 * l + 2] = -1; box[4 * l + 3] = -1; }
+  int* d_box = (int*)ensure(c, "gate_box", size_t(kLevelTableMax) * 4 * sizeof(int));
+  if (!d_box) return PF_ERR_NOMEM;
+  HIPCHK(c, hipMemcpyAsync(d_box, box.data(), box.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  launch_gate_bbox(st, gate, t, total, d_box);
+  HIPCHK(c, hipMemcpyAsync(box.data(), d_box, box.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return 0;
 }
 
 // The whole solver for 1 or 2 directions on device-resident packed BGRA images.
@@ -209,6 +224,7 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
     launch_pyr_down4(sm, pyrI[0] + g.off[l - 1], pyrI[1] + g.off[l - 1], pyrA[0] + g.off[l - 1], pyrA[1] + g.off[l - 1], g.ws[l - 1], g.hs[l - 1],
                      pyrI[0] + g.off[l], pyrI[1] + g.off[l], pyrA[0] + g.off[l], pyrA[1] + g.off[l], g.ws[l], g.hs[l]);
   }
+  bool have_table = false; LevelTable table;
   if (g.n <= kLevelTableMax && g.P < (size_t(1) << 31)) {
     // gradients and gates of all levels in two launches (the level planes are contiguous; padding between them is skipped / harmless)
     PROF(c, sm, "gradients");
@@ -216,6 +232,7 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
     for (int l = 0; l < g.n; ++l) { t.w[l] = g.ws[l]; t.h[l] = g.hs[l]; t.off[l] = (unsigned)g.off[l]; }
     launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], t, g.P, c->g3_05);
     launch_gate(sm, pyrA[0], pyrA[1], (int)g.P, gate);
+    have_table = true; table = t;
   } else {
     for (int l = 0; l < g.n; ++l) {
       PROF(c, sm, "gradients");
@@ -238,7 +255,11 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   launch_count_gate(sm, gate, g.ws[0] * g.hs[0], d_cnt);
   unsigned h_cnt = 0;
   HIPCHK(c, hipMemcpyAsync(&h_cnt, d_cnt, 4, hipMemcpyDeviceToHost, sm));
-  HIPCHK(c, hipStreamSynchronize(sm));
+  // ... and, in the same sync, the bounding box of the gated pixels of every level: the sweeps only cover that window
+  // (everything outside keeps its flow, PixFlow.hpp:317), which removes the wavefront skew of the no-data borders.
+  std::vector<int> boxes;
+  if (have_table && !getenv("PANOFLOW_NO_WINDOW")) { if (int e = gate_boxes_to_host(c, sm, gate, table, g.P, boxes)) return e; }
+  else HIPCHK(c, hipStreamSynchronize(sm));
   int sparse = (double)h_cnt < 0.5 * (double)g.ws[0] * g.hs[0] ? 1 : 0;
   if (const char* e = getenv("PANOFLOW_SPARSE")) sparse = atoi(e) ? 1 : 0;   // experiment switch: results are identical either way
   HIPCHK(c, hipEventRecord(c->ev_pre, sm));
@@ -260,7 +281,8 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
         }
       }
       float* res = nullptr;
-      run_level(c, st, grad[i0] + 2 * o, grad[i1] + 2 * o, pyrA[i0] + o, pyrA[i1] + o, gate + o, w, h, sparse, b, bnd[d] + bnd_off[level],
+      run_level(c, st, grad[i0] + 2 * o, grad[i1] + 2 * o, pyrA[i0] + o, pyrA[i1] + o, gate + o, w, h, sparse, boxes.empty() ? nullptr : &boxes[4 * level], b,
+                bnd[d] + bnd_off[level],
                 bnd[d] + bnd_total + bnd_off[level], ctrl[d] + level * 4, ctrl[d] + level * 4 + 2, &res);
       if (level > 0) {
         PROF(c, st, "upsample_cubic");
@@ -662,6 +684,11 @@ int pf_stage_sweep(pf_ctx* c, const float* g0, const float* g1, const float* blu
   HIPCHK(c, hipMemsetAsync(ctrl, 0, 16, sm));
   SweepArgs sa; sa.g0 = (const float2*)dg0; sa.g1 = (const float2*)dg1; sa.blurred = (const float2*)dbl; sa.gate = gate; sa.flow = (float2*)df;
   sa.boundary = bnd; sa.ctrl = ctrl; sa.W = w; sa.H = h; sa.forward = forward; sa.sparse = (w * h) % 2;   // stage test: exercise both variants
+  {
+    std::vector<int> box; LevelTable t; t.n = 1; t.w[0] = w; t.h[0] = h; t.off[0] = 0;
+    if (int e = gate_boxes_to_host(c, sm, gate, t, n, box)) return e;
+    sa.ax0 = box[0]; sa.ay0 = box[1]; sa.ax1 = box[2] + 1; sa.ay1 = box[3] + 1;
+  }
   float* rec = (float*)ensure(c, "sg_rec", sweep2_rec_bytes(w, h));
   if (!rec) return PF_ERR_NOMEM;
   { PROF(c, sm, "sweep"); if (c->sweep_version == 1) launch_sweep(sm, sa); else launch_sweep2(sm, sa, rec); }
@@ -729,7 +756,9 @@ int pf_stage_level(pf_ctx* c, const float* i0, const float* i1, const float* a0,
     if (max_pct > 0 && hint != PF_HINT_UNKNOWN) launch_adjust_initial_flow(sm, d0, d1, da0, da1, w, h, hint, max_pct, rt, b.flow_a);
   }
   float* res = nullptr;
-  run_level(c, sm, g0, g1, da0, da1, gate, w, h, (w + h) % 2, b, bnd, bnd + nb, ctrl, ctrl + 2, &res);
+  std::vector<int> box;
+  { LevelTable t; t.n = 1; t.w[0] = w; t.h[0] = h; t.off[0] = 0; if (int e = gate_boxes_to_host(c, sm, gate, t, n, box)) return e; }
+  run_level(c, sm, g0, g1, da0, da1, gate, w, h, (w + h) % 2, box.data(), b, bnd, bnd + nb, ctrl, ctrl + 2, &res);
   int hc[4] = {0, 0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(hc, ctrl, 16, hipMemcpyDeviceToHost, sm));
   if (int e = stage_down(c, flow_out, res, n * 8)) return e;

@@ -86,6 +86,7 @@ void launch_gradients(hipStream_t st, const float* img, int w, int h, float* gxy
 // offsets/sizes of the pyramid levels inside one pyramid plane, passed by value to kernels that cover all levels at once
 constexpr int kLevelTableMax = 96;
 struct LevelTable { int n; int w[kLevelTableMax]; int h[kLevelTableMax]; unsigned off[kLevelTableMax]; };
+void launch_gate_bbox(hipStream_t st, const uint8_t* gate, const LevelTable& t, size_t total, int* box);   // box[4*l..]: min x, min y, max x, max y
 void launch_gradients_all(hipStream_t st, const float* pyr0, const float* pyr1, float* grad0, float* grad1, const LevelTable& t, size_t total,
                           const Gauss& g3);
 void launch_gate(hipStream_t st, const float* a0, const float* a1, int n, uint8_t* gate);
@@ -108,6 +109,7 @@ struct SweepArgs {
   int* ctrl;              // [0] ticket, [1] abort/timeout flag
   int W, H, forward;
   int sparse;             // few pixels gated (full-canvas inputs): use the kernel variant that skips ungated anti-diagonals
+  int ax0 = 0, ay0 = 0, ax1 = 1 << 30, ay1 = 1 << 30;   // bounding box [ax0,ax1) x [ay0,ay1) of the gated pixels (default: everything); v2 sweep only
 };
 size_t sweep_boundary_elems(int W, int H);   // hand-off granules needed per sweep launch (covers both sweep kernels)
 void launch_sweep(hipStream_t st, const SweepArgs& a);          // v1: 64 rows per wave, kept as a cross-check (PANOFLOW_SWEEP=1)

@@ -16,3 +16,8 @@ for rep in range(2):
         ts.append(time.time() - t1)
     print("5+top stitch %dx%d: total %.3f s, steps %s" % (cols, rows, time.time() - t0, " ".join("%.3f" % t for t in ts)), flush=True)
 print("final alpha coverage %.3f" % (out[..., 3] > 0).mean())
+if os.environ.get("PROFILE"):
+    ctx.profile_enable(1); ctx.profile_reset()
+    t1 = time.time(); ctx.stitch_step(imgs[2], None, 20, want_out=False); dt = time.time() - t1
+    prof = ctx.profile()
+    print("one profiled step %.3f s; kernel families (ms): %s" % (dt, ", ".join("%s %.2f/%d" % (k, v[0], v[1]) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0]))))

@@ -199,3 +199,28 @@ def test_sweep_operands_outside_fast_math_range(ctx, orc, w, h):
         ref = orc.sweep(g0[..., 0], g0[..., 1], g1[..., 0], g1[..., 1], blurred, a, a, flow, fwd)
         got = ctx.stage_sweep(g0, g1, blurred, a, a, flow, fwd)
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "mismatches %d" % (got.view(np.uint32) != ref.view(np.uint32)).sum()
+
+
+@pytest.mark.parametrize("w,h,box", [(150, 90, (37, 21, 118, 70)), (90, 150, (5, 40, 60, 149)), (130, 130, (0, 0, 50, 130)), (100, 64, (99, 63, 100, 64)),
+                                     (120, 80, (17, 9, 111, 15)), (96, 72, None)])
+def test_sweep_only_covers_the_window_of_gated_pixels(ctx, orc, w, h, box):
+    """The v2 sweep only processes the bounding box of the gated pixels (alpha0, alpha1 > 0.9); everything outside must keep
+    its flow and still act as 'previous pixel' / 'row above' proposal for the window's first column and row.  Windows inside
+    the image, touching borders, one pixel, a thin stripe, and no gated pixel at all (identity); plus holes inside the window."""
+    r = np.random.default_rng(3 * w + h)
+    img0 = r.random((h, w)).astype(np.float32); img1 = r.random((h, w)).astype(np.float32)
+    g0 = np.stack(orc.gradients(img0), -1); g1 = np.stack(orc.gradients(img1), -1)
+    flow = (r.standard_normal((h, w, 2)) * 2.0).astype(np.float32)
+    blurred = orc.gaussian_blur(flow, 15, 8.0)
+    a0 = np.zeros((h, w), np.float32); a1 = np.ones((h, w), np.float32)
+    if box is not None:
+        x0, y0, x1, y1 = box
+        a0[y0:y1, x0:x1] = 1.0
+        a0[y0 + (y1 - y0) // 3:y0 + (y1 - y0) // 2, x0 + (x1 - x0) // 4:x0 + (x1 - x0) // 2] = 0.5     # a hole (not updated) inside
+        a0[y0, x0] = 1.0; a0[y1 - 1, x1 - 1] = 1.0                                                   # keep the corners gated
+    for fwd in (1, 0):
+        ref = orc.sweep(g0[..., 0], g0[..., 1], g1[..., 0], g1[..., 1], blurred, a0, a1, flow, fwd)
+        got = ctx.stage_sweep(g0, g1, blurred, a0, a1, flow, fwd)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "fwd=%d mismatches %d" % (fwd, (got.view(np.uint32) != ref.view(np.uint32)).sum())
+        if box is None:
+            assert np.array_equal(got, flow)
