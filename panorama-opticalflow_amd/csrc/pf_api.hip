@@ -260,7 +260,9 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   std::vector<int> boxes;
   if (have_table && !getenv("PANOFLOW_NO_WINDOW")) { if (int e = gate_boxes_to_host(c, sm, gate, table, g.P, boxes)) return e; }
   else HIPCHK(c, hipStreamSynchronize(sm));
-  int sparse = (double)h_cnt < 0.5 * (double)g.ws[0] * g.hs[0] ? 1 : 0;
+  double area0 = (double)g.ws[0] * g.hs[0];   // the sweeps only cover the window of gated pixels: density inside that window is what counts
+  if (!boxes.empty() && boxes[2] >= boxes[0] && boxes[3] >= boxes[1]) area0 = double(boxes[2] - boxes[0] + 1) * double(boxes[3] - boxes[1] + 1);
+  int sparse = (double)h_cnt < 0.5 * area0 ? 1 : 0;
   if (const char* e = getenv("PANOFLOW_SPARSE")) sparse = atoi(e) ? 1 : 0;   // experiment switch: results are identical either way
   HIPCHK(c, hipEventRecord(c->ev_pre, sm));
 
