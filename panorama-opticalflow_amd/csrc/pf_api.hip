@@ -32,7 +32,8 @@ struct ProfPending { int id; hipEvent_t a, b; };
 
 struct pf_ctx {
   int device = 0;
-  hipStream_t s_main = nullptr, s_dir[2] = {nullptr, nullptr};
+  hipStream_t s_main = nullptr, s_dir[2] = {nullptr, nullptr}, s_aux = nullptr;
+  hipEvent_t ev_aux_go = nullptr, ev_aux_done = nullptr;
   hipEvent_t ev_pre = nullptr, ev_dir[2] = {nullptr, nullptr};
   std::string err;
   std::map<std::string, DevBuf> bufs;  // named grow-only arena: everything a solve needs stays resident
@@ -362,6 +363,8 @@ pf_ctx* pf_create(int device) {
   c->device = device;
   bool ok = hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking) == hipSuccess;
   for (int d = 0; d < 2 && ok; ++d) ok = hipStreamCreateWithFlags(&c->s_dir[d], hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&c->s_aux, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_aux_go, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) == hipSuccess;
   for (int d = 0; d < 2 && ok; ++d) ok = hipEventCreateWithFlags(&c->ev_dir[d], hipEventDisableTiming) == hipSuccess;
   if (!ok) { fail(nullptr, PF_ERR_DEVICE, "stream/event creation failed"); delete c; return nullptr; }
@@ -379,6 +382,9 @@ void pf_destroy(pf_ctx* c) {
   for (auto& p : c->prof_pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   if (c->ev_pre) hipEventDestroy(c->ev_pre);
   for (int d = 0; d < 2; ++d) { if (c->ev_dir[d]) hipEventDestroy(c->ev_dir[d]); if (c->s_dir[d]) hipStreamDestroy(c->s_dir[d]); }
+  if (c->ev_aux_go) hipEventDestroy(c->ev_aux_go);
+  if (c->ev_aux_done) hipEventDestroy(c->ev_aux_done);
+  if (c->s_aux) hipStreamDestroy(c->s_aux);
   if (c->s_main) hipStreamDestroy(c->s_main);
   delete c;
 }
@@ -523,9 +529,9 @@ int pf_blend(pf_ctx* c, const uint8_t* l, const uint8_t* r, size_t step, const f
   return finish(c);
 }
 
-static int blend_smooth_dev(pf_ctx* c, float* d_blend, const float* d_md, int cols, int rows) {
+static int blend_smooth_dev(pf_ctx* c, float* d_blend, const float* d_md, int cols, int rows, hipStream_t sm = nullptr) {
   const int step = cols <= rows ? cols / 200 : rows / 200, k1 = rows / 130, k2 = rows / 400;
-  hipStream_t sm = c->s_main;
+  if (!sm) sm = c->s_main;
   if (step > 0 && k1 > 0) { PROF(c, sm, "tile_blur"); launch_tile_blur(sm, d_blend, d_md, cols, rows, step, k1); }
   if (k2 > 0) {
     double* rs = (double*)ensure(c, "st_rowsum", size_t(cols) * rows * 8);
@@ -602,11 +608,18 @@ int pf_stitch_step(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int 
     HIPCHK(c, hipMemcpyAsync(dr, dfin, n * 4, hipMemcpyDeviceToDevice, sm));
   }
   { PROF(c, sm, "match_images"); launch_match_images(sm, dl, dr, cols, rows, dm, dol, dor); }
-  { PROF(c, sm, "countblend"); launch_countblend(sm, dm, cols, rows, db, dmd); }
-  if (int e = blend_smooth_dev(c, db, dmd, cols, rows)) return e;
+  // The blend ramp (GenerateBlend + countblend + smoothing, StitchTool.cpp:98-191) only depends on the map and is only
+  // needed by the final blend: it runs on its own stream beside the two flow solves.
+  hipStream_t sa = c->s_aux;
+  HIPCHK(c, hipEventRecord(c->ev_aux_go, sm));
+  HIPCHK(c, hipStreamWaitEvent(sa, c->ev_aux_go, 0));
+  { PROF(c, sa, "countblend"); launch_countblend(sa, dm, cols, rows, db, dmd); }
+  if (int e = blend_smooth_dev(c, db, dmd, cols, rows, sa)) return e;
+  HIPCHK(c, hipEventRecord(c->ev_aux_done, sa));
   const int hints[2] = {PF_HINT_LEFT, PF_HINT_RIGHT}; float* outs[2] = {f0, f1};
   const int pad = cols / 20;
-  if (int e = solve(c, dol, dor, cols, rows, pad, max_pct, 2, hints, outs)) return e;
+  if (int e = solve(c, dol, dor, cols, rows, pad, max_pct, 2, hints, outs)) { hipStreamSynchronize(sa); return e; }
+  HIPCHK(c, hipStreamWaitEvent(sm, c->ev_aux_done, 0));
   { PROF(c, sm, "blend"); launch_blend(sm, dol, dor, f0, f1, db, cols, rows, dmerged); }
   { PROF(c, sm, "gather"); launch_gather(sm, dl, dr, dmerged, dm, cols, rows, dfin); }
   if (out) if (int e = down2d(c, out, ostep, dfin, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
