@@ -41,6 +41,37 @@ def gather_to_rank0(local, n_pairs, rank, world, like):
     return out
 
 
+class OverlappedGather:
+    """The path's only exchange, taken off the critical path: the gather of pair k's result to rank 0 runs (on the
+    collective's own stream) while pair k+1 is being computed.  Results alternate between two buffers so that the one a
+    gather is still reading is never the one being written; at most one gather is in flight."""
+
+    def __init__(self, like, world, rank):
+        self.world, self.rank, self.pending, self.k = world, rank, None, 0
+        self.bufs = [like, torch.empty_like(like)]
+        self.recv = [[torch.empty_like(like) for _ in range(world)] for _ in range(2)] if rank == 0 else [None, None]
+
+    def out_buffer(self):
+        """where the next result has to be written"""
+        return self.bufs[self.k % 2]
+
+    def submit(self):
+        """start gathering the buffer just written; waits for the previous gather first"""
+        self.wait()
+        j = self.k % 2
+        self.pending = dist.gather(self.bufs[j], self.recv[j], dst=0, async_op=True)
+        self.k += 1
+
+    def wait(self):
+        if self.pending is not None:
+            self.pending.wait()
+            self.pending = None
+
+    def last(self):
+        """rank 0: the most recently gathered list of results (after wait())"""
+        return self.recv[(self.k - 1) % 2] if self.k else None
+
+
 def max_over_ranks(seconds, device="cpu"):
     """The job's time is the slowest rank's (bench.py contract)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -72,3 +72,43 @@ def test_round_robin_assignment():
     assert sorted(sum((shard.pairs_for_rank(11, r, 3) for r in range(3)), [])) == list(range(11))
     with pytest.raises(ValueError):
         shard.pairs_for_rank(4, 4, 4)
+
+
+def _worker_overlap(rank, world, port, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard = load_pkg_module("shard")
+    like = torch.zeros((6, 5, 4), dtype=torch.uint8)
+    og = shard.OverlappedGather(like, world, rank)
+    seen = []
+    for k in range(steps):
+        buf = og.out_buffer()
+        buf.fill_(10 * k + rank + 1)         # "compute" step k into the buffer no gather is reading
+        og.submit()                          # gather k starts; gather k-1 was waited for inside
+        if rank == 0 and k > 0:
+            pass                             # (the previous result list may be consumed here)
+    og.wait()
+    if rank == 0:
+        seen = [int(t[0, 0, 0]) for t in og.last()]
+    q.put((rank, seen, og.k))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("steps", [1, 4])
+def test_overlapped_gather_two_ranks(steps):
+    """bench.py's N>1 path: the final gather of step k overlaps step k+1 (double-buffered); after wait() rank 0 holds
+    every rank's LAST result."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 1000) + steps
+    procs = [ctx.Process(target=_worker_overlap, args=(r, world, port, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r[0], r) for r in (q.get(timeout=120) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][2] == steps and res[1][2] == steps
+    assert res[0][1] == [10 * (steps - 1) + 1, 10 * (steps - 1) + 2]
