@@ -65,8 +65,9 @@ def main():
     ap.add_argument("--concurrent", type=int, default=1, help="independent pairs in flight per GPU (one context + host thread each); 1 = the BASELINE config")
     args = ap.parse_args()
 
-    if args.concurrent > 1:   # each pair drives 3 HIP streams; the runtime's default of 4 hardware queues would serialise them
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(24, 4 * args.concurrent)))
+    # a context drives 4 HIP streams (front end, two flow directions, blend ramp) next to torch's and RCCL's: with the
+    # runtime's default of 4 hardware queues two of them could share a queue and serialise
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(24, max(8, 4 * args.concurrent))))
     import numpy as np
     import torch  # first: the HIP runtime it loads is the one libpanoflow.so then binds to
     import torch.distributed as dist
