@@ -42,7 +42,7 @@ constexpr int kWA = kRows + 2 * kRad + 1;   // window extent across the band (25
 constexpr int kWC = 64;      // window ring along the step axis (columns)
 constexpr int kSpinLimit2 = 1 << 20;
 #ifndef PF_SWEEP_UNROLL
-#define PF_SWEEP_UNROLL 4
+#define PF_SWEEP_UNROLL 8
 #endif
 #ifndef PF_MARGIN
 #define PF_MARGIN(top) ((top) == 2 ? 1 : 0)   // extra columns to fall behind after catching up with the producer (measured: 0 inside a workgroup, 1 across)
@@ -409,9 +409,16 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
     if (s0 == 8) statR8 = wall_clock64();
     if (s0 == 0) statC0 = wall_clock64();
 #endif
-    const int send = s0 + kChunk;   // nsteps is a whole number of chunks
+    // Ring positions of the chunk (nsteps is a whole number of chunks; every ring length is a multiple of the chunk, so a
+    // chunk never wraps inside a ring): with the step loop unrolled, the per-step ring addresses are base + constant.
+    const float4* recChunk = &sm.rec[w][s0 % kRS][r][0];                    // record of step s0 + j: recChunk + j * kRows * 3
+    const float4* recNext = &sm.rec[w][(s0 + kChunk) % kRS][r][0];          // first record of the next chunk
+    float2* outChunk = &sm.out[w][s0 % kOS][r];                             // result slot of step s0 + j: outChunk + j * kRows
+    const unsigned long long* topChunk = (TOP == 1) ? top_slot(s0 + 1) : &sm.bnd[s0 & (kBS - 1)] + 1;   // top value of column s0 + j + 1
+    const unsigned long long* topNext = top_slot(s0 + kChunk);              // ... of the next chunk's first column
 #pragma unroll PF_SWEEP_UNROLL
-    for (int s = s0; s < send; ++s) {
+    for (int j = 0; j < kChunk; ++j) {
+      const int s = s0 + j;
       // ---- top neighbour: row r-1's result of the previous step (DPP); row 0 of the band from the ring ----
       float2 up = prev;   // lanes the two DPP moves do not write (row 0 of the band) keep this: the ring value when there is one
       if (TOP != 0) {
@@ -458,7 +465,8 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       int hN = 0; unsigned long long tvN = tv;
       // next step's inputs (LDS): records (unconditional: past the chunk it reads a slot that is reloaded at the chunk
       // start anyway), producer counter, then the top value.  Issued behind the gather inside the evaluation below.
-      const float4* rpn = &sm.rec[w][(s + 1) % kRS][r][0];
+      const float4* rpn = (j + 1 < kChunk) ? recChunk + (j + 1) * (kRows * 3) : recNext;
+      const unsigned long long* tpn = (j + 1 < kChunk) ? topChunk + j * ((TOP == 1) ? kRows : 1) : topNext;
       // Sparse overlap (full-canvas inputs, CPU/StitchTool.cpp:17-33): when no pixel of this anti-diagonal is gated
       // the whole step is bookkeeping only (wave-uniform branch; an ungated pixel keeps its flow, PixFlow.hpp:317).
       if (!SPARSE || __any(gatev > 0.0f)) {
@@ -471,7 +479,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       int emin; float vmax;
       float e = d_error_fast<TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, fx, fy, ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy, emin, vmax);
       na = rpn[0]; nb = rpn[1]; nc = *reinterpret_cast<const float2*>(rpn + 2);
-      if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(top_slot(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+      if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
       fin = select_step<true>(e, eC, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
       asm volatile("" : "+v"(fin.x), "+v"(fin.y));   // finish the fast result before the branch: the range test then runs beside the division, not before it
       // Only pixels that will be updated count: the lanes of a pixel without data (gate <= 0) still run the arithmetic, and
@@ -485,7 +493,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       fin.x = bcast8(fin.x); fin.y = bcast8(fin.y);
       } else {
       na = rpn[0]; nb = rpn[1]; nc = *reinterpret_cast<const float2*>(rpn + 2);
-      if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(top_slot(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+      if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
       }
       fpos += forward ? 1.0f : -1.0f;
       if (TOP != 0) {
@@ -498,7 +506,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       }
       prev = fin;   // "no pixel" steps (gate < 0) hand on their zero record: never used as a neighbour (masked / outside the image)
       // ---- publish: result ring (all 8 lanes of a row store the same value to the same slot), then the step counter ----
-      sm.out[w][s % kOS][r] = fin;
+      outChunk[j * kRows] = fin;
       st_cnt(&sm.outHead[w], s + 1);
       ra = na; rb = nb; rc = nc;
     }
