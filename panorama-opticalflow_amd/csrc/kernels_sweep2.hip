@@ -325,7 +325,8 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   const int LS = transposed ? H : W;         // extent along the step axis
   const bool hasCross = ib > 0;              // the cross-lane neighbour (row/column before this one) exists
   const float2* win = &sm.win[w][0][0];
-  const int ob = band * kRows - kRad;         // window origin across the bands
+  int ob = band * kRows - kRad;               // window origin across the bands
+  asm volatile("" : "+s"(ob));                // opaque: otherwise the compiler splits it into (v - band*8) + 8, one more instruction on the address chain
   const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
   const bool candIsT = (k >= 3);
   const int kk = k % 3;
