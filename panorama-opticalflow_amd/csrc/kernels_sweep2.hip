@@ -26,6 +26,7 @@
 // Workgroups take their band index from an atomic ticket (a band only waits for bands already
 // running), every spin is bounded and raises ctrl[1] instead of hanging.
 #include "pf_common.hpp"
+#include "sweep_window.hpp"
 
 namespace pf {
 
@@ -830,17 +831,11 @@ size_t sweep2_rec_bytes(int W, int H) {
   return (a > b ? a : b) * kRows * 48;
 }
 void launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
-  // active window in image coordinates (pixels outside it are not updated by this sweep and keep their flow)
-  const int x0 = a.ax0 < 0 ? 0 : a.ax0, y0 = a.ay0 < 0 ? 0 : a.ay0, x1 = a.ax1 > a.W ? a.W : a.ax1, y1 = a.ay1 > a.H ? a.H : a.ay1;
-  if (x1 <= x0 || y1 <= y0) return;   // nothing to update: the sweep is the identity
-  const int tr = (x1 - x0) < (y1 - y0) ? 1 : 0;
-  // the same window in sweep order (mirrored for the backward sweep), as (u = along the step axis, v = across the bands)
-  const int cx0 = a.forward ? x0 : a.W - x1, cx1 = a.forward ? x1 : a.W - x0, cy0 = a.forward ? y0 : a.H - y1, cy1 = a.forward ? y1 : a.H - y0;
-  const int U0 = tr ? cy0 : cx0, U1 = tr ? cy1 : cx1, V0 = tr ? cx0 : cy0, V1 = tr ? cx1 : cy1;
-  const int uLo = U0 > 0 ? U0 - 1 : 0, uHi = U1, LSv = uHi - uLo;   // one column before the window: its (unchanged) flow is the first "previous pixel" proposal
-  const int bandLo = V0 / kRows, bandHi = (V1 + kRows - 1) / kRows, nbands = bandHi - bandLo;
-  const int nwg = (nbands + kWaves - 1) / kWaves, nbandsPad = nwg * kWaves;
-  const int nstepsPad = steps_pad(LSv);
+  // active window: bounding box of the gated pixels (pixels outside it are not updated by this sweep and keep their flow)
+  const SweepWindow win = make_sweep_window(a.W, a.H, a.forward, a.ax0, a.ay0, a.ax1, a.ay1, kRows, kWaves, kChunk);
+  if (win.empty) return;   // nothing to update: the sweep is the identity
+  const int tr = win.tr, uLo = win.uLo, uHi = win.uHi, LSv = win.LSv, bandLo = win.bandLo, nbands = win.nbands;
+  const int nwg = win.nwg, nbandsPad = nwg * kWaves, nstepsPad = win.nstepsPad;
   const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
   const size_t prepThreads = total > size_t(LSv) ? total : size_t(LSv);
   const float rW = (float)(1.0 / (double)(float)a.W), rEps = (float)(1.0 / (double)kGradEpsilon);
