@@ -202,7 +202,8 @@ def test_sweep_operands_outside_fast_math_range(ctx, orc, w, h):
 
 
 @pytest.mark.parametrize("w,h,box", [(150, 90, (37, 21, 118, 70)), (90, 150, (5, 40, 60, 149)), (130, 130, (0, 0, 50, 130)), (100, 64, (99, 63, 100, 64)),
-                                     (120, 80, (17, 9, 111, 15)), (96, 72, None)])
+                                     (120, 80, (17, 9, 111, 15)), (96, 72, None), (100, 100, (40, 0, 60, 100)), (200, 300, (50, 10, 150, 290)),
+                                     (300, 200, (10, 50, 290, 150))])
 def test_sweep_only_covers_the_window_of_gated_pixels(ctx, orc, w, h, box):
     """The v2 sweep only processes the bounding box of the gated pixels (alpha0, alpha1 > 0.9); everything outside must keep
     its flow and still act as 'previous pixel' / 'row above' proposal for the window's first column and row.  Windows inside
