@@ -225,3 +225,28 @@ def test_sweep_only_covers_the_window_of_gated_pixels(ctx, orc, w, h, box):
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "fwd=%d mismatches %d" % (fwd, (got.view(np.uint32) != ref.view(np.uint32)).sum())
         if box is None:
             assert np.array_equal(got, flow)
+
+
+def test_sweep_fuzz_sizes_gates_and_flows(ctx, orc):
+    """40 seeded random cases: image size, gate pattern (random rectangles of valid alpha with holes, sometimes nothing),
+    flow magnitude (small ... far outside the LDS window) and direction; every one bit-identical to the oracle."""
+    r = np.random.default_rng(20260928)
+    for case in range(40):
+        w, h = int(r.integers(9, 230)), int(r.integers(9, 230))
+        img0 = r.random((h, w)).astype(np.float32); img1 = r.random((h, w)).astype(np.float32)
+        g0 = np.stack(orc.gradients(img0), -1); g1 = np.stack(orc.gradients(img1), -1)
+        flow = (r.standard_normal((h, w, 2)) * float(r.choice([0.3, 2.0, 9.0]))).astype(np.float32)
+        blurred = orc.gaussian_blur(flow, 15, 8.0)
+        a0 = np.zeros((h, w), np.float32); a1 = np.ones((h, w), np.float32)
+        for _ in range(int(r.integers(0, 4))):
+            x0, y0 = int(r.integers(0, w)), int(r.integers(0, h))
+            x1, y1 = int(r.integers(x0, w)) + 1, int(r.integers(y0, h)) + 1
+            a0[y0:y1, x0:x1] = 1.0
+        if r.random() < 0.5:
+            x0, y0 = int(r.integers(0, w)), int(r.integers(0, h))
+            a1[y0:y0 + int(r.integers(1, 20)), x0:x0 + int(r.integers(1, 20))] = 0.3
+        fwd = int(r.integers(0, 2))
+        ref = orc.sweep(g0[..., 0], g0[..., 1], g1[..., 0], g1[..., 1], blurred, a0, a1, flow, fwd)
+        got = ctx.stage_sweep(g0, g1, blurred, a0, a1, flow, fwd)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "case %d (%dx%d fwd=%d): %d mismatches" % (
+            case, w, h, fwd, (got.view(np.uint32) != ref.view(np.uint32)).sum())
