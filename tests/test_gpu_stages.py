@@ -250,3 +250,21 @@ def test_sweep_fuzz_sizes_gates_and_flows(ctx, orc):
         got = ctx.stage_sweep(g0, g1, blurred, a0, a1, flow, fwd)
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "case %d (%dx%d fwd=%d): %d mismatches" % (
             case, w, h, fwd, (got.view(np.uint32) != ref.view(np.uint32)).sum())
+
+
+def test_level_fuzz_alpha_patterns(ctx, orc):
+    """12 seeded random whole-level cases (blurred flow, both sweeps, medians, diffusion) with alpha planes made of random
+    rectangles -- including levels whose gate is empty (sweeps are the identity) or a thin stripe -- bit-identical to the oracle."""
+    r = np.random.default_rng(777)
+    for case in range(12):
+        w, h = int(r.integers(26, 180)), int(r.integers(26, 180))
+        I0 = r.random((h, w)).astype(np.float32); I1 = np.roll(I0, int(r.integers(-3, 4)), axis=1) + 0.03 * r.random((h, w)).astype(np.float32)
+        A0 = np.zeros((h, w), np.float32); A1 = np.zeros((h, w), np.float32)
+        for A in (A0, A1):
+            for _ in range(int(r.integers(0, 3)) + (case % 4 != 0)):
+                x0, y0 = int(r.integers(0, w)), int(r.integers(0, h))
+                A[y0:int(r.integers(y0, h)) + 1, x0:int(r.integers(x0, w)) + 1] = float(r.choice([1.0, 0.95, 0.6]))
+        fin = (r.standard_normal((h, w, 2)) * 1.2).astype(np.float32)
+        ref = orc.level(I0, I1, A0, A1, fin, 0, 0)
+        got = ctx.stage_level(I0, I1, A0, A1, fin, 0, 0)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "case %d (%dx%d): %d mismatches" % (case, w, h, (got.view(np.uint32) != ref.view(np.uint32)).sum())
