@@ -176,3 +176,26 @@ def test_fused_stitch_step_equals_object_sequence(ctx, synth):
         R = ctx.stitch_gather(L, R, merged, mp)
         fused = ctx.stitch_step(L, top if i == 0 else None, 20)
         assert np.array_equal(fused, R), "step %d" % (i + 1)
+
+
+def test_flow_bidir_fuzz_alpha_shapes(ctx, orc, synth):
+    """6 seeded random pairs (odd sizes, both algorithms) whose alpha channels keep only a few random rectangles: every pyramid
+    level then has its own, sometimes empty, window of updated pixels.  Flows bit-identical to the oracle."""
+    r = np.random.default_rng(4242)
+    for case in range(6):
+        cols, rows = int(r.integers(60, 420)), int(r.integers(60, 420))
+        L, R, _ = synth.make_pair_np(cols, rows, 500 + case)
+        L = L.copy(); R = R.copy()
+        for img in (L, R):
+            keep = np.zeros((rows, cols), bool)
+            for _ in range(int(r.integers(1, 4))):
+                x0, y0 = int(r.integers(0, cols)), int(r.integers(0, rows))
+                keep[y0:int(r.integers(y0, rows)) + 1, x0:int(r.integers(x0, cols)) + 1] = True
+            if case == 3:
+                keep[:] = False                      # one image without any valid pixel
+            img[..., 3] = np.where(keep, img[..., 3], 0)
+        max_pct = 20 if case % 2 else 0
+        r0, r1 = orc.flow_bidir(L, R, max_pct)
+        g0, g1 = ctx.flow_bidir(L, R, max_pct)
+        assert np.array_equal(g0.view(np.uint32), r0.view(np.uint32)) and np.array_equal(g1.view(np.uint32), r1.view(np.uint32)), \
+            "case %d (%dx%d, max_pct %d): %d / %d mismatches" % (case, cols, rows, max_pct, (g0 != r0).sum(), (g1 != r1).sum())
