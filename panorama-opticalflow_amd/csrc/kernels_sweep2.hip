@@ -346,6 +346,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 #ifdef PF_SWEEP_STATS
   int statHits = 0, statSpins = 0;
   long long statT0 = 0, statWait = 0, statR8 = 0, statC0 = 0;
+  int statRedo = 0, statOOW = 0;
   int statSlowChunks = 0, statChunkSpins = 0, statFailRec = 0, statFailTail = 0, statFailPub = 0, statFailNext = 0;
   const long long statB = wall_clock64();
 #endif
@@ -479,6 +480,9 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       const bool okL = transposed ? hasCross : hasAlong, okT = transposed ? hasAlong : hasCross;
       const float2 cand = candIsT ? T : L;
       int emin; float vmax;
+#ifdef PF_SWEEP_STATS
+      if (__any(!(__builtin_fmaxf(fabsf(cand.x + addx), fabsf(cand.y + addy)) <= float(kRad - 1)))) ++statOOW;
+#endif
       float e = d_error_fast<TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, fx, fy, ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy, emin, vmax);
       na = rpn[0]; nb = rpn[1]; nc = *reinterpret_cast<const float2*>(rpn + 2);
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -487,6 +491,9 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       // Only pixels that will be updated count: the lanes of a pixel without data (gate <= 0) still run the arithmetic, and
       // there the inputs are blur tails of black borders (operands ~1e-40) -- their result is discarded two lines below.
       if (__builtin_expect(__any((emin < -94 || !(vmax <= 0x1p100f)) && gatev > 0.0f), 0)) {
+#ifdef PF_SWEEP_STATS
+        ++statRedo;
+#endif
         // an operand left the range where the fast forms are exact: the whole wave redoes the step with IEEE sqrt and division
         e = d_error2(g1, W, wm2, hm2, fW, int(fx), int(fy), ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
         fin = select_step<false>(e, eC, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
@@ -516,8 +523,8 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 #ifdef PF_SWEEP_STATS
   if (lane == 0) {
     atomicAdd(&sm.statHits, statHits); atomicAdd(&sm.statSpins, statSpins);
-    if (band < 8 || band % 32 == 1 || (!hasNext && !publishes)) printf("band %d xcc %d: %lld cycles, %lld in chunk-start waits, %d edge waits, %d spins, nsteps %d, slow chunk starts %d (%d spins; first check failed on rec %d tail %d pub %d next %d), step8 at %lld, end at %lld; since kernel entry: band start %lld, first chunk %lld, end %lld (10ns)\n", band, (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF),
-           (long long)__builtin_readcyclecounter() - statT0, statWait, statHits, statSpins, nsteps, statSlowChunks, statChunkSpins, statFailRec, statFailTail, statFailPub, statFailNext, statR8, (long long)wall_clock64(), statB - sm.statEntry, statC0 - sm.statEntry, (long long)wall_clock64() - sm.statEntry);
+    if (band < 8 || band % 32 == 1 || (!hasNext && !publishes)) printf("band %d xcc %d: %lld cycles, %lld in chunk-start waits, %d edge waits, %d spins, nsteps %d, IEEE-redo steps %d, out-of-window steps %d, slow chunk starts %d (%d spins; first check failed on rec %d tail %d pub %d next %d), step8 at %lld, end at %lld; since kernel entry: band start %lld, first chunk %lld, end %lld (10ns)\n", band, (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF),
+           (long long)__builtin_readcyclecounter() - statT0, statWait, statHits, statSpins, nsteps, statRedo, statOOW, statSlowChunks, statChunkSpins, statFailRec, statFailTail, statFailPub, statFailNext, statR8, (long long)wall_clock64(), statB - sm.statEntry, statC0 - sm.statEntry, (long long)wall_clock64() - sm.statEntry);
   }
 #endif
   return !dead;
