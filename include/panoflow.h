@@ -43,7 +43,10 @@ typedef enum pf_hint { PF_HINT_UNKNOWN = 0, PF_HINT_RIGHT = 1, PF_HINT_DOWN = 2,
 /* ---- lifetime -------------------------------------------------------------------------------
  * Replaces the reference's runtime device probe (GPU/OpticalFlow.cpp:132-189, GPU/StitchTool.cpp:33-60). */
 int pf_device_count(void);
-pf_ctx* pf_create(int device);                 /* NULL on failure; pf_last_error(NULL) explains */
+/* max_cols x max_rows > 0: every device buffer a bidirectional solve / a stitch step of that size needs is allocated
+ * now (the first call then pays no allocation); 0 x 0: allocate lazily.  The arena only ever grows, so larger images
+ * are still accepted later.  NULL on failure; pf_last_error(NULL) explains. */
+pf_ctx* pf_create(int device, int max_cols, int max_rows);
 void pf_destroy(pf_ctx* ctx);
 const char* pf_last_error(const pf_ctx* ctx);  /* ctx may be NULL (creation errors) */
 const char* pf_version(void);

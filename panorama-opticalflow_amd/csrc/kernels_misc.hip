@@ -303,6 +303,8 @@ void launch_tile_blur(hipStream_t st, float* blend, const float* mergedDis, int 
   const int a = k / 2, reach = a > (k - 1 - a) ? a : (k - 1 - a);
   const int d = (reach + step - 1) / step, dskew = d + 1;
   const size_t shmem = size_t(step + k - 1) * step * sizeof(double);
+  // canvases beyond ~13000 rows need more than the default 64 KB of dynamic LDS (gfx950 has 160 KB per CU)
+  if (shmem > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_blur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   const int tmax = (ntx - 1) + dskew * (nty - 1);
   for (int t = 0; t <= tmax; ++t) {
     const int ty_min = (t - (ntx - 1) + dskew - 1) / dskew > 0 ? (t - (ntx - 1) + dskew - 1) / dskew : 0;

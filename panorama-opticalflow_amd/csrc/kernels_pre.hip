@@ -143,4 +143,15 @@ void launch_fill_u64(hipStream_t st, unsigned long long* p, size_t n, unsigned l
   hipLaunchKernelGGL(k_fill_u64, dim3(blocks), dim3(256), 0, st, p, n, v);
 }
 
+// Did any sweep launch of a solve give up (ctrl[4*l+1], ctrl[4*l+3])?  One word in mapped pinned host memory per
+// context: the host reads it after the stream sync the call ends with -- no copy, no extra sync.
+__global__ void k_collect_status(const int* __restrict__ ctrl, int nwords, int* __restrict__ status, int bit) {
+  int bad = 0;
+  for (int i = threadIdx.x; i < nwords; i += blockDim.x) if ((i & 1) && ctrl[i]) bad = 1;
+  if (__any(bad) && (threadIdx.x & 63) == 0) __hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_collect_status(hipStream_t st, const int* ctrl, int nwords, int* status, int bit) {
+  hipLaunchKernelGGL(k_collect_status, dim3(1), dim3(64), 0, st, ctrl, nwords, status, bit);
+}
+
 }  // namespace pf

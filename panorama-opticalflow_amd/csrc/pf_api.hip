@@ -41,6 +41,8 @@ struct pf_ctx {
   int prof = 0;   // 0 off, 1 every kernel family, 2 only the dominant family (the sweeps): fewer events in a timed region
   int sweep_version = 2;
   int chain_cols = 0, chain_rows = 0;   // size of the stitch-chain result resident in "ch_final"
+  int* h_status = nullptr;              // mapped pinned host word: bit d set = a sweep band of direction d timed out
+  int* d_status = nullptr;              // the same word as the device sees it
   std::vector<std::string> prof_names;
   std::vector<ProfEntry> prof_tot;
   std::vector<ProfPending> prof_pending;
@@ -137,6 +139,13 @@ Geometry make_geometry(int cols, int rows, int pad) {
   return g;
 }
 
+// plain image entry points (blend / stitch): positive size, pixel count inside the kernels' 32-bit indexing
+int check_image(pf_ctx* c, int cols, int rows) {
+  if (cols <= 0 || rows <= 0) return fail(c, PF_ERR_ARG, "bad image size %dx%d", cols, rows);
+  if ((double)cols * rows > 2.0e9) return fail(c, PF_ERR_ARG, "image too large");
+  return 0;
+}
+
 int check_dims(pf_ctx* c, int cols, int rows, int pad) {
   if (cols <= 0 || rows <= 0) return fail(c, PF_ERR_ARG, "bad image size %dx%d", cols, rows);
   const int w0 = int((cols + 2 * pad) * kDownscaleFactor), h0 = int(rows * kDownscaleFactor);
@@ -178,6 +187,44 @@ int gate_boxes_to_host(pf_ctx* c, hipStream_t st, const uint8_t* gate, const Lev
   return 0;
 }
 
+// Everything one solve keeps in HBM (named grow-only arena): shared pyramids / gradients / gate, per-direction flow
+// planes, record buffers, hand-off granules and control words.  Also used by pf_create's pre-sizing.
+struct SolveBufs {
+  float* pyrI[2]; float* pyrA[2]; float* grad[2];
+  uint8_t* gate; float* half_tmp;
+  std::vector<size_t> bnd_off; size_t bnd_total;
+  LevelBufs lb[2]; unsigned long long* bnd[2]; int* ctrl[2]; float* ratio[2];
+};
+int alloc_solve(pf_ctx* c, const Geometry& g, int ndirs, SolveBufs& b) {
+  const size_t n0 = size_t(g.w0) * g.h0;
+  const char* nI[2] = {"pyrI0", "pyrI1"}; const char* nA[2] = {"pyrA0", "pyrA1"}; const char* nG[2] = {"grad0", "grad1"};
+  for (int i = 0; i < 2; ++i) {
+    b.pyrI[i] = (float*)ensure(c, nI[i], g.P * 4); b.pyrA[i] = (float*)ensure(c, nA[i], g.P * 4); b.grad[i] = (float*)ensure(c, nG[i], g.P * 8);
+    if (!b.pyrI[i] || !b.pyrA[i] || !b.grad[i]) return PF_ERR_NOMEM;
+  }
+  b.gate = (uint8_t*)ensure(c, "gate", g.P);
+  b.half_tmp = (float*)ensure(c, "half_tmp", n0 * 4);
+  if (!b.gate || !b.half_tmp) return PF_ERR_NOMEM;
+  // hand-off rows + control words of every sweep launch of this solve
+  b.bnd_off.assign(g.n, 0);
+  b.bnd_total = 0;
+  for (int l = 0; l < g.n; ++l) { b.bnd_off[l] = b.bnd_total; b.bnd_total += sweep_boundary_elems(g.ws[l], g.hs[l]); }
+  const char* nb[2][8] = {{"d0_flow_a", "d0_flow_b", "d0_blurred", "d0_tmp", "d0_bnd", "d0_ctrl", "d0_ratio", "d0_rec"},
+                          {"d1_flow_a", "d1_flow_b", "d1_blurred", "d1_tmp", "d1_bnd", "d1_ctrl", "d1_ratio", "d1_rec"}};
+  for (int d = 0; d < ndirs; ++d) {
+    b.lb[d].flow_a = (float*)ensure(c, nb[d][0], n0 * 8); b.lb[d].flow_b = (float*)ensure(c, nb[d][1], n0 * 8);
+    b.lb[d].blurred = (float*)ensure(c, nb[d][2], n0 * 8); b.lb[d].tmp = (float*)ensure(c, nb[d][3], n0 * 8);
+    b.bnd[d] = (unsigned long long*)ensure(c, nb[d][4], b.bnd_total * 2 * 8);
+    b.ctrl[d] = (int*)ensure(c, nb[d][5], size_t(g.n) * 2 * 2 * sizeof(int));
+    b.ratio[d] = (float*)ensure(c, nb[d][6], 256);
+    b.lb[d].rec = (float*)ensure(c, nb[d][7], sweep2_rec_bytes(g.w0, g.h0));
+    if (!b.lb[d].rec) return PF_ERR_NOMEM;
+    if (!b.lb[d].flow_a || !b.lb[d].flow_b || !b.lb[d].blurred || !b.lb[d].tmp || !b.bnd[d] || !b.ctrl[d] || !b.ratio[d]) return PF_ERR_NOMEM;
+  }
+  if (!ensure(c, "gate_box", size_t(kLevelTableMax) * 4 * sizeof(int)) || !ensure(c, "gate_count", 256)) return PF_ERR_NOMEM;
+  return 0;
+}
+
 // The whole solver for 1 or 2 directions on device-resident packed BGRA images.
 // dir 0: I0 = img0, I1 = img1, hint0;  dir 1: I0 = img1, I1 = img0, hint1.  out[d]: cols x rows float2 (pad cropped).
 int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int rows, int pad, int max_pct, int ndirs, const int* hints,
@@ -185,34 +232,13 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   if (int e = check_dims(c, cols, rows, pad)) return e;
   if (max_pct < 0 || max_pct > 100) return fail(c, PF_ERR_ARG, "max_percentage %d out of range", max_pct);
   const Geometry g = make_geometry(cols, rows, pad);
-  const size_t n0 = size_t(g.w0) * g.h0;
-  float* pyrI[2]; float* pyrA[2]; float* grad[2];
-  const char* nI[2] = {"pyrI0", "pyrI1"}; const char* nA[2] = {"pyrA0", "pyrA1"}; const char* nG[2] = {"grad0", "grad1"};
-  for (int i = 0; i < 2; ++i) {
-    pyrI[i] = (float*)ensure(c, nI[i], g.P * 4); pyrA[i] = (float*)ensure(c, nA[i], g.P * 4); grad[i] = (float*)ensure(c, nG[i], g.P * 8);
-    if (!pyrI[i] || !pyrA[i] || !grad[i]) return PF_ERR_NOMEM;
-  }
-  uint8_t* gate = (uint8_t*)ensure(c, "gate", g.P);
-  float* half_tmp = (float*)ensure(c, "half_tmp", n0 * 4);
-  if (!gate || !half_tmp) return PF_ERR_NOMEM;
-  // hand-off rows + control words of every sweep launch of this solve
-  std::vector<size_t> bnd_off(g.n);
-  size_t bnd_total = 0;
-  for (int l = 0; l < g.n; ++l) { bnd_off[l] = bnd_total; bnd_total += sweep_boundary_elems(g.ws[l], g.hs[l]); }
-  LevelBufs lb[2]; unsigned long long* bnd[2]; int* ctrl[2]; float* ratio[2];
-  const char* nb[2][8] = {{"d0_flow_a", "d0_flow_b", "d0_blurred", "d0_tmp", "d0_bnd", "d0_ctrl", "d0_ratio", "d0_rec"},
-                          {"d1_flow_a", "d1_flow_b", "d1_blurred", "d1_tmp", "d1_bnd", "d1_ctrl", "d1_ratio", "d1_rec"}};
-  for (int d = 0; d < ndirs; ++d) {
-    lb[d].flow_a = (float*)ensure(c, nb[d][0], n0 * 8); lb[d].flow_b = (float*)ensure(c, nb[d][1], n0 * 8);
-    lb[d].blurred = (float*)ensure(c, nb[d][2], n0 * 8); lb[d].tmp = (float*)ensure(c, nb[d][3], n0 * 8);
-    bnd[d] = (unsigned long long*)ensure(c, nb[d][4], bnd_total * 2 * 8);
-    ctrl[d] = (int*)ensure(c, nb[d][5], size_t(g.n) * 2 * 2 * sizeof(int));
-    ratio[d] = (float*)ensure(c, nb[d][6], 256);
-    lb[d].rec = (float*)ensure(c, nb[d][7], sweep2_rec_bytes(g.w0, g.h0));
-    if (!lb[d].rec) return PF_ERR_NOMEM;
-    if (!lb[d].flow_a || !lb[d].flow_b || !lb[d].blurred || !lb[d].tmp || !bnd[d] || !ctrl[d] || !ratio[d]) return PF_ERR_NOMEM;
-  }
-
+  SolveBufs sb;
+  if (int e = alloc_solve(c, g, ndirs, sb)) return e;
+  float** pyrI = sb.pyrI; float** pyrA = sb.pyrA; float** grad = sb.grad;
+  uint8_t* gate = sb.gate; float* half_tmp = sb.half_tmp;
+  const std::vector<size_t>& bnd_off = sb.bnd_off; const size_t bnd_total = sb.bnd_total;
+  LevelBufs* lb = sb.lb; unsigned long long** bnd = sb.bnd; int** ctrl = sb.ctrl; float** ratio = sb.ratio;
+  *c->h_status = 0;
   hipStream_t sm = c->s_main;
   // --- shared front end on the main stream: half-res planes, pyramids, gradients + gate of ALL levels ---
   const uint8_t* imgs[2] = {d_img0, d_img1};
@@ -267,15 +293,17 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   if (const char* e = getenv("PANOFLOW_SPARSE")) sparse = atoi(e) ? 1 : 0;   // experiment switch: results are identical either way
   HIPCHK(c, hipEventRecord(c->ev_pre, sm));
 
-  // --- the two directions are independent (OpticalFlow.cpp:130-139): one stream each ---
-  for (int d = 0; d < ndirs; ++d) {
-    hipStream_t st = c->s_dir[d];
-    HIPCHK(c, hipStreamWaitEvent(st, c->ev_pre, 0));
-    const int i0 = d, i1 = 1 - d;
-    LevelBufs b = lb[d];
-    for (int level = g.n - 1; level >= 0; --level) {
-      const int w = g.ws[level], h = g.hs[level];
-      const size_t o = g.off[level];
+  // --- the two directions are independent (OpticalFlow.cpp:130-139): one stream each.  The host enqueues them level by
+  // level in turn (a direction's ~430 launches take the host >1 ms: enqueued one after the other, the second
+  // direction's stream would sit idle that long) ---
+  for (int d = 0; d < ndirs; ++d) HIPCHK(c, hipStreamWaitEvent(c->s_dir[d], c->ev_pre, 0));
+  for (int level = g.n - 1; level >= 0; --level) {
+    const int w = g.ws[level], h = g.hs[level];
+    const size_t o = g.off[level];
+    for (int d = 0; d < ndirs; ++d) {
+      hipStream_t st = c->s_dir[d];
+      const int i0 = d, i1 = 1 - d;
+      LevelBufs& b = lb[d];
       if (level == g.n - 1) {
         HIPCHK(c, hipMemsetAsync(b.flow_a, 0, size_t(w) * h * 8, st));  // PixFlow.hpp:298
         if (max_pct > 0 && hints[d] != PF_HINT_UNKNOWN) {
@@ -295,23 +323,21 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
         launch_final_flow(st, res, w, h, g.ce, rows, pad, 1.0f / kDownscaleFactor, c->g3_1, d_out[d]);
       }
     }
-    HIPCHK(c, hipEventRecord(c->ev_dir[d], st));
+  }
+  for (int d = 0; d < ndirs; ++d) {
+    launch_collect_status(c->s_dir[d], ctrl[d], g.n * 4, c->d_status, 1 << d);
+    HIPCHK(c, hipEventRecord(c->ev_dir[d], c->s_dir[d]));
     HIPCHK(c, hipStreamWaitEvent(sm, c->ev_dir[d], 0));
   }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
 
-// after the main stream has drained: did any sweep band give up?
-int check_sweeps(pf_ctx* c, int cols, int rows, int pad, int ndirs) {
-  const Geometry g = make_geometry(cols, rows, pad);
-  std::vector<int> h(size_t(g.n) * 4);
-  const char* names[2] = {"d0_ctrl", "d1_ctrl"};
-  for (int d = 0; d < ndirs; ++d) {
-    HIPCHK(c, hipMemcpy(h.data(), c->bufs[names[d]].p, h.size() * sizeof(int), hipMemcpyDeviceToHost));
-    for (int l = 0; l < g.n; ++l)
-      if (h[l * 4 + 1] || h[l * 4 + 3]) return fail(c, PF_ERR_TIMEOUT, "sweep band timed out (dir %d level %d)", d, l);
-  }
+// after the streams have drained: did any sweep band give up?  (the word lives in mapped pinned host memory and was
+// written by k_collect_status at the end of each direction's stream: no copy, no further sync)
+int check_sweeps(pf_ctx* c, int, int, int, int) {
+  const int st = __atomic_load_n(c->h_status, __ATOMIC_ACQUIRE);
+  if (st) { *c->h_status = 0; return fail(c, PF_ERR_TIMEOUT, "sweep band timed out (direction mask %d)", st); }
   return 0;
 }
 
@@ -319,9 +345,22 @@ int finish(pf_ctx* c) {
   HIPCHK(c, hipStreamSynchronize(c->s_main));
   HIPCHK(c, hipStreamSynchronize(c->s_dir[0]));
   HIPCHK(c, hipStreamSynchronize(c->s_dir[1]));
+  HIPCHK(c, hipStreamSynchronize(c->s_aux));
   if (c->prof) prof_collect(c);
   return 0;
 }
+
+// Every entry point that enqueues work owns one of these: whichever way the call returns (also on an early error,
+// with copies from the caller's buffers or kernels still in flight), all four streams are idle afterwards, so the
+// caller may free or reuse its buffers and the next call starts from a clean pipeline.
+struct CallGuard {
+  pf_ctx* c;
+  explicit CallGuard(pf_ctx* c_) : c(c_) {}
+  ~CallGuard() {
+    if (!c) return;
+    hipStreamSynchronize(c->s_main); hipStreamSynchronize(c->s_dir[0]); hipStreamSynchronize(c->s_dir[1]); hipStreamSynchronize(c->s_aux);
+  }
+};
 
 int use(pf_ctx* c) {
   if (!c) return fail(nullptr, PF_ERR_ARG, "null context");
@@ -351,7 +390,7 @@ int pf_device_count(void) {
 
 const char* pf_version(void) { return "panoflow-mi355x r1 (gfx950)"; }
 
-pf_ctx* pf_create(int device) {
+pf_ctx* pf_create(int device, int max_cols, int max_rows) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { fail(nullptr, PF_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)"); return nullptr; }
   if (device < 0 || device >= n) { fail(nullptr, PF_ERR_ARG, "device %d out of range (0..%d)", device, n - 1); return nullptr; }
@@ -367,9 +406,25 @@ pf_ctx* pf_create(int device) {
   ok = ok && hipEventCreateWithFlags(&c->ev_aux_go, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) == hipSuccess;
   for (int d = 0; d < 2 && ok; ++d) ok = hipEventCreateWithFlags(&c->ev_dir[d], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&c->h_status, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void**)&c->d_status, c->h_status, 0) == hipSuccess;
+  if (ok) *c->h_status = 0;
   if (!ok) { fail(nullptr, PF_ERR_DEVICE, "stream/event creation failed"); delete c; return nullptr; }
   if (const char* sv = getenv("PANOFLOW_SWEEP")) c->sweep_version = atoi(sv) == 1 ? 1 : 2;
   c->g5 = make_gauss(5, 0.25); c->g3_05 = make_gauss(3, 0.5); c->g3_1 = make_gauss(3, 1.0); c->g15 = make_gauss(15, 8.0);
+  // Pre-sizing: every buffer a bidirectional solve / a stitch step on max_cols x max_rows needs is
+  // allocated now, so that the first call does not pay ~40 hipMallocs.  0 x 0 = allocate lazily (the arena only grows).
+  if (max_cols > 0 && max_rows > 0) {
+    const int pad = max_cols / 20;
+    bool ok2 = check_dims(c, max_cols, max_rows, pad) == 0;
+    if (ok2) { SolveBufs sb; ok2 = alloc_solve(c, make_geometry(max_cols, max_rows, pad), 2, sb) == 0; }
+    const size_t n = size_t(max_cols) * max_rows;
+    const struct { const char* name; size_t bytes; } io[] = {
+        {"nv_flow_l2r", n * 8}, {"nv_flow_r2l", n * 8}, {"h_img0", n * 4}, {"h_img1", n * 4}, {"h_flow0", n * 8}, {"h_flow1", n * 8}, {"h_blend", n * 4}, {"h_out", n * 4},
+        {"ch_l", n * 4}, {"ch_r", n * 4}, {"ch_final", n * 4}, {"st_map", n}, {"st_ovl", n * 4}, {"st_ovr", n * 4}, {"st_blend", n * 4}, {"st_md", n * 4},
+        {"st_merged", n * 4}, {"st_rowsum", n * 8}, {"st_blur_tmp", n * 4}};
+    for (const auto& e : io) if (ok2) ok2 = ensure(c, e.name, e.bytes) != nullptr;
+    if (!ok2) { g_err = c->err; pf_destroy(c); return nullptr; }
+  }
   return c;
 }
 
@@ -386,6 +441,7 @@ void pf_destroy(pf_ctx* c) {
   if (c->ev_aux_done) hipEventDestroy(c->ev_aux_done);
   if (c->s_aux) hipStreamDestroy(c->s_aux);
   if (c->s_main) hipStreamDestroy(c->s_main);
+  if (c->h_status) hipHostFree(c->h_status);
   delete c;
 }
 
@@ -407,11 +463,13 @@ void* pf_dev_alloc(pf_ctx* c, size_t bytes) {
 void pf_dev_free(pf_ctx* c, void* p) { if (!use(c) && p) hipFree(p); }
 int pf_upload(pf_ctx* c, void* dst, const void* src, size_t bytes) {
   if (int e = use(c)) return e;
+  CallGuard guard_(c);
   HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
   return 0;
 }
 int pf_download(pf_ctx* c, void* dst, const void* src, size_t bytes) {
   if (int e = use(c)) return e;
+  CallGuard guard_(c);
   HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return 0;
 }
@@ -420,6 +478,7 @@ int pf_sync(pf_ctx* c) { if (int e = use(c)) return e; return finish(c); }
 // ---- device-resident entry points ----
 int pf_flow_bidir_dev(pf_ctx* c, const uint8_t* d_l, const uint8_t* d_r, int cols, int rows, int max_pct, float* d_l2r, float* d_r2l) {
   if (int e = use(c)) return e;
+  CallGuard guard_(c);
   if (!d_l || !d_r || !d_l2r || !d_r2l) return fail(c, PF_ERR_ARG, "null device pointer");
   const int hints[2] = {PF_HINT_LEFT, PF_HINT_RIGHT};  // OpticalFlow.cpp:134,139
   float* outs[2] = {d_l2r, d_r2l};
@@ -432,7 +491,9 @@ int pf_flow_bidir_dev(pf_ctx* c, const uint8_t* d_l, const uint8_t* d_r, int col
 int pf_blend_dev(pf_ctx* c, const uint8_t* d_l, const uint8_t* d_r, const float* d_l2r, const float* d_r2l, const float* d_blend, int cols,
                  int rows, uint8_t* d_out) {
   if (int e = use(c)) return e;
-  if (!d_l || !d_r || !d_l2r || !d_r2l || !d_blend || !d_out || cols <= 0 || rows <= 0) return fail(c, PF_ERR_ARG, "bad argument");
+  CallGuard guard_(c);
+  if (!d_l || !d_r || !d_l2r || !d_r2l || !d_blend || !d_out) return fail(c, PF_ERR_ARG, "null pointer");
+  if (int e = check_image(c, cols, rows)) return e;
   { PROF(c, c->s_main, "blend"); launch_blend(c->s_main, d_l, d_r, d_l2r, d_r2l, d_blend, cols, rows, d_out); }
   HIPCHK(c, hipGetLastError());
   return finish(c);
@@ -441,6 +502,7 @@ int pf_blend_dev(pf_ctx* c, const uint8_t* d_l, const uint8_t* d_r, const float*
 int pf_novel_view_dev(pf_ctx* c, const uint8_t* d_l, const uint8_t* d_r, int cols, int rows, int max_pct, const float* d_blend, uint8_t* d_out,
                       float* d_l2r, float* d_r2l) {
   if (int e = use(c)) return e;
+  CallGuard guard_(c);
   if (!d_l || !d_r || !d_blend || !d_out) return fail(c, PF_ERR_ARG, "null device pointer");
   if (int e = check_dims(c, cols, rows, cols / 20)) return e;
   float* f0 = d_l2r ? d_l2r : (float*)ensure(c, "nv_flow_l2r", size_t(cols) * rows * 8);
@@ -459,6 +521,7 @@ int pf_novel_view_dev(pf_ctx* c, const uint8_t* d_l, const uint8_t* d_r, int col
 // ---- host-buffer entry points ----
 int pf_flow(pf_ctx* c, const uint8_t* i0, const uint8_t* i1, int cols, int rows, size_t step, int max_pct, int hint, float* flow, size_t fstep) {
   if (int e = use(c)) return e;
+  CallGuard guard_(c);
   if (!i0 || !i1 || !flow) return fail(c, PF_ERR_ARG, "null pointer");
   if (int e = check_dims(c, cols, rows, 0)) return e;
   if (step < size_t(cols) * 4 || fstep < size_t(cols) * 8) return fail(c, PF_ERR_ARG, "row step too small");
@@ -479,6 +542,7 @@ int pf_flow(pf_ctx* c, const uint8_t* i0, const uint8_t* i1, int cols, int rows,
 int pf_novel_view(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int rows, size_t step, int max_pct, const float* blend, size_t bstep,
                   uint8_t* out, size_t ostep, float* f_l2r, float* f_r2l, size_t fstep) {
   if (int e = use(c)) return e;
+  CallGuard guard_(c);
   if (!l || !r) return fail(c, PF_ERR_ARG, "null pointer");
   if (int e = check_dims(c, cols, rows, cols / 20)) return e;
   if (step < size_t(cols) * 4) return fail(c, PF_ERR_ARG, "row step too small");
@@ -513,7 +577,10 @@ int pf_flow_bidir(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int r
 int pf_blend(pf_ctx* c, const uint8_t* l, const uint8_t* r, size_t step, const float* f_l2r, const float* f_r2l, size_t fstep, const float* blend,
              size_t bstep, int cols, int rows, uint8_t* out, size_t ostep) {
   if (int e = use(c)) return e;
-  if (!l || !r || !f_l2r || !f_r2l || !blend || !out || cols <= 0 || rows <= 0) return fail(c, PF_ERR_ARG, "bad argument");
+  CallGuard guard_(c);
+  if (!l || !r || !f_l2r || !f_r2l || !blend || !out) return fail(c, PF_ERR_ARG, "null pointer");
+  if (int e = check_image(c, cols, rows)) return e;
+  if (step < size_t(cols) * 4 || ostep < size_t(cols) * 4 || bstep < size_t(cols) * 4 || fstep < size_t(cols) * 8) return fail(c, PF_ERR_ARG, "row step too small");
   const size_t ib = size_t(cols) * rows * 4, fb = size_t(cols) * rows * 8;
   uint8_t* dl = (uint8_t*)ensure(c, "h_img0", ib); uint8_t* dr = (uint8_t*)ensure(c, "h_img1", ib); uint8_t* dout = (uint8_t*)ensure(c, "h_out", ib);
   float* d0 = (float*)ensure(c, "h_flow0", fb); float* d1 = (float*)ensure(c, "h_flow1", fb); float* db = (float*)ensure(c, "h_blend", ib);
@@ -532,7 +599,11 @@ int pf_blend(pf_ctx* c, const uint8_t* l, const uint8_t* r, size_t step, const f
 static int blend_smooth_dev(pf_ctx* c, float* d_blend, const float* d_md, int cols, int rows, hipStream_t sm = nullptr) {
   const int step = cols <= rows ? cols / 200 : rows / 200, k1 = rows / 130, k2 = rows / 400;
   if (!sm) sm = c->s_main;
-  if (step > 0 && k1 > 0) { PROF(c, sm, "tile_blur"); launch_tile_blur(sm, d_blend, d_md, cols, rows, step, k1); }
+  if (step > 0 && k1 > 0) {
+    // the tile kernel keeps (step+k1-1) x step row sums in LDS: 160 KB per CU bound the canvas at ~17900 rows
+    if (size_t(step + k1 - 1) * step * sizeof(double) > 160 * 1024) return fail(c, PF_ERR_ARG, "canvas %dx%d too large for the blend-ramp tile smoothing (LDS)", cols, rows);
+    PROF(c, sm, "tile_blur"); launch_tile_blur(sm, d_blend, d_md, cols, rows, step, k1);
+  }
   if (k2 > 0) {
     double* rs = (double*)ensure(c, "st_rowsum", size_t(cols) * rows * 8);
     float* tmp = (float*)ensure(c, "st_blur_tmp", size_t(cols) * rows * 4);
@@ -547,7 +618,10 @@ static int blend_smooth_dev(pf_ctx* c, float* d_blend, const float* d_md, int co
 int pf_stitch_prepare(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int rows, size_t step, uint8_t* map_out, size_t mstep, uint8_t* ovl,
                       uint8_t* ovr, float* blend_out, size_t bstep, float* merged_dis) {
   if (int e = use(c)) return e;
-  if (!l || !r || cols <= 0 || rows <= 0 || step < size_t(cols) * 4) return fail(c, PF_ERR_ARG, "bad argument");
+  CallGuard guard_(c);
+  if (!l || !r) return fail(c, PF_ERR_ARG, "null pointer");
+  if (int e = check_image(c, cols, rows)) return e;
+  if (step < size_t(cols) * 4 || (map_out && mstep < size_t(cols)) || (blend_out && bstep < size_t(cols) * 4)) return fail(c, PF_ERR_ARG, "row step too small");
   const size_t n = size_t(cols) * rows;
   uint8_t* dl = (uint8_t*)ensure(c, "h_img0", n * 4); uint8_t* dr = (uint8_t*)ensure(c, "h_img1", n * 4);
   uint8_t* dm = (uint8_t*)ensure(c, "st_map", n); uint8_t* dol = (uint8_t*)ensure(c, "st_ovl", n * 4); uint8_t* dor = (uint8_t*)ensure(c, "st_ovr", n * 4);
@@ -571,7 +645,10 @@ int pf_stitch_prepare(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, i
 int pf_stitch_gather(pf_ctx* c, const uint8_t* l, const uint8_t* r, const uint8_t* merged, size_t step, const uint8_t* map, size_t mstep, int cols,
                      int rows, uint8_t* out, size_t ostep) {
   if (int e = use(c)) return e;
-  if (!l || !r || !merged || !map || !out || cols <= 0 || rows <= 0) return fail(c, PF_ERR_ARG, "bad argument");
+  CallGuard guard_(c);
+  if (!l || !r || !merged || !map || !out) return fail(c, PF_ERR_ARG, "null pointer");
+  if (int e = check_image(c, cols, rows)) return e;
+  if (step < size_t(cols) * 4 || ostep < size_t(cols) * 4 || mstep < size_t(cols)) return fail(c, PF_ERR_ARG, "row step too small");
   const size_t n = size_t(cols) * rows;
   uint8_t* dl = (uint8_t*)ensure(c, "h_img0", n * 4); uint8_t* dr = (uint8_t*)ensure(c, "h_img1", n * 4); uint8_t* dg = (uint8_t*)ensure(c, "st_merged", n * 4);
   uint8_t* dm = (uint8_t*)ensure(c, "st_map", n); uint8_t* dout = (uint8_t*)ensure(c, "h_out", n * 4);
@@ -592,8 +669,10 @@ int pf_stitch_gather(pf_ctx* c, const uint8_t* l, const uint8_t* r, const uint8_
 // r_bgra == NULL chains on the previous call's result, which stays resident in HBM (main.cpp:64-65).
 int pf_stitch_step(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int rows, size_t step, int max_pct, uint8_t* out, size_t ostep) {
   if (int e = use(c)) return e;
-  if (!l || cols <= 0 || rows <= 0 || step < size_t(cols) * 4) return fail(c, PF_ERR_ARG, "bad argument");
+  CallGuard guard_(c);
+  if (!l) return fail(c, PF_ERR_ARG, "null pointer");
   if (int e = check_dims(c, cols, rows, cols / 20)) return e;
+  if (step < size_t(cols) * 4 || (out && ostep < size_t(cols) * 4)) return fail(c, PF_ERR_ARG, "row step too small");
   const size_t n = size_t(cols) * rows;
   uint8_t* dl = (uint8_t*)ensure(c, "ch_l", n * 4); uint8_t* dr = (uint8_t*)ensure(c, "ch_r", n * 4); uint8_t* dfin = (uint8_t*)ensure(c, "ch_final", n * 4);
   uint8_t* dm = (uint8_t*)ensure(c, "st_map", n); uint8_t* dol = (uint8_t*)ensure(c, "st_ovl", n * 4); uint8_t* dor = (uint8_t*)ensure(c, "st_ovr", n * 4);
@@ -630,7 +709,7 @@ int pf_stitch_step(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int 
 }
 
 // ---- stage-level entry points (tests) ----
-#define STAGE_BEGIN(c) if (int e_ = use(c)) return e_; hipStream_t sm = c->s_main; (void)sm
+#define STAGE_BEGIN(c) if (int e_ = use(c)) return e_; CallGuard guard_(c); hipStream_t sm = c->s_main; (void)sm
 static void* stage_up(pf_ctx* c, const char* name, const void* host, size_t bytes) {
   void* d = ensure(c, name, bytes);
   if (d && host) hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, c->s_main);

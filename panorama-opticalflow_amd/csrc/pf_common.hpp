@@ -131,5 +131,6 @@ void launch_tile_blur(hipStream_t st, float* blend, const float* mergedDis, int 
 void launch_gather(hipStream_t st, const uint8_t* L, const uint8_t* R, const uint8_t* merged, const uint8_t* map, int cols, int rows,
                    uint8_t* out);
 void launch_fill_u64(hipStream_t st, unsigned long long* p, size_t n, unsigned long long v);
+void launch_collect_status(hipStream_t st, const int* ctrl, int nwords, int* status_mapped, int bit);
 
 }  // namespace pf

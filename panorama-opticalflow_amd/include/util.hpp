@@ -5,6 +5,8 @@
 
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <memory>
@@ -107,7 +109,10 @@ static inline pf_ctx* context() {
   static thread_local ContextHolder holder;
   if (!holder.ctx) {
     const char* env = std::getenv("PANOFLOW_DEVICE");
-    holder.ctx = pf_create(env ? std::atoi(env) : 0);
+    // PANOFLOW_PRESIZE=COLSxROWS allocates every device buffer for that image size up front (pf_create's pre-sizing)
+    int mc = 0, mr = 0;
+    if (const char* ps = std::getenv("PANOFLOW_PRESIZE")) { if (std::sscanf(ps, "%dx%d", &mc, &mr) != 2) mc = mr = 0; }
+    holder.ctx = pf_create(env ? std::atoi(env) : 0, mc, mr);
     if (!holder.ctx) throw util::VrCamException(std::string("panoflow: ") + pf_last_error(nullptr));
   }
   return holder.ctx;

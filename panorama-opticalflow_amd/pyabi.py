@@ -36,7 +36,7 @@ def lib():
             raise PanoflowError("libpanoflow.so is not built (run __graft_entry__.build()); there is no fallback path")
         _lib = C.CDLL(SO_PATH)
         _lib.pf_create.restype = C.c_void_p
-        _lib.pf_create.argtypes = [C.c_int]
+        _lib.pf_create.argtypes = [C.c_int, C.c_int, C.c_int]
         _lib.pf_destroy.argtypes = [C.c_void_p]
         _lib.pf_last_error.restype = C.c_char_p
         _lib.pf_last_error.argtypes = [C.c_void_p]
@@ -62,7 +62,9 @@ EXPORTS = [
 
 
 def _p(a):
-    return C.c_void_p(a.ctypes.data)
+    # data_as keeps a reference to the array inside the returned ctypes object, so a converted temporary
+    # (_p(_f32(x)) where x needed a copy) stays alive for the duration of the C call
+    return a.ctypes.data_as(C.c_void_p)
 
 
 def _f32(a):
@@ -92,9 +94,9 @@ def level_pixels(cols, rows):
 
 
 class Context:
-    def __init__(self, device=0):
+    def __init__(self, device=0, max_cols=0, max_rows=0):
         self.l = lib()
-        h = self.l.pf_create(device)
+        h = self.l.pf_create(device, max_cols, max_rows)
         if not h:
             raise PanoflowError("pf_create failed: " + self.l.pf_last_error(None).decode())
         self.h = C.c_void_p(h)  # keep it a c_void_p: a bare int would be passed as a 32-bit C int

@@ -55,7 +55,12 @@ static inline void lzw_decode(const unsigned char* src, size_t n, std::vector<un
   for (int i = 0; i < 256; ++i) { prefix[i] = -1; suffix[i] = first[i] = (unsigned char)i; length[i] = 1; }
   int next = 258, bits = 9, old = -1; unsigned acc = 0; int nacc = 0; size_t pos = 0;
   std::vector<unsigned char> tmp(4096);
-  auto emit = [&](int code) { int len = length[code]; size_t base = out.size(); out.resize(base + len); int c = code; for (int i = len - 1; i >= 0; --i) { out[base + i] = suffix[c]; c = prefix[c]; } };
+  // a corrupt stream must not walk off the table: every code emitted is < next, its chain has exactly length[code] links
+  auto emit = [&](int code) -> bool {
+    const int len = length[code]; const size_t base = out.size(); out.resize(base + len); int c = code;
+    for (int i = len - 1; i >= 0; --i) { if (c < 0) return false; out[base + i] = suffix[c]; c = prefix[c]; }
+    return true;
+  };
   while (out.size() < expect) {
     while (nacc < bits && pos < n) { acc = (acc << 8) | src[pos++]; nacc += 8; }
     if (nacc < bits) break;
@@ -63,12 +68,14 @@ static inline void lzw_decode(const unsigned char* src, size_t n, std::vector<un
     if (code == 257) break;
     if (code == 256) { next = 258; bits = 9; old = -1; continue; }
     if (old < 0) { if (code >= 256) break; emit(code); old = code; continue; }
+    if (code > next || code >= 4096) break;   // not a code the encoder can have produced
     if (code < next) {
-      emit(code);
+      if (!emit(code)) break;
       if (next < 4096) { prefix[next] = old; suffix[next] = first[code]; first[next] = first[old]; length[next] = length[old] + 1; ++next; }
     } else {
       if (next < 4096) { prefix[next] = old; suffix[next] = first[old]; first[next] = first[old]; length[next] = length[old] + 1; ++next; }
-      emit(next - 1);
+      else break;                     // table full: "code == next" cannot occur
+      if (!emit(next - 1)) break;
     }
     old = code;
     if (next + 1 >= (1 << bits) && bits < 12) ++bits;   // early change
@@ -114,6 +121,8 @@ static inline Mat read_tiff(const std::string& path) {
   if (!w || !h || bps != 8 || planar != 1 || (spp != 3 && spp != 4) || photo != 2 || so.empty() || so.size() != sc.size())
     throw VrCamException("unsupported TIFF layout (need 8-bit chunky RGB/RGBA strips): " + path);
   if (rps > h) rps = h;
+  if (rps == 0 || so.size() != (size_t(h) + rps - 1) / rps) throw VrCamException("inconsistent TIFF strip table (RowsPerStrip / StripOffsets): " + path);
+  if ((double)w * h > 4.0e9) throw VrCamException("TIFF too large: " + path);
   std::vector<unsigned char> pix; pix.reserve(size_t(w) * h * spp);
   for (size_t s = 0; s < so.size(); ++s) {
     const unsigned rows = (unsigned)std::min<size_t>(rps, h - s * rps);
@@ -129,6 +138,7 @@ static inline Mat read_tiff(const std::string& path) {
     if (pred == 2)
       for (unsigned y = 0; y < rows; ++y) { unsigned char* r = pix.data() + before + size_t(y) * w * spp; for (size_t i = spp; i < size_t(w) * spp; ++i) r[i] = (unsigned char)(r[i] + r[i - spp]); }
   }
+  if (pix.size() != size_t(w) * h * spp) throw VrCamException("TIFF strips do not cover the image: " + path);
   Mat m(h, w, panocv::CV_8UC4);
   for (unsigned y = 0; y < h; ++y)
     for (unsigned x = 0; x < w; ++x) {
@@ -173,7 +183,7 @@ static inline Mat read_png(const std::string& path) {
   for (size_t o = 8; o + 12 <= b.size();) {
     const unsigned n = rd(o); const char* ty = (const char*)&b[o + 4];
     if (o + 12 + n > b.size()) break;
-    if (!memcmp(ty, "IHDR", 4)) { w = rd(o + 8); h = rd(o + 12); ct = b[o + 17]; if (b[o + 16] != 8 || b[o + 20] != 0 || (ct != 2 && ct != 6)) throw VrCamException("unsupported PNG (need 8-bit RGB/RGBA, non-interlaced): " + path); }
+    if (!memcmp(ty, "IHDR", 4)) { if (n != 13) throw VrCamException("bad PNG header: " + path); w = rd(o + 8); h = rd(o + 12); ct = b[o + 17]; if (b[o + 16] != 8 || b[o + 20] != 0 || (ct != 2 && ct != 6)) throw VrCamException("unsupported PNG (need 8-bit RGB/RGBA, non-interlaced): " + path); }
     else if (!memcmp(ty, "IDAT", 4)) z.insert(z.end(), b.begin() + o + 8, b.begin() + o + 8 + n);
     o += 12 + n;
   }

@@ -77,3 +77,89 @@ def test_canvas_stitch_step_window_and_sparse_switches(pf, synth):
     for name, value in (("PANOFLOW_NO_WINDOW", "1"), ("PANOFLOW_SPARSE", "0"), ("PANOFLOW_SPARSE", "1")):
         assert np.array_equal(ref, _with_env(name, value, chain)), name
     c.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE configs 2 and 3 at their real size, directly against the oracle (the GPU box's host finishes one
+# 2000x4000 direction in ~13-25 s; the four oracle solves run on four host threads).
+# ---------------------------------------------------------------------------------------------------------------
+def test_strip_pixflow_low_and_search_20_vs_oracle(pf, orc, strip):
+    import threading
+    L, R, blend = strip
+    ref = {}
+
+    def run(pct, d):
+        ref[(pct, d)] = orc.flow_one_dir(L, R, pct, d)
+
+    th = [threading.Thread(target=run, args=(pct, d)) for pct in (0, 20) for d in (0, 1)]
+    [t.start() for t in th]
+    c = pf.Context(0)
+    got = {pct: c.novel_view(L, R, pct, blend) for pct in (0, 20)}
+    c.close()
+    [t.join() for t in th]
+    for pct in (0, 20):
+        out, f0, f1 = got[pct]
+        r0, r1 = ref[(pct, 0)], ref[(pct, 1)]
+        # tolerance for the flows: none -- bit-identical
+        assert np.array_equal(f0.view(np.uint32), r0.view(np.uint32)), "pixflow %d L->R" % pct
+        assert np.array_equal(f1.view(np.uint32), r1.view(np.uint32)), "pixflow %d R->L" % pct
+        rout = orc.combine_novel_views(L, R, r0, r1, blend)
+        d = np.abs(out.astype(np.int32) - rout.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 2e-3          # libm ulps in tanhf/exp of the blend only
+    # the wide-search path (PixFlow.hpp:226-270,296-303) really took part: it changes the result
+    assert not np.array_equal(got[0][1], got[20][1])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 4 (5+top chain, 9000x4000, pixflow_search_20) against the oracle chain computed in the build
+# container (tests/golden/make_chain_golden.py -> chain_9000x4000.npz).
+# ---------------------------------------------------------------------------------------------------------------
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+# PSNR floor of step i of the chain vs the oracle chain, on the fixture's stride-8 subsample.  Step 1 sees identical
+# inputs (<= 1 LSB off in rare pixels); from step 2 on the inputs differ in those LSBs and the solver's strict '<'
+# decisions amplify them.  Measured values are printed by the test and kept in DESIGN.md.
+CHAIN_PSNR_FLOOR = (60.0, 45.0, 42.0, 40.0, 40.0)
+
+
+def test_config4_chain_vs_oracle_fixture(pf, synth):
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chain_9000x4000.npz")
+    g = np.load(path)
+    cols, rows, stride, pct = int(g["cols"]), int(g["rows"]), int(g["stride"]), int(g["max_pct"])
+    top, imgs = synth.make_stitch_set(cols, rows, int(g["seed"]), 5, "cpu")       # CPU: the generator the fixture used
+    top = top.numpy(); imgs = [im.numpy() for im in imgs]
+    shas = [_sha(top)] + [_sha(im) for im in imgs]
+    assert shas == list(g["sha_inputs"]), "synthetic canvases differ from the ones the fixture was computed on"
+    c = pf.Context(0)
+    # ---- step 1, stage by stage: everything up to the flows is bit-identical to the oracle ----
+    mp, ovl, ovr, bl, md = c.stitch_prepare(imgs[0], top)
+    s_map, s_blend, s_md, s_f0, s_f1, s_merged = list(g["sha_step1"])
+    assert _sha(mp) == s_map and _sha(bl) == s_blend and _sha(md) == s_md
+    f0, f1 = c.flow_bidir(ovl, ovr, pct)
+    assert _sha(f0) == s_f0 and _sha(f1) == s_f1, "step-1 flows are not bit-identical to the oracle's"
+    merged = c.blend(ovl, ovr, f0, f1, bl)
+    d = np.abs(merged[::stride, ::stride].astype(np.int32) - g["merged1_sub"].astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3
+    del mp, ovl, ovr, bl, md, f0, f1, merged
+    # ---- the whole chain through the fused, device-resident entry point ----
+    psnr = []
+    for i, L in enumerate(imgs):
+        out = c.stitch_step(L, top if i == 0 else None, pct, want_out=True)
+        ref = g["final%d_sub" % (i + 1)]
+        sub = out[::stride, ::stride]
+        psnr.append(_psnr(sub, ref))
+        if i == 0:
+            d = np.abs(sub.astype(np.int32) - ref.astype(np.int32))
+            assert d.max() <= 1 and (d > 0).mean() < 2e-3
+    c.close()
+    print("config-4 chain PSNR vs oracle per step:", ["%.1f" % p for p in psnr])
+    for p, floor in zip(psnr, CHAIN_PSNR_FLOOR):
+        assert p >= floor, psnr
