@@ -1,15 +1,24 @@
 #!/usr/bin/env python
-"""Benchmark of the hot path: Mpix/s of bidirectional PixFlow + novel-view blend on one overlap strip
-per GPU (BASELINE.json configs[1]: 2000x4000, pixflow_low), inputs resident in HBM when the clock starts.
+"""Benchmark of the hot path: Mpix/s of bidirectional PixFlow + novel-view blend, inputs resident in HBM
+when the clock starts.
 
-One process per GPU (torch.distributed / RCCL for the barrier, the max-over-ranks time and the final
-gather of the blended strips to rank 0); each rank owns one independent pair -> weak scaling.
-Prints ONE JSON line on rank 0.
+  --gpus 1 (default): BASELINE.json configs[1] -- ONE 2000x4000 overlap strip, pixflow_low.  `value` is quoted on it.
+      The same JSON line carries, as extra keys, the other single-GPU configs timed in-process:
+      `canvas_pair_9000x4000` (north_star's target size through pf_novel_view_dev), `config4_chain` (the full 5+top
+      stitch chain at 9000x4000, pixflow_search_20, host images -> host composite through pf_stitch_step),
+      `roofline.latency_bound` (dependency-chain bound of the exact sweeps) and `cpu_baseline` (1 and 2 threads).
+  --gpus N>1: BASELINE.json configs[4] -- N independent 9000x4000 pairs, one per GPU (seeds 1234..), weak scaling;
+      the blended strips are gathered to rank 0 over RCCL, overlapped with the next pair.
+      (--cols/--rows override the workload in either mode.)
+
+One process per GPU (torch.distributed / RCCL for the barrier, the max-over-ranks time and the final gather);
+prints ONE JSON line on rank 0.
 """
 import argparse
 import importlib.util
 import json
 import os
+import statistics
 import sys
 import threading
 import time
@@ -30,26 +39,57 @@ def _load(name):
 
 
 def cpu_baseline(L, R, blend, max_pct):
-    """The oracle (a port: the reference's CPU/ cannot be compiled here) on the GPU box's host cores, on the
-    SAME pair: both flow directions on 2 threads (the only result-preserving parallelism the algorithm has,
-    OpticalFlow.cpp:130-139) + the blend."""
+    """The oracle (a port: the reference's CPU/ cannot be compiled here) on the GPU box's host cores, on the SAME pair.
+    (i) 1 thread: both directions one after the other (the reference has no threading of its own);
+    (ii) 2 threads: one per flow direction, the only result-preserving parallelism the algorithm has
+    (OpticalFlow.cpp:130-139).  Both legs run at the same time on three host threads (the box has hundreds)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
     orc.build()
     res = [None, None]
+    t_one = [0.0]
+    t_two = [0.0, 0.0]
 
-    def run(d):
-        res[d] = orc.flow_one_dir(L, R, max_pct, d)
+    def serial():
+        t0 = time.perf_counter()
+        for d in (0, 1):
+            res[d] = orc.flow_one_dir(L, R, max_pct, d)
+        t_one[0] = time.perf_counter() - t0
 
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=run, args=(d,)) for d in (0, 1)]
+    def single(d):
+        t0 = time.perf_counter()
+        orc.flow_one_dir(L, R, max_pct, d)
+        t_two[d] = time.perf_counter() - t0
+
+    th = [threading.Thread(target=serial)] + [threading.Thread(target=single, args=(d,)) for d in (0, 1)]
     for t in th:
         t.start()
     for t in th:
         t.join()
+    t0 = time.perf_counter()
     out = orc.combine_novel_views(L, R, res[0], res[1], blend)
-    dt = time.perf_counter() - t0
-    return dt, res[0], res[1], out
+    t_blend = time.perf_counter() - t0
+    return t_one[0] + t_blend, max(t_two) + t_blend, res[0], res[1], out
+
+
+def measure_t_step(pf, ctx, np):
+    """Step time of ONE lone band of the sweep kernel (8 rows x 4096 columns, dense random data): the machine's floor for
+    this instruction sequence, with no band-to-band skew.  HIP events around the kernel (the 'sweep' family)."""
+    rng = np.random.default_rng(5)
+    h, w = 8, 4096
+    g0 = rng.standard_normal((h, w, 2)).astype(np.float32) * 0.05
+    g1 = rng.standard_normal((h, w, 2)).astype(np.float32) * 0.05
+    bl = rng.standard_normal((h, w, 2)).astype(np.float32)
+    fl = rng.standard_normal((h, w, 2)).astype(np.float32)
+    a = np.ones((h, w), np.float32)
+    ctx.stage_sweep(g0, g1, bl, a, a, fl, True)          # warm-up (allocations)
+    ctx.profile_reset(); ctx.profile_enable(1)
+    for _ in range(3):
+        ctx.stage_sweep(g0, g1, bl, a, a, fl, True)
+    ctx.profile_enable(0)
+    ms, n = ctx.profile()["sweep"]
+    ctx.profile_reset()
+    return 1000.0 * ms / n / (w + h - 1)
 
 
 def main():
@@ -57,10 +97,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cols", type=int, default=2000)
-    ap.add_argument("--rows", type=int, default=4000)
+    ap.add_argument("--cols", type=int, default=0, help="default: 2000 at --gpus 1 (configs[1]), 9000 at --gpus N>1 (configs[4])")
+    ap.add_argument("--rows", type=int, default=0, help="default: 4000")
     ap.add_argument("--alg", default="pixflow_low")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the 9000x4000 pair / config-4 chain / lone-band step-time legs")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--concurrent", type=int, default=1, help="independent pairs in flight per GPU (one context + host thread each); 1 = the BASELINE config")
     args = ap.parse_args()
@@ -83,9 +124,10 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     pf = _load("pyabi"); synth = _load("synth"); shard = _load("shard")
-    cols, rows = args.cols, args.rows
+    cols = args.cols or (2000 if world == 1 else 9000)
+    rows = args.rows or 4000
     max_pct = pf.max_percentage_by_name(args.alg)
-    ctx = pf.Context(local_rank)
+    ctx = pf.Context(local_rank, cols, rows)            # pre-sized: the first step pays no allocation
 
     # one independent synthetic pair per rank (seed 1234 + rank), generated straight into HBM
     L, R, blend, _ = synth.make_pair(cols, rows, 1234 + rank, dev)
@@ -100,7 +142,7 @@ def main():
     extra = []
     for j in range(1, max(1, args.concurrent)):
         Lj, Rj, bj, _ = synth.make_pair(cols, rows, 1234 + rank + 1000 * j, dev)
-        extra.append((pf.Context(local_rank), Lj, Rj, bj, torch.empty_like(out), torch.empty_like(f0), torch.empty_like(f1)))
+        extra.append((pf.Context(local_rank, cols, rows), Lj, Rj, bj, torch.empty_like(out), torch.empty_like(f0), torch.empty_like(f1)))
     torch.cuda.synchronize()
 
     def one(cx, Lx, Rx, bx, ox, fx0, fx1):
@@ -109,9 +151,11 @@ def main():
     # the only exchange of the path: final gather of the blended strips to rank 0 over RCCL/xGMI.  It overlaps the next
     # pair's compute (two result buffers, one gather in flight); the fence waits for the last one.
     og = shard.OverlappedGather(out, world, rank) if (world > 1 or force_dist) else None
+    step_ms = []
 
     def step():
         # flows + blended strip end up resident in HBM; the call is synchronous on return
+        t_s = time.perf_counter()
         ths = [threading.Thread(target=one, args=e) for e in extra]
         for t in ths:
             t.start()
@@ -121,6 +165,7 @@ def main():
             t.join()
         if og:
             og.submit()
+        step_ms.append(1000 * (time.perf_counter() - t_s))
 
     def fence():
         if og:
@@ -133,6 +178,7 @@ def main():
     ctx.profile_reset()
     ctx.profile_enable(0 if args.no_profile else 2)   # timed region: HIP events around the dominant kernel (the sweeps) only
     fence()
+    del step_ms[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -140,22 +186,29 @@ def main():
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
     dt = shard.max_over_ranks(dt, dev)
+    med_ms = statistics.median(step_ms)
+    swept = ctx.last_swept_steps()
 
     prof = ctx.profile()
     # per-family breakdown from ONE extra, untimed step with every family instrumented
     ctx.profile_reset(); ctx.profile_enable(1); step(); ctx.profile_enable(0)
     prof_all = ctx.profile()
+    ctx.profile_reset()
     if rank == 0:
         mpix = cols * rows / 1e6
-        value = world * max(1, args.concurrent) * mpix * args.steps / dt
+        npairs = world * max(1, args.concurrent)
+        value = npairs * mpix * args.steps / dt
         P, nlev, sweep_steps = pf.level_pixels(cols, rows)
         b_alg = pf.algorithmic_bytes(cols, rows)
+        which = "BASELINE configs[1]" if (world == 1 and (cols, rows) == (2000, 4000)) else ("BASELINE configs[4] (one 9000x4000 pair per GPU)" if (cols, rows) == (9000, 4000) else "custom size")
         res = {
             "metric": "Mpix/s bidirectional optical flow (overlap strip) at 1/2/4/8 GPU", "value": round(value, 3), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%dx%d overlap strip, %s, flow L->R + R->L + novel-view blend, %d pair(s) in flight per GPU" % (cols, rows, args.alg, max(1, args.concurrent)),
-                       "levels": nlev, "level_pixels": P, "sweep_steps_per_direction": sweep_steps, "final_gather": "rccl, overlapped with the next pair" if world > 1 else "none"},
+            "config": {"workload": "%s: %dx%d overlap pair per GPU, %s, flow L->R + R->L + novel-view blend, %d pair(s) in flight per GPU" % (which, cols, rows, args.alg, max(1, args.concurrent)),
+                       "levels": nlev, "level_pixels": P, "sweep_steps_per_direction": sweep_steps, "swept_steps_per_direction_in_gated_window": swept,
+                       "final_gather": "rccl, overlapped with the next pair" if world > 1 else "none"},
+            "ms_per_step_median": round(med_ms, 3), "value_at_median": round(npairs * mpix / (med_ms * 1e-3), 3),
         }
         # roofline of the dominant kernel (the exact wavefront sweep): algorithmic bytes per launch =
         # 48 B per level-pixel (alpha/grad0 16 + blurred 8 + flow r/w 16 + grad1 gather 8)
@@ -164,34 +217,85 @@ def main():
         # figure comes from the committed rocprofv3 --pmc pass of this same command (profiles/, see its note); it only
         # applies to the default workload.
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_bench.json")
-        if (cols, rows, args.alg) == (2000, 4000, "pixflow_low") and os.path.exists(pmc_path):
-            try:
-                pl = json.load(open(pmc_path))["sweep_per_launch"]
-                traffic = round(0.5 * (pl["traffic_bytes_lo"] + pl["traffic_bytes_hi"]))
-                traffic_src = "profiles/r01_pmc_bench.json (FETCH_SIZE+WRITE_SIZE per sweep launch; read side bracketed [raw,2x raw], midpoint reported)"
-            except Exception:
-                pass
+        for name in ("r02_pmc_bench.json", "r01_pmc_bench.json"):
+            pmc_path = os.path.join(ROOT, "profiles", name)
+            if (cols, rows, args.alg) == (2000, 4000, "pixflow_low") and os.path.exists(pmc_path):
+                try:
+                    pl = json.load(open(pmc_path))["sweep_per_launch"]
+                    traffic = round(0.5 * (pl["traffic_bytes_lo"] + pl["traffic_bytes_hi"]))
+                    traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per sweep launch; read side bracketed [raw,2x raw], midpoint reported; not re-measured in this run)" % name
+                    break
+                except Exception:
+                    pass
         if "sweep" in prof and prof["sweep"][1] > 0:
             ms, n = prof["sweep"]
             bytes_total = 48.0 * P * 4 * args.steps
             ach = bytes_total / (ms * 1e-3) / 1e9
             res["roofline"] = {"bound": "hbm", "kernel": "k_sweep_prep+k_sweep2", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6),
                                "traffic": traffic, "traffic_source": traffic_src, "launches": n, "avg_launch_us": round(1000 * ms / n, 2),
-                               "note": "exact Gauss-Seidel sweep is dependency-latency bound (critical path %d wavefront steps/direction), not HBM bound" % sweep_steps}
+                               "note": "exact Gauss-Seidel sweep is dependency-latency bound (see latency_bound), not HBM bound"}
+            sweep_ms_per_dir = ms / args.steps / 2.0          # the two directions run concurrently on two streams
         else:
             res["roofline"] = {"bound": "hbm", "kernel": "k_sweep", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None}
+            sweep_ms_per_dir = None
         ach_path = b_alg * args.steps / dt / 1e9
         res["roofline_path"] = {"bound": "hbm", "achieved": round(ach_path, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach_path / 8000.0, 6),
                                 "algorithmic_bytes_per_pair": b_alg}
         res["kernels_ms_per_step"] = {k: round(v[0], 3) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}
+
+        if world == 1 and not args.no_extras and args.concurrent <= 1:
+            # ---- the honest bound of the sweeps: a dependency chain of `swept` steps per direction x the time of one step
+            # of a lone band (measured live) ----
+            t_step = measure_t_step(pf, ctx, np)
+            if sweep_ms_per_dir:
+                bound_ms = swept * t_step * 1e-3
+                res["roofline"]["latency_bound"] = {"swept_steps": swept, "t_step_us": round(t_step, 4), "bound_ms": round(bound_ms, 3),
+                                                    "measured_sweep_ms_per_direction": round(sweep_ms_per_dir, 3), "frac_of_bound": round(bound_ms / sweep_ms_per_dir, 4),
+                                                    "note": "bound = swept_steps x t_step of ONE lone band (8 rows x 4096, HIP events); the two directions run concurrently"}
+            # ---- north_star's target size: one 9000x4000 pair through the same entry point ----
+            del extra[:]
+            cc, cr = 9000, 4000
+            cx = pf.Context(local_rank, cc, cr)
+            Lc, Rc, bc, _ = synth.make_pair(cc, cr, 1234, dev)
+            oc = torch.empty((cr, cc, 4), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            ts = []
+            for i in range(4):
+                t1 = time.perf_counter()
+                cx.novel_view_dev(Lc.data_ptr(), Rc.data_ptr(), cc, cr, max_pct, bc.data_ptr(), oc.data_ptr())
+                ts.append(time.perf_counter() - t1)
+            tm = statistics.median(ts[1:])
+            res["canvas_pair_9000x4000"] = {"value": round(cc * cr / 1e6 / tm, 3), "unit": "Mpix/s", "ms_per_pair": round(1000 * tm, 3), "alg": args.alg,
+                                            "swept_steps_per_direction": cx.last_swept_steps(), "steps": 3, "warmup": 1,
+                                            "roofline_path_frac": round(pf.algorithmic_bytes(cc, cr) / tm / 8e12, 6)}
+            del Lc, Rc, bc, oc
+            # ---- BASELINE configs[3]: the full 5+top chain, 9000x4000, pixflow_search_20, host images -> host composite ----
+            top, imgs = synth.make_stitch_set(cc, cr, 1234, 5, dev)
+            top = top.cpu().numpy(); imgs = [im.cpu().numpy() for im in imgs]
+            torch.cuda.empty_cache()
+
+            def chain():
+                t1 = time.perf_counter()
+                for i, im in enumerate(imgs):
+                    last = i == len(imgs) - 1
+                    o = cx.stitch_step(im, top if i == 0 else None, 20, want_out=last)
+                return time.perf_counter() - t1, o
+
+            chain()
+            tc = sorted(chain()[0] for _ in range(3))[1]
+            res["config4_chain"] = {"seconds": round(tc, 4), "unit": "s", "workload": "5+top stitch chain, 9000x4000, pixflow_search_20, pf_stitch_step x5 (host images in, host composite out)",
+                                    "Mpix/s_canvas": round(5 * cc * cr / 1e6 / tc, 2), "runs": 3, "warmup": 1}
+            cx.close()
         if world == 1 and not args.no_cpu_baseline:
             Lh, Rh, bh = L.cpu().numpy(), R.cpu().numpy(), blend.cpu().numpy()
-            tcpu, r0, r1, rout = cpu_baseline(Lh, Rh, bh, max_pct)
+            t1, t2, r0, r1, rout = cpu_baseline(Lh, Rh, bh, max_pct)
             g0, g1, gout = f0.cpu().numpy(), f1.cpu().numpy(), (og.bufs[(og.k - 1) % 2] if og else out).cpu().numpy()
             off = np.abs(gout.astype(np.int32) - rout.astype(np.int32))
-            res["cpu_baseline"] = {"value": round(mpix / tcpu, 4), "unit": "Mpix/s", "cores": 2, "kind": "port",
-                                   "sample": "the same %dx%d pair, whole path once: 2 flow directions on 2 threads + blend (%.1f s)" % (cols, rows, tcpu)}
+            res["cpu_baseline"] = {"value": round(mpix / t2, 4), "unit": "Mpix/s", "cores": 2, "kind": "port",
+                                   "sample": "the same %dx%d pair, whole path once: 2 flow directions on 2 threads + blend (%.1f s)" % (cols, rows, t2),
+                                   "one_thread": {"value": round(mpix / t1, 4), "unit": "Mpix/s", "cores": 1, "seconds": round(t1, 2)},
+                                   "host_threads_available": os.cpu_count(),
+                                   "note": "leg (iii) of SURVEY 8(d) (one pair per core) only applies to config 5 and is not run"}
             res["parity_vs_cpu"] = {"max_abs_dflow_px": float(max(np.abs(g0 - r0).max(), np.abs(g1 - r1).max())),
                                     "blend_pixels_off": int((off > 0).sum()), "blend_max_lsb": int(off.max())}
         line = json.dumps(res)

@@ -140,6 +140,9 @@ int pf_profile_get(pf_ctx* ctx, int idx, char* name, int name_cap, double* total
 /* algorithmic HBM bytes of one pf_novel_view on cols x rows (SURVEY.md section 8(d) model) */
 double pf_algorithmic_bytes(int cols, int rows);
 long long pf_level_pixels(int cols, int rows, int* n_levels, long long* sweep_steps);
+/* dependent wavefront steps of ONE direction of the last solve: sum over levels and both sweeps of (w + h - 1) of the
+ * window of gated pixels -- the length of the exact Gauss-Seidel dependency chain (SURVEY.md 8(d) "honest bound") */
+long long pf_last_swept_steps(pf_ctx* ctx);
 
 #ifdef __cplusplus
 }

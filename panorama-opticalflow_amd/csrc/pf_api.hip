@@ -41,6 +41,7 @@ struct pf_ctx {
   int prof = 0;   // 0 off, 1 every kernel family, 2 only the dominant family (the sweeps): fewer events in a timed region
   int sweep_version = 2;
   int chain_cols = 0, chain_rows = 0;   // size of the stitch-chain result resident in "ch_final"
+  long long last_swept_steps = 0;       // wavefront steps of one direction of the last solve (both sweeps, all levels, gated windows)
   int* h_status = nullptr;              // mapped pinned host word: bit d set = a sweep band of direction d timed out
   int* d_status = nullptr;              // the same word as the device sees it
   std::vector<std::string> prof_names;
@@ -292,6 +293,13 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   int sparse = (double)h_cnt < 0.5 * area0 ? 1 : 0;
   if (const char* e = getenv("PANOFLOW_SPARSE")) sparse = atoi(e) ? 1 : 0;   // experiment switch: results are identical either way
   HIPCHK(c, hipEventRecord(c->ev_pre, sm));
+  // critical path of the exact sweeps given the windows: (w + h - 1) anti-diagonals per sweep, two sweeps per level
+  c->last_swept_steps = 0;
+  for (int l = 0; l < g.n; ++l) {
+    int bw = g.ws[l], bh = g.hs[l];
+    if (!boxes.empty()) { bw = boxes[4 * l + 2] - boxes[4 * l] + 1; bh = boxes[4 * l + 3] - boxes[4 * l + 1] + 1; }
+    if (bw > 0 && bh > 0) c->last_swept_steps += 2 * (long long)(bw + bh - 1);
+  }
 
   // --- the two directions are independent (OpticalFlow.cpp:130-139): one stream each.  The host enqueues them level by
   // level in turn (a direction's ~430 launches take the host >1 ms: enqueued one after the other, the second
@@ -879,6 +887,8 @@ int pf_profile_get(pf_ctx* c, int idx, char* name, int cap, double* ms, int* lau
   if (launches) *launches = c->prof_tot[idx].n;
   return 0;
 }
+
+long long pf_last_swept_steps(pf_ctx* c) { return c ? c->last_swept_steps : 0; }
 
 long long pf_level_pixels(int cols, int rows, int* n_levels, long long* sweep_steps) {
   const Geometry g = make_geometry(cols, rows, cols / 20);

@@ -46,6 +46,8 @@ def lib():
         _lib.pf_dev_free.argtypes = [C.c_void_p, C.c_void_p]
         _lib.pf_algorithmic_bytes.restype = C.c_double
         _lib.pf_level_pixels.restype = C.c_longlong
+        _lib.pf_last_swept_steps.restype = C.c_longlong
+        _lib.pf_last_swept_steps.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -57,7 +59,7 @@ EXPORTS = [
     "pf_stage_preprocess", "pf_stage_pyr_down", "pf_stage_gradients", "pf_stage_gauss", "pf_stage_median5", "pf_stage_sweep",
     "pf_stage_diffusion", "pf_stage_upsample_cubic", "pf_stage_final", "pf_stage_adjust_initial_flow", "pf_stage_level",
     "pf_stage_blend_smooth",
-    "pf_profile_enable", "pf_profile_reset", "pf_profile_count", "pf_profile_get", "pf_algorithmic_bytes", "pf_level_pixels",
+    "pf_profile_enable", "pf_profile_reset", "pf_profile_count", "pf_profile_get", "pf_algorithmic_bytes", "pf_level_pixels", "pf_last_swept_steps",
 ]
 
 
@@ -269,6 +271,10 @@ class Context:
         b = _f32(blend).copy(); rows, cols = b.shape
         self._chk(self.l.pf_stage_blend_smooth(self.h, _p(b), _p(_f32(md)), cols, rows))
         return b
+
+    def last_swept_steps(self):
+        """dependent wavefront steps of one direction of the last solve (windows of gated pixels)"""
+        return int(self.l.pf_last_swept_steps(self.h))
 
     # ---- profiling ----
     def profile_enable(self, on=True):

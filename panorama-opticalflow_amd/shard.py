@@ -63,8 +63,13 @@ class OverlappedGather:
         self.k += 1
 
     def wait(self):
+        """Host-blocking: on return the previous gather has finished READING its buffer.  For the NCCL/RCCL backend
+        Work.wait() only orders torch's current stream, and libpanoflow writes the buffers from its own HIP streams,
+        so the host additionally waits for that stream before the buffer may be overwritten."""
         if self.pending is not None:
             self.pending.wait()
+            if self.bufs[0].is_cuda:
+                torch.cuda.current_stream(self.bufs[0].device).synchronize()
             self.pending = None
 
     def last(self):

@@ -2,7 +2,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmcb_$c
-  timeout 150 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcb_$c -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > gpurun_out/pmcb_$c.log 2>&1
+  timeout 150 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcb_$c -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-profile > gpurun_out/pmcb_$c.log 2>&1
   echo "$c rc=$?"; tail -2 gpurun_out/pmcb_$c.log | cut -c1-300
 done
 python - <<PY
