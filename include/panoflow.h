@@ -83,6 +83,12 @@ int pf_stitch_prepare(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra,
                       uint8_t* map_out, size_t map_step_bytes, uint8_t* overlapped_l, uint8_t* overlapped_r,
                       float* blend_out, size_t blend_step_bytes, float* merged_dis /* packed, nullable */);
 
+/* GenerateBlend's per-pixel loop alone, CPU/StitchTool.cpp:113-125: 0 / 1 / 0.5 by map code and, in the overlap,
+ * Stitchtools::countblend(x, y) (:148-191) = minLdis / (minRdis + minLdis) -- the ramp BEFORE the smoothing of
+ * :130-143 -- plus MergedDis (:185-188, nullable, packed). */
+int pf_stitch_raw_blend(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, int cols, int rows, size_t step_bytes,
+                        float* raw_blend_out, size_t blend_step_bytes, float* merged_dis);
+
 /* Stitchtools::Gather, CPU/StitchTool.cpp:52-96. */
 int pf_stitch_gather(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, const uint8_t* merged_bgra, size_t step_bytes,
                      const uint8_t* map, size_t map_step_bytes, int cols, int rows, uint8_t* out_bgra, size_t out_step_bytes);

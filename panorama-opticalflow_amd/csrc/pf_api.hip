@@ -650,6 +650,30 @@ int pf_stitch_prepare(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, i
   return finish(c);
 }
 
+// GenerateBlend's per-pixel part alone (StitchTool.cpp:113-125 with countblend :148-191): the ramp BEFORE the tile / global
+// box smoothing, i.e. what Stitchtools::countblend(x, y) returns for overlap pixels, and MergedDis.
+int pf_stitch_raw_blend(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int rows, size_t step, float* raw_blend, size_t bstep, float* merged_dis) {
+  if (int e = use(c)) return e;
+  CallGuard guard_(c);
+  if (!l || !r || !raw_blend) return fail(c, PF_ERR_ARG, "null pointer");
+  if (int e = check_image(c, cols, rows)) return e;
+  if (step < size_t(cols) * 4 || bstep < size_t(cols) * 4) return fail(c, PF_ERR_ARG, "row step too small");
+  const size_t n = size_t(cols) * rows;
+  uint8_t* dl = (uint8_t*)ensure(c, "h_img0", n * 4); uint8_t* dr = (uint8_t*)ensure(c, "h_img1", n * 4);
+  uint8_t* dm = (uint8_t*)ensure(c, "st_map", n); uint8_t* dol = (uint8_t*)ensure(c, "st_ovl", n * 4); uint8_t* dor = (uint8_t*)ensure(c, "st_ovr", n * 4);
+  float* db = (float*)ensure(c, "st_blend", n * 4); float* dmd = (float*)ensure(c, "st_md", n * 4);
+  if (!dl || !dr || !dm || !dol || !dor || !db || !dmd) return PF_ERR_NOMEM;
+  hipStream_t sm = c->s_main;
+  if (int e = up2d(c, dl, size_t(cols) * 4, l, step, size_t(cols) * 4, rows)) return e;
+  if (int e = up2d(c, dr, size_t(cols) * 4, r, step, size_t(cols) * 4, rows)) return e;
+  { PROF(c, sm, "match_images"); launch_match_images(sm, dl, dr, cols, rows, dm, dol, dor); }
+  { PROF(c, sm, "countblend"); launch_countblend(sm, dm, cols, rows, db, dmd); }
+  if (int e = down2d(c, raw_blend, bstep, db, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
+  if (merged_dis) if (int e = down2d(c, merged_dis, size_t(cols) * 4, dmd, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
+  HIPCHK(c, hipGetLastError());
+  return finish(c);
+}
+
 int pf_stitch_gather(pf_ctx* c, const uint8_t* l, const uint8_t* r, const uint8_t* merged, size_t step, const uint8_t* map, size_t mstep, int cols,
                      int rows, uint8_t* out, size_t ostep) {
   if (int e = use(c)) return e;

@@ -29,6 +29,7 @@ class Stitchtools {
       throw util::VrCamException("Stitchtools::prepare: inputs must be two CV_8UC4 images of equal size");
     ImageL = colorImageL.clone();
     ImageR = colorImageR.clone();
+    raw_ = Mat(); rawDis_ = Mat();
     MatchImages();
     GenerateBlend();
   }
@@ -46,13 +47,22 @@ class Stitchtools {
     if (ramp_.empty()) MatchImages();
     Blend = ramp_.clone();
   }
-  // CPU/StitchTool.cpp:148-191.  x is in wrap-extended map coordinates (cols/5 columns were prepended);
-  // returns the smoothed ramp value the device computed for that pixel.
+  // CPU/StitchTool.cpp:148-191.  x is in wrap-extended map coordinates (cols/5 columns were prepended, :102-111).
+  // Like the reference it returns the RAW ratio minLdis / (minRdis + minLdis) of that pixel -- not the smoothed ramp --
+  // and writes min(minLdis, minRdis) into MergedDis (:185-188).  The device evaluates the 8-direction search for the
+  // whole image in one pass (pf_stitch_raw_blend); the result is cached until the next prepare().
   float countblend(const int x, const int y) {
-    if (ramp_.empty()) MatchImages();
+    if (ImageL.empty()) throw util::VrCamException("Stitchtools::countblend: prepare first");
+    if (raw_.empty()) {
+      raw_ = Mat(ImageL.rows, ImageL.cols, CV_32FC1); rawDis_ = Mat(ImageL.rows, ImageL.cols, CV_32FC1);
+      pano::check(pf_stitch_raw_blend(pano::context(), ImageL.data, ImageR.data, ImageL.cols, ImageL.rows, ImageL.step, raw_.ptr<float>(), raw_.step,
+                                      rawDis_.ptr<float>()));
+    }
     int sx = x - ImageL.cols / 5;
     if (sx < 0) sx += ImageL.cols; else if (sx >= ImageL.cols) sx -= ImageL.cols;
-    return ramp_.at<float>(y, sx);
+    if (MergedDis.empty()) MergedDis = Mat(ImageL.rows, ImageL.cols, CV_32FC1);
+    MergedDis.at<float>(y, sx) = rawDis_.at<float>(y, sx);
+    return raw_.at<float>(y, sx);
   }
   // CPU/StitchTool.cpp:52-96
   void Gather() {
@@ -72,7 +82,8 @@ class Stitchtools {
   void setMergedmiddle(const Mat& image) { Mergedmiddle = image.clone(); }
 
  private:
-  Mat ramp_;
+  Mat ramp_;            // smoothed ramp of the last MatchImages() pass
+  Mat raw_, rawDis_;    // unsmoothed ramp / MergedDis for countblend(), computed on first use
 };
 
 // One whole iteration of the stitch loop (CPU/main.cpp:70-95) without leaving the device (pf_stitch_step).

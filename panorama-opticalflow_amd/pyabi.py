@@ -53,7 +53,7 @@ def lib():
 
 EXPORTS = [
     "pf_device_count", "pf_create", "pf_destroy", "pf_last_error", "pf_version", "pf_max_percentage_by_name",
-    "pf_flow", "pf_flow_bidir", "pf_blend", "pf_novel_view", "pf_stitch_prepare", "pf_stitch_gather", "pf_stitch_step",
+    "pf_flow", "pf_flow_bidir", "pf_blend", "pf_novel_view", "pf_stitch_prepare", "pf_stitch_raw_blend", "pf_stitch_gather", "pf_stitch_step",
     "pf_dev_alloc", "pf_dev_free", "pf_upload", "pf_download", "pf_sync",
     "pf_flow_bidir_dev", "pf_blend_dev", "pf_novel_view_dev",
     "pf_stage_preprocess", "pf_stage_pyr_down", "pf_stage_gradients", "pf_stage_gauss", "pf_stage_median5", "pf_stage_sweep",
@@ -154,6 +154,13 @@ class Context:
         self._chk(self.l.pf_stitch_prepare(self.h, _p(a), _p(b), cols, rows, C.c_size_t(cols * 4), _p(mp), C.c_size_t(cols), _p(ovl), _p(ovr), _p(bl),
                                            C.c_size_t(cols * 4), _p(md)))
         return mp, ovl, ovr, bl, md
+
+    def stitch_raw_blend(self, L, R):
+        """GenerateBlend before its smoothing (what countblend returns in the overlap) + MergedDis."""
+        a = _u8(L); b = _u8(R); rows, cols, _ = a.shape
+        bl = np.empty((rows, cols), np.float32); md = np.empty((rows, cols), np.float32)
+        self._chk(self.l.pf_stitch_raw_blend(self.h, _p(a), _p(b), cols, rows, C.c_size_t(cols * 4), _p(bl), C.c_size_t(cols * 4), _p(md)))
+        return bl, md
 
     def stitch_gather(self, L, R, merged, mp):
         a = _u8(L); rows, cols, _ = a.shape

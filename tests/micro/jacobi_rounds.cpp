@@ -18,7 +18,7 @@ using namespace orc;
 struct Stat { int level, w, h, fwd, rounds; long long evals, gated; int maxdepth; };
 static std::vector<Stat> g_stats;
 #include <map>
-static std::map<int, double> g_model; static double g_fast = 180, g_slow = 920, g_hand = 600;
+static std::map<int, double> g_model; static double g_fast = 180, g_slow = 920, g_hand = 600; static int g_rows = 8;
 
 static inline bool same(float a, float b) { uint32_t x, y; memcpy(&x, &a, 4); memcpy(&y, &b, 4); return x == y; }
 
@@ -70,7 +70,7 @@ static void jacobi(const LevelCtx& L, const ImgF& alpha0, const ImgF& alpha1, co
       if (!same(ox, cur.at(y, x, 0)) || !same(oy, cur.at(y, x, 1))) { nchanged[i] = 1; ++nch; nxt.at(y, x, 0) = ox; nxt.at(y, x, 1) = oy; }
     }
     cur.d.swap(nxt.d); changed.swap(nchanged);
-    for (int K : {2, 4, 8, 16, 32}) if (rounds == K) {
+    for (int K : {2, 4, 8, 16, 32, 64}) if (rounds == K) {
       // pixel "slow" in a verifying wavefront after K rounds: its predecessors' final values differ from the ones its last evaluation used,
       // i.e. a predecessor still changes after round K-1  <=>  predecessor's value after round K-1 (= cur before... see below) != final.
       // Here: cur = out^K.  A pixel evaluated with out^{K-1} neighbours is right iff those equal the final values; approximate with out^K (one round later => slightly optimistic).
@@ -79,32 +79,32 @@ static void jacobi(const LevelCtx& L, const ImgF& alpha0, const ImgF& alpha1, co
       for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) { const size_t i = size_t(y) * W + x; if (!same(cur.d[2 * i], expect.d[2 * i]) || !same(cur.d[2 * i + 1], expect.d[2 * i + 1])) { bad[i] = 1; ++wrong; } }
       // bands of 8 across the shorter side; step = anti-diagonal inside the band; pixel needs the slow path if a predecessor is bad
       const bool tr = W < H; const int LB = tr ? W : H, LS = tr ? H : W;
-      const int nb = (LB + 7) / 8, ns = LS + 7;
+      const int nb = (LB + g_rows - 1) / g_rows, ns = LS + g_rows - 1;
       // pipeline model of the band wavefront: band b step s may start when its own step s-1 and band b-1's step s+7 (+ hand-off) are done
       const double cFast = g_fast, cSlow = g_slow, cHand = g_hand;
       std::vector<double> Tprev(ns + 8, 0.0), Tcur(ns + 8, 0.0);
       double tEnd = 0;
-      for (int b = 0; b < nb; ++b) { const int b0 = b * 8; double t = 0;
+      for (int b = 0; b < nb; ++b) { const int b0 = b * g_rows; double t = 0;
         for (int s = 0; s < ns; ++s) {
         bool any = false, has = false;
-        for (int r = 0; r < 8 && b0 + r < LB; ++r) { const int u = s - r; if (u < 0 || u >= LS) continue; has = true;
+        for (int r = 0; r < g_rows && b0 + r < LB; ++r) { const int u = s - r; if (u < 0 || u >= LS) continue; has = true;
           int x = tr ? b0 + r : u, y = tr ? u : b0 + r; if (!forward) { x = W - 1 - x; y = H - 1 - y; }
           if (!gate[size_t(y) * W + x]) continue;
           const int ax = x + sx, by = y + sy;
           if ((ax >= 0 && ax < W && bad[size_t(y) * W + ax]) || (by >= 0 && by < H && bad[size_t(by) * W + x])) any = true; }
         if (has) { ++cells; slow += any; }
-        double start = t; if (b > 0) { const double dep = Tprev[std::min(s + 7, ns - 1)] + cHand; if (dep > start) start = dep; }
+        double start = t; if (b > 0) { const double dep = Tprev[std::min(s + g_rows - 1, ns - 1)] + cHand; if (dep > start) start = dep; }
         t = start + (any ? cSlow : cFast); Tcur[s] = t; }
         Tprev.swap(Tcur); tEnd = t; }
-      g_model[K] += tEnd; if (K == 2) g_model[0] += double(ns + 8.6 * (nb - 1)) * cSlow;
+      g_model[K] += tEnd; if (K == 2) g_model[0] += double(ns + (g_rows + 0.6) * (nb - 1)) * cSlow;
       fprintf(stderr, "   level %d %s K=%d: %.3f%% pixels not final, %.2f%% of band-steps slow\n", level, forward ? "fwd" : "bwd", K, 100.0 * wrong / (double)(gated ? gated : 1), 100.0 * slow / (double)cells);
     }
     if (rounds <= 12 || rounds % 50 == 0) fprintf(stderr, "   level %d %s round %d: %lld changed\n", level, forward ? "fwd" : "bwd", rounds, nch);
     if (nch == 0) break;
     if (rounds > W + H) { fprintf(stderr, "did not converge?!\n"); break; }
   }
-  { const bool tr = W < H; const int LB = tr ? W : H, LS = tr ? H : W; const int nb = (LB + 7) / 8, ns = LS + 7;
-    for (int K : {2, 4, 8, 16, 32}) if (rounds < K) g_model[K] += ns * g_fast + (nb - 1) * (8 * g_fast + g_hand); }   // converged before K rounds: every step fast
+  { const bool tr = W < H; const int LB = tr ? W : H, LS = tr ? H : W; const int nb = (LB + g_rows - 1) / g_rows, ns = LS + g_rows - 1;
+    for (int K : {2, 4, 8, 16, 32, 64}) if (rounds < K) g_model[K] += ns * g_fast + (nb - 1) * (g_rows * g_fast + g_hand); }   // converged before K rounds: every step fast
   bool ok = true;
   for (size_t i = 0; i < cur.d.size(); ++i) if (!same(cur.d[i], expect.d[i])) { ok = false; break; }
   if (!ok) fprintf(stderr, "MISMATCH vs sequential sweep at level %d\n", level);
@@ -115,6 +115,7 @@ int main(int argc, char** argv) {
   if (argc < 5) { fprintf(stderr, "usage: %s a.raw b.raw cols rows [maxPct]\n", argv[0]); return 2; }
   const int cols = atoi(argv[3]), rows = atoi(argv[4]); const int maxPct = argc > 5 ? atoi(argv[5]) : 0;
   if (argc > 6) g_fast = atof(argv[6]);
+  if (argc > 7) g_rows = atoi(argv[7]);
   ImgU8 a(cols, rows, 4), b(cols, rows, 4);
   FILE* f = fopen(argv[1], "rb"); if (!f || fread(a.d.data(), 1, a.d.size(), f) != a.d.size()) return 3; fclose(f);
   f = fopen(argv[2], "rb"); if (!f || fread(b.d.data(), 1, b.d.size(), f) != b.d.size()) return 3; fclose(f);

@@ -83,7 +83,7 @@ def test_canvas_stitch_step_window_and_sparse_switches(pf, synth):
 # BASELINE configs 2 and 3 at their real size, directly against the oracle (the GPU box's host finishes one
 # 2000x4000 direction in ~13-25 s; the four oracle solves run on four host threads).
 # ---------------------------------------------------------------------------------------------------------------
-def test_strip_pixflow_low_and_search_20_vs_oracle(pf, orc, strip):
+def test_strip_pixflow_low_and_search_20_vs_oracle(pf, orc, synth, strip):
     import threading
     L, R, blend = strip
     ref = {}
@@ -91,10 +91,20 @@ def test_strip_pixflow_low_and_search_20_vs_oracle(pf, orc, strip):
     def run(pct, d):
         ref[(pct, d)] = orc.flow_one_dir(L, R, pct, d)
 
+    # On the BASELINE pair the displacement (<= 6 px) is 0.1 px at the coarsest level, so the wide search confirms flow 0
+    # and configs 2 and 3 give the same field (both sides agree on that).  A second pair with 24x the displacement
+    # (1.8 px at the coarsest level) makes the search path change the result; it is held to the oracle as well.
+    Lw, Rw, _ = synth.make_pair_np(2000, 4000, 4321, disp_scale=24.0)
+
+    def run_wide(pct, d):
+        ref[("wide", pct, d)] = orc.flow_one_dir(Lw, Rw, pct, d)
+
     th = [threading.Thread(target=run, args=(pct, d)) for pct in (0, 20) for d in (0, 1)]
+    th += [threading.Thread(target=run_wide, args=(pct, d)) for pct in (0, 20) for d in (0, 1)]
     [t.start() for t in th]
     c = pf.Context(0)
     got = {pct: c.novel_view(L, R, pct, blend) for pct in (0, 20)}
+    gotw = {pct: c.flow_bidir(Lw, Rw, pct) for pct in (0, 20)}
     c.close()
     [t.join() for t in th]
     for pct in (0, 20):
@@ -106,8 +116,11 @@ def test_strip_pixflow_low_and_search_20_vs_oracle(pf, orc, strip):
         rout = orc.combine_novel_views(L, R, r0, r1, blend)
         d = np.abs(out.astype(np.int32) - rout.astype(np.int32))
         assert d.max() <= 1 and (d > 0).mean() < 2e-3          # libm ulps in tanhf/exp of the blend only
+    for pct in (0, 20):
+        for d in (0, 1):
+            assert np.array_equal(gotw[pct][d].view(np.uint32), ref[("wide", pct, d)].view(np.uint32)), "wide pair, pixflow %d dir %d" % (pct, d)
     # the wide-search path (PixFlow.hpp:226-270,296-303) really took part: it changes the result
-    assert not np.array_equal(got[0][1], got[20][1])
+    assert not np.array_equal(gotw[0][0], gotw[20][0])
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,97 @@
+"""Boundary / oracle hygiene: the raw countblend ratio, median selection on ties and signed zeros
+(and what NaN does), and the three latent hazards of the reference that both sides DEFINE instead of reproducing
+(SURVEY.md section 5): out-of-bounds probes in Gather, the single wrap in generateNovelViewPoint, step == 0 in countblend."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+rng = np.random.default_rng(23)
+
+
+@pytest.fixture(scope="module")
+def ctx(pf):
+    c = pf.Context(0)
+    yield c
+    c.close()
+
+
+def test_countblend_raw_ratio_and_merged_dis(ctx, orc, synth):
+    """Stitchtools::countblend returns minLdis/(minRdis+minLdis) BEFORE any smoothing and writes MergedDis
+    (CPU/StitchTool.cpp:185-190): pf_stitch_raw_blend against the oracle's GenerateBlend with the smoothing switched off."""
+    L, R = synth.make_canvas_pair(640, 420, 9)
+    L = L.numpy(); R = R.numpy()
+    raw, md = ctx.stitch_raw_blend(L, R)
+    mp, _, _, ref_raw, ref_md = orc.stitch_prepare(L, R, False)
+    assert (mp == 150).mean() > 0.05
+    assert np.array_equal(raw, ref_raw) and np.array_equal(md, ref_md)
+    _, _, _, smooth, _ = ctx.stitch_prepare(L, R)
+    assert not np.array_equal(raw, smooth)               # the smoothed ramp is a different thing
+
+
+def test_median5_ties_and_signed_zeros(ctx, orc):
+    """medianBlur(5) is pure selection: with heavy ties and both zeros present the selected VALUE equals the oracle's
+    (np.array_equal: +0 == -0; which zero is picked is unspecified on both sides -- OpenCV's sorting network and
+    nth_element disagree on that themselves)."""
+    f = rng.integers(-2, 3, size=(61, 47, 2)).astype(np.float32)        # five distinct values: ties everywhere
+    f[rng.random(f.shape) < 0.2] = -0.0
+    got = ctx.stage_median5(f)
+    assert np.array_equal(got, orc.median5(f))
+    flat = np.full((33, 40, 2), 7.25, np.float32)
+    assert np.array_equal(ctx.stage_median5(flat), flat)
+
+
+def test_median5_nan_is_dropped_not_propagated(ctx):
+    """NaN has no defined rank (the reference's result depends on OpenCV's SIMD vs scalar path).  Defined here: the
+    min/max exchange network treats a NaN as absent (fminf/fmaxf return the other operand), so a window with a few NaNs
+    yields a finite value inside the range of its finite members, and windows without NaN are unaffected."""
+    f = rng.standard_normal((40, 52, 2)).astype(np.float32)
+    clean = ctx.stage_median5(f)
+    g = f.copy(); g[20, 30, 0] = np.nan; g[5, 5, 1] = np.nan
+    got = ctx.stage_median5(g)
+    assert np.isfinite(got).all()
+    far = np.ones(f.shape[:2], bool); far[18:23, 28:33] = False; far[3:8, 3:8] = False
+    assert np.array_equal(got[far], clean[far])
+    win = f[18:23, 28:33, 0]
+    assert win.min() <= got[20, 30, 0] <= win.max()
+
+
+def test_gather_out_of_bounds_probes_are_no_match(ctx, orc):
+    """Gather's 8-direction probes (StitchTool.cpp:70-90) index the map without bounds checks; defined as 'no match'.
+    An overlap pixel (code 150, merged alpha 0) in a corner whose only L-only neighbour lies to the right."""
+    cols, rows = 64, 48
+    L = np.zeros((rows, cols, 4), np.uint8); R = np.zeros_like(L); merged = np.zeros_like(L)
+    mp = np.zeros((rows, cols), np.uint8)
+    mp[0:3, 0:3] = 150                      # overlap pixels in the top-left corner, nothing merged there
+    mp[0:3, 3:10] = 100                     # L-only to the right
+    mp[40:48, 60:64] = 150                  # bottom-right corner, nothing within reach -> stays (0,0,0,255)
+    L[...] = (10, 20, 30, 255); R[...] = (200, 210, 220, 255)
+    got = ctx.stitch_gather(L, R, merged, mp)
+    assert np.array_equal(got, orc.stitch_gather(L, R, merged, mp))
+    assert tuple(got[0, 0]) == (10, 20, 30, 255)           # found L at distance 3 to the right; probes at x-3 < 0 ignored
+    assert tuple(got[47, 63]) == (0, 0, 0, 255)
+
+
+def test_novel_view_point_wraps_with_true_modulo(ctx, orc, synth):
+    """generateNovelViewPoint wraps x once (OpticalFlow.cpp:17-20): |flow * t| > cols would read out of bounds.
+    Defined as a true modulo on both sides."""
+    cols, rows = 96, 64
+    L, R, blend = synth.make_pair_np(cols, rows, 3)
+    L[..., 3] = 255; R[..., 3] = 255
+    f0 = np.zeros((rows, cols, 2), np.float32); f1 = np.zeros_like(f0)
+    f0[..., 0] = 2.5 * cols; f1[..., 0] = -3.25 * cols; f0[::2, :, 1] = 5 * rows; f1[1::2, :, 1] = -7 * rows   # y clamps, x wraps
+    got = ctx.blend(L, R, f0, f1, blend)
+    ref = orc.combine_novel_views(L, R, f0, f1, blend)
+    d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 5e-3
+
+
+@pytest.mark.parametrize("cols,rows", [(150, 120), (120, 260)])
+def test_countblend_step_zero_is_defined(ctx, orc, synth, cols, rows):
+    """min(cols, rows) < 200 makes the reference's search stride 0 (an endless loop, StitchTool.cpp:153-158) and
+    rows < 130 a zero-size blur kernel (an OpenCV assertion): defined as stride 1 / 'skip the blur' on both sides."""
+    L, R = synth.make_canvas_pair(cols, rows, 4)
+    L = L.numpy(); R = R.numpy()
+    mp, ovl, ovr, bl, md = ctx.stitch_prepare(L, R)
+    rmp, rovl, rovr, rbl, rmd = orc.stitch_prepare(L, R, True)
+    assert (mp == 150).any()
+    assert np.array_equal(mp, rmp) and np.array_equal(bl, rbl) and np.array_equal(md, rmd)
