@@ -150,7 +150,15 @@ def main():
 
     # the only exchange of the path: final gather of the blended strips to rank 0 over RCCL/xGMI.  It overlaps the next
     # pair's compute (two result buffers, one gather in flight); the fence waits for the last one.
-    og = shard.OverlappedGather(out, world, rank) if (world > 1 or force_dist) else None
+    og = None
+    pfd = None
+    if world > 1 or force_dist:
+        # control plane only: rank 0's ncclUniqueId reaches the other ranks through torch.distributed; the gather itself runs
+        # inside libpanoflow.so (pf_dist_*: grouped ncclSend/ncclRecv on its own HIP stream)
+        ids = [pf.dist_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        pfd = pf.Dist(local_rank, ids[0], rank, world)
+        og = shard.RcclGather(out, pfd)
     step_ms = []
 
     def step():
@@ -170,7 +178,7 @@ def main():
     def fence():
         if og:
             og.wait()
-            dist.barrier()
+            pfd.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -185,7 +193,11 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
-    dt = shard.max_over_ranks(dt, dev)
+    dt = pfd.max(dt) if pfd else dt
+    gathered_ok = None
+    if og and rank == 0:
+        # the strip this rank produced last must be what arrived in its own slot of the receive area
+        gathered_ok = bool(torch.equal(og.last()[0], og.bufs[(og.k - 1) % 2]))
     med_ms = statistics.median(step_ms)
     swept = ctx.last_swept_steps()
 
@@ -207,7 +219,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %dx%d overlap pair per GPU, %s, flow L->R + R->L + novel-view blend, %d pair(s) in flight per GPU" % (which, cols, rows, args.alg, max(1, args.concurrent)),
                        "levels": nlev, "level_pixels": P, "sweep_steps_per_direction": sweep_steps, "swept_steps_per_direction_in_gated_window": swept,
-                       "final_gather": "rccl, overlapped with the next pair" if world > 1 else "none"},
+                       "final_gather": ("rccl send/recv to rank 0 inside libpanoflow.so (pf_dist_*), overlapped with the next pair; rank-0 slot verified: %s" % gathered_ok) if og else "none"},
             "ms_per_step_median": round(med_ms, 3), "value_at_median": round(npairs * mpix / (med_ms * 1e-3), 3),
         }
         # roofline of the dominant kernel (the exact wavefront sweep): algorithmic bytes per launch =
@@ -299,6 +311,8 @@ def main():
             res["parity_vs_cpu"] = {"max_abs_dflow_px": float(max(np.abs(g0 - r0).max(), np.abs(g1 - r1).max())),
                                     "blend_pixels_off": int((off > 0).sum()), "blend_max_lsb": int(off.max())}
         line = json.dumps(res)
+    if pfd:
+        pfd.close()
     if world > 1 or force_dist:
         dist.destroy_process_group()
     if rank == 0:

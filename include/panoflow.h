@@ -117,6 +117,24 @@ int pf_blend_dev(pf_ctx* ctx, const uint8_t* d_l, const uint8_t* d_r, const floa
 int pf_novel_view_dev(pf_ctx* ctx, const uint8_t* d_l, const uint8_t* d_r, int cols, int rows, int max_percentage,
                       const float* d_blend, uint8_t* d_out, float* d_flow_l2r, float* d_flow_r2l);
 
+/* ---- multi-GPU: the path's only exchange ---------------------------------
+ * Overlap pairs are independent units (no state shared between the reference's Stitchtools / NovelViewGenerator objects,
+ * CPU/main.cpp:70,82): one rank (process or host thread) + one pf_ctx per GPU, pair i on rank i % world, NO collective
+ * on the data path.  What remains is the final gather of the results into rank 0's HBM: grouped ncclSend/ncclRecv over
+ * RCCL/xGMI on a stream of its own, so that the gather of pair k overlaps the compute of pair k+1.  RCCL is bound at run
+ * time (dlopen): single-GPU users carry no dependency on it.  The reference has no counterpart (it is single-device). */
+typedef struct pf_dist pf_dist;
+int pf_dist_unique_id(void* id128);                                   /* rank 0: 128-byte ncclUniqueId to hand to every rank */
+pf_dist* pf_dist_init(int device, const void* id128, int rank, int world);   /* NULL on failure; pf_dist_last_error(NULL) */
+void pf_dist_destroy(pf_dist* d);
+const char* pf_dist_last_error(const pf_dist* d);
+/* every rank sends `bytes` from d_send; rank 0 receives rank r's block at d_recv_all + r*bytes (d_recv_all ignored elsewhere).
+ * Asynchronous; at most one gather in flight (a second call first waits for the previous one). */
+int pf_dist_gather_async(pf_dist* d, const void* d_send, void* d_recv_all, size_t bytes);
+int pf_dist_wait(pf_dist* d);                                         /* host-blocking: the last gather has completed */
+int pf_dist_max(pf_dist* d, double* value_inout);                     /* max over ranks (the job's time is the slowest rank's) */
+int pf_dist_barrier(pf_dist* d);
+
 /* ---- stage-level entry points (host buffers, packed) ---------------------------------------
  * One per reference step, so that tests can check every HIP kernel family against the oracle in
  * isolation.  They run the very kernels the entry points above chain together. */

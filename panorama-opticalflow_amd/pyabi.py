@@ -46,6 +46,15 @@ def lib():
         _lib.pf_dev_free.argtypes = [C.c_void_p, C.c_void_p]
         _lib.pf_algorithmic_bytes.restype = C.c_double
         _lib.pf_level_pixels.restype = C.c_longlong
+        _lib.pf_dist_init.restype = C.c_void_p
+        _lib.pf_dist_init.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
+        _lib.pf_dist_destroy.argtypes = [C.c_void_p]
+        _lib.pf_dist_last_error.restype = C.c_char_p
+        _lib.pf_dist_last_error.argtypes = [C.c_void_p]
+        _lib.pf_dist_gather_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        _lib.pf_dist_wait.argtypes = [C.c_void_p]
+        _lib.pf_dist_max.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.pf_dist_barrier.argtypes = [C.c_void_p]
         _lib.pf_last_swept_steps.restype = C.c_longlong
         _lib.pf_last_swept_steps.argtypes = [C.c_void_p]
     return _lib
@@ -60,6 +69,7 @@ EXPORTS = [
     "pf_stage_diffusion", "pf_stage_upsample_cubic", "pf_stage_final", "pf_stage_adjust_initial_flow", "pf_stage_level",
     "pf_stage_blend_smooth",
     "pf_profile_enable", "pf_profile_reset", "pf_profile_count", "pf_profile_get", "pf_algorithmic_bytes", "pf_level_pixels", "pf_last_swept_steps",
+    "pf_dist_unique_id", "pf_dist_init", "pf_dist_destroy", "pf_dist_last_error", "pf_dist_gather_async", "pf_dist_wait", "pf_dist_max", "pf_dist_barrier",
 ]
 
 
@@ -93,6 +103,48 @@ def level_pixels(cols, rows):
     n = C.c_int(0); s = C.c_longlong(0)
     p = lib().pf_level_pixels(cols, rows, C.byref(n), C.byref(s))
     return int(p), n.value, int(s.value)
+
+
+def dist_unique_id():
+    """rank 0: the 128-byte ncclUniqueId every rank passes to Dist()"""
+    buf = C.create_string_buffer(128)
+    if lib().pf_dist_unique_id(buf) != 0:
+        raise PanoflowError("pf_dist_unique_id: " + lib().pf_dist_last_error(None).decode())
+    return buf.raw
+
+
+class Dist:
+    """The path's only exchange: gather of per-pair results into rank 0's HBM over RCCL (pf_dist_*), asynchronous."""
+
+    def __init__(self, device, unique_id, rank, world):
+        self.l = lib()
+        h = self.l.pf_dist_init(device, C.c_char_p(unique_id), rank, world)
+        if not h:
+            raise PanoflowError("pf_dist_init failed: " + self.l.pf_dist_last_error(None).decode())
+        self.h = C.c_void_p(h); self.rank = rank; self.world = world
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise PanoflowError("pf_dist error %d: %s" % (rc, self.l.pf_dist_last_error(self.h).decode()))
+
+    def gather_async(self, d_send, d_recv_all, nbytes):
+        self._chk(self.l.pf_dist_gather_async(self.h, C.c_void_p(d_send), C.c_void_p(d_recv_all) if d_recv_all else None, C.c_size_t(nbytes)))
+
+    def wait(self):
+        self._chk(self.l.pf_dist_wait(self.h))
+
+    def max(self, value):
+        v = C.c_double(value)
+        self._chk(self.l.pf_dist_max(self.h, C.byref(v)))
+        return v.value
+
+    def barrier(self):
+        self._chk(self.l.pf_dist_barrier(self.h))
+
+    def close(self):
+        if self.h:
+            self.l.pf_dist_destroy(self.h)
+            self.h = None
 
 
 class Context:

@@ -77,6 +77,34 @@ class OverlappedGather:
         return self.recv[(self.k - 1) % 2] if self.k else None
 
 
+class RcclGather:
+    """Same job as OverlappedGather, but through the product's own C ABI (pf_dist_*: grouped ncclSend/ncclRecv on a
+    dedicated HIP stream inside libpanoflow.so) -- torch is not on the data path; it only carried the 128-byte
+    ncclUniqueId to the ranks.  `dist_obj` is a pyabi.Dist; buffers are torch CUDA tensors used as raw HBM."""
+
+    def __init__(self, like, dist_obj):
+        self.d, self.k = dist_obj, 0
+        self.bufs = [like, torch.empty_like(like)]
+        self.nbytes = like.numel() * like.element_size()
+        self.recv = [torch.empty((dist_obj.world,) + tuple(like.shape), dtype=like.dtype, device=like.device) for _ in range(2)] if dist_obj.rank == 0 else [None, None]
+
+    def out_buffer(self):
+        return self.bufs[self.k % 2]
+
+    def submit(self):
+        """start gathering the buffer just written (the producing pf_* call is synchronous on return); pf_dist_gather_async
+        itself first waits for the previous gather, so a buffer is never overwritten while it is being sent"""
+        j = self.k % 2
+        self.d.gather_async(self.bufs[j].data_ptr(), self.recv[j].data_ptr() if self.recv[j] is not None else 0, self.nbytes)
+        self.k += 1
+
+    def wait(self):
+        self.d.wait()
+
+    def last(self):
+        return self.recv[(self.k - 1) % 2] if self.k else None
+
+
 def max_over_ranks(seconds, device="cpu"):
     """The job's time is the slowest rank's (bench.py contract)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

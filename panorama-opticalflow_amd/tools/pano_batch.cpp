@@ -1,0 +1,168 @@
+// pano_batch -- multi-GPU batch driver for independent overlap pairs (BASELINE config 5).
+//
+// One host thread + one pf_ctx + one RCCL rank per GPU; pair i runs on GPU i % N (static round-robin, no collective on
+// the data path: pairs share no state, CPU/main.cpp:70,82).  The only exchange is the gather of the blended strips
+// into rank 0's HBM: grouped ncclSend/ncclRecv on the gather stream (pf_dist_gather_async), double-buffered so that the
+// gather of round j overlaps the compute of round j+1.  Host code is C++ over the C ABI; no Python, no torch.
+//
+//   pano_batch -pairs 8 -size 9000x4000 -flow_alg pixflow_search_20 [-gpus N] [-verify 1]
+//
+// Inputs are synthetic (textured pair with a smooth displacement, alpha holes at the edges) generated on the host per
+// pair and uploaded once; the clock covers compute + gather with inputs resident in HBM.
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/panoflow.h"
+#include "batch_plan.hpp"
+
+namespace {
+
+struct Args { int pairs = 8, cols = 9000, rows = 4000, gpus = 0, verify = 1; std::string alg = "pixflow_low"; };
+
+bool parse(int argc, char** argv, Args& a) {
+  for (int i = 1; i < argc; ++i) {
+    std::string k = argv[i];
+    while (!k.empty() && k[0] == '-') k.erase(0, 1);
+    std::string v;
+    const size_t eq = k.find('=');
+    if (eq != std::string::npos) { v = k.substr(eq + 1); k = k.substr(0, eq); }
+    else if (i + 1 < argc) v = argv[++i];
+    else return false;
+    if (k == "pairs") a.pairs = atoi(v.c_str());
+    else if (k == "size") { if (sscanf(v.c_str(), "%dx%d", &a.cols, &a.rows) != 2) return false; }
+    else if (k == "flow_alg") a.alg = v;
+    else if (k == "gpus") a.gpus = atoi(v.c_str());
+    else if (k == "verify") a.verify = atoi(v.c_str());
+    else return false;
+  }
+  return a.pairs > 0 && a.cols > 0 && a.rows > 0;
+}
+
+// deterministic synthetic pair: three sinusoid layers per channel, L = T(x + d/2), R = 1.05 T(x - d/2)
+void make_pair(int cols, int rows, int seed, std::vector<uint8_t>& L, std::vector<uint8_t>& R, std::vector<float>& blend) {
+  L.assign(size_t(cols) * rows * 4, 0); R.assign(size_t(cols) * rows * 4, 0); blend.assign(size_t(cols) * rows, 0.f);
+  const double ph = 0.37 * seed;
+  auto tex = [&](double u, double v, int c) {
+    return 128.0 + 40.0 * std::sin(0.071 * u + 0.013 * v + ph + c) + 35.0 * std::sin(0.019 * u - 0.047 * v + 2.0 * ph + 0.5 * c) +
+           25.0 * std::sin(0.23 * u + 0.31 * v + 3.0 * ph + 0.25 * c);
+  };
+  const int band = cols / 16;
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x) {
+      const double dx = 6.0 * std::sin(3 * M_PI * y / rows) + 3.0 * std::cos(4 * M_PI * x / cols), dy = 1.5 * std::sin(6 * M_PI * x / cols);
+      const size_t i = (size_t(y) * cols + x) * 4;
+      const bool in = x >= band && x < cols - band;
+      for (int c = 0; c < 3; ++c) {
+        const double l = tex(x + dx / 2, y + dy / 2, c), r = 1.05 * tex(x - dx / 2, y - dy / 2, c);
+        L[i + c] = in ? (uint8_t)std::lround(std::fmin(240.0, std::fmax(16.0, l))) : 0;
+        R[i + c] = in ? (uint8_t)std::lround(std::fmin(240.0, std::fmax(16.0, r))) : 0;
+      }
+      L[i + 3] = R[i + 3] = in ? 255 : 0;
+      blend[size_t(y) * cols + x] = float(x) / float(cols - 1);
+    }
+}
+
+uint64_t fnv(const uint8_t* p, size_t n) { uint64_t h = 1469598103934665603ull; for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; } return h; }
+
+struct Shared {
+  Args a; int ndev; int max_pct; unsigned char id[128];
+  std::vector<uint64_t> sum_local, sum_gathered;   // per pair: checksum at its producer / at rank 0 after the gather
+  std::vector<double> secs;                        // per device
+  std::atomic<int> failed{0};
+};
+
+void worker(Shared* s, int dev) {
+  const Args& a = s->a;
+  const int ndev = s->ndev;
+  auto die = [&](const char* what, const char* msg) { fprintf(stderr, "[gpu %d] %s: %s\n", dev, what, msg); s->failed = 1; };
+  pf_ctx* ctx = pf_create(dev, a.cols, a.rows);
+  if (!ctx) return die("pf_create", pf_last_error(nullptr));
+  pf_dist* dist = pf_dist_init(dev, s->id, dev, ndev);
+  if (!dist) { die("pf_dist_init", pf_dist_last_error(nullptr)); pf_destroy(ctx); return; }
+  const size_t n = size_t(a.cols) * a.rows, ib = n * 4;
+  const std::vector<int> mine = pano_batch::pairs_for_device(a.pairs, dev, ndev);
+  const int nrounds = pano_batch::rounds(a.pairs, ndev);
+  // inputs of all my pairs resident in HBM before the clock starts
+  std::vector<void*> dL(mine.size()), dR(mine.size());
+  void* dBlend = pf_dev_alloc(ctx, n * 4);
+  void* dOut[2] = {pf_dev_alloc(ctx, ib), pf_dev_alloc(ctx, ib)};
+  void* dRecv[2] = {nullptr, nullptr};
+  if (dev == 0) { dRecv[0] = pf_dev_alloc(ctx, ib * ndev); dRecv[1] = pf_dev_alloc(ctx, ib * ndev); }
+  {
+    std::vector<uint8_t> L, R; std::vector<float> blend;
+    for (size_t k = 0; k < mine.size(); ++k) {
+      make_pair(a.cols, a.rows, 1234 + mine[k], L, R, blend);
+      dL[k] = pf_dev_alloc(ctx, ib); dR[k] = pf_dev_alloc(ctx, ib);
+      if (!dL[k] || !dR[k] || pf_upload(ctx, dL[k], L.data(), ib) || pf_upload(ctx, dR[k], R.data(), ib)) { die("upload", pf_last_error(ctx)); return; }
+      if (k == 0 && pf_upload(ctx, dBlend, blend.data(), n * 4)) { die("upload", pf_last_error(ctx)); return; }
+    }
+    if (mine.empty()) { make_pair(a.cols, a.rows, 1, L, R, blend); pf_upload(ctx, dBlend, blend.data(), n * 4); }
+  }
+  std::vector<uint8_t> host(a.verify ? ib : 0);
+  auto consume = [&](int round) {   // rank 0: the blocks of `round` are in dRecv[round % 2]
+    if (dev != 0 || !a.verify) return;
+    for (int r = 0; r < ndev; ++r) {
+      const int p = pano_batch::pair_of(round, r, a.pairs, ndev);
+      if (p < 0) continue;
+      pf_download(ctx, host.data(), static_cast<char*>(dRecv[round % 2]) + size_t(r) * ib, ib);
+      s->sum_gathered[p] = fnv(host.data(), ib);
+    }
+  };
+  if (pf_dist_barrier(dist)) { die("barrier", pf_dist_last_error(dist)); return; }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int j = 0; j < nrounds; ++j) {
+    const int p = pano_batch::pair_of(j, dev, a.pairs, ndev);
+    void* out = dOut[j % 2];
+    if (p >= 0) {
+      const size_t k = size_t(j);   // my k-th pair is handled in round k
+      if (pf_novel_view_dev(ctx, (const uint8_t*)dL[k], (const uint8_t*)dR[k], a.cols, a.rows, s->max_pct, (const float*)dBlend, (uint8_t*)out, nullptr, nullptr)) {
+        die("pf_novel_view_dev", pf_last_error(ctx)); return;
+      }
+      if (a.verify) { pf_download(ctx, host.data(), out, ib); s->sum_local[p] = fnv(host.data(), ib); }
+    }
+    // all ranks take part in every round (a rank without a pair in the last round sends its stale buffer, which rank 0 ignores);
+    // the call first waits for the previous gather, whose receive area the consumer below then owns
+    if (pf_dist_gather_async(dist, out, dRecv[j % 2], ib)) { die("gather", pf_dist_last_error(dist)); return; }
+    if (j > 0) consume(j - 1);
+  }
+  if (pf_dist_wait(dist)) { die("wait", pf_dist_last_error(dist)); return; }
+  if (nrounds > 0) consume(nrounds - 1);
+  double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  s->secs[dev] = dt;
+  if (pf_dist_max(dist, &dt)) { die("max", pf_dist_last_error(dist)); return; }
+  if (dev == 0) s->secs[0] = dt;   // the job's time: the slowest rank's
+  pf_dist_destroy(dist);
+  pf_destroy(ctx);
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  Shared s;
+  if (!parse(argc, argv, s.a)) { fprintf(stderr, "usage: pano_batch -pairs P -size COLSxROWS -flow_alg pixflow_low|pixflow_search_20 [-gpus N] [-verify 0|1]\n"); return 2; }
+  s.max_pct = pf_max_percentage_by_name(s.a.alg.c_str());
+  if (s.max_pct < 0) { fprintf(stderr, "%s\n", pf_last_error(nullptr)); return 1; }
+  const int have = pf_device_count();
+  if (have <= 0) { fprintf(stderr, "no HIP device (this driver has no CPU path)\n"); return 1; }
+  s.ndev = s.a.gpus > 0 ? s.a.gpus : have;
+  if (s.ndev > have) { fprintf(stderr, "%d GPUs requested, %d present\n", s.ndev, have); return 1; }
+  if (pf_dist_unique_id(s.id)) { fprintf(stderr, "%s\n", pf_dist_last_error(nullptr)); return 1; }
+  s.sum_local.assign(s.a.pairs, 0); s.sum_gathered.assign(s.a.pairs, 0); s.secs.assign(s.ndev, 0.0);
+  std::vector<std::thread> th;
+  for (int d = 0; d < s.ndev; ++d) th.emplace_back(worker, &s, d);
+  for (auto& t : th) t.join();
+  if (s.failed) return 1;
+  int bad = 0;
+  if (s.a.verify) for (int p = 0; p < s.a.pairs; ++p) if (!s.sum_local[p] || s.sum_local[p] != s.sum_gathered[p]) { fprintf(stderr, "pair %d: gathered strip differs from its producer's\n", p); ++bad; }
+  const double mpix = double(s.a.cols) * s.a.rows * s.a.pairs / 1e6;
+  printf("{\"tool\": \"pano_batch\", \"gpus\": %d, \"pairs\": %d, \"size\": \"%dx%d\", \"flow_alg\": \"%s\", \"seconds\": %.4f, \"Mpix/s\": %.2f, \"verified_pairs\": %d, \"gather\": \"rccl send/recv to rank 0, overlapped\"}\n",
+         s.ndev, s.a.pairs, s.a.cols, s.a.rows, s.a.alg.c_str(), s.secs[0], mpix / s.secs[0], s.a.verify ? s.a.pairs - bad : 0);
+  return bad ? 1 : 0;
+}
