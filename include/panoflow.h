@@ -117,6 +117,14 @@ int pf_blend_dev(pf_ctx* ctx, const uint8_t* d_l, const uint8_t* d_r, const floa
 int pf_novel_view_dev(pf_ctx* ctx, const uint8_t* d_l, const uint8_t* d_r, int cols, int rows, int max_percentage,
                       const float* d_blend, uint8_t* d_out, float* d_flow_l2r, float* d_flow_r2l);
 
+/* Throughput mode: n_pairs independent pairs of one size, `in_flight` (1..16) of them side by side on this GPU (the exact
+ * sweeps of one pair are a dependency chain that occupies ~1/4 of the CUs).  Arrays of n_pairs device pointers; d_flow_*
+ * may be NULL (or hold NULL entries).  Same results as n_pairs calls of pf_novel_view_dev.  Needs GPU_MAX_HW_QUEUES >=
+ * 4 * in_flight in the environment before the first HIP call, or the lanes' streams share hardware queues. */
+int pf_novel_view_batch_dev(pf_ctx* ctx, int n_pairs, const uint8_t* const* d_l, const uint8_t* const* d_r, int cols, int rows,
+                            int max_percentage, const float* const* d_blend, uint8_t* const* d_out, float* const* d_flow_l2r,
+                            float* const* d_flow_r2l, int in_flight);
+
 /* ---- multi-GPU: the path's only exchange ---------------------------------
  * Overlap pairs are independent units (no state shared between the reference's Stitchtools / NovelViewGenerator objects,
  * CPU/main.cpp:70,82): one rank (process or host thread) + one pf_ctx per GPU, pair i on rank i % world, NO collective

@@ -41,7 +41,10 @@ constexpr int kChunk = 8;    // steps streamed per helper iteration and wave
 constexpr int kRad = 8;      // LDS window of the gathered plane: +-kRad texels around the band
 constexpr int kWA = kRows + 2 * kRad + 1;   // window extent across the band (25)
 constexpr int kWC = 64;      // window ring along the step axis (columns)
-constexpr int kSpinLimit2 = 1 << 20;
+// Every wait is bounded by WALL-CLOCK time, not by a spin count: the deadline (kernel entry + a budget the host scales with
+// the launch: 2 s + 1000x the expected duration) sits in LDS and is only looked at every 1024 polls.  A band that is merely
+// slow -- several contexts oversubscribing the GPU, a predecessor workgroup not scheduled yet -- therefore never raises
+// PF_ERR_TIMEOUT; a genuinely stuck one still does instead of hanging the GPU.
 #ifndef PF_SWEEP_UNROLL
 #define PF_SWEEP_UNROLL 8
 #endif
@@ -292,9 +295,15 @@ struct Smem {
   int bndHead;           // boundary columns available to wave 0        (granule helper -> compute)
   int abort;
   int wg;
+  long long deadline;        // wall_clock64() value after which a waiting wave gives up
   int statHits, statSpins;   // -DPF_SWEEP_STATS only
   long long statEntry;
 };
+
+__device__ __forceinline__ bool spin_expired(int& spins, const Smem& sm) {
+  if ((++spins & 1023) != 0) return false;
+  return (long long)wall_clock64() > *(const volatile long long*)&sm.deadline;
+}
 
 // LDS counters: a wave's LDS operations are executed in issue order by the CU's LDS unit, so "write data,
 // then write counter" / "read counter, then read data" needs no s_waitcnt between them -- only the
@@ -388,7 +397,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
         fcRec = ld_cnt(&sm.recHead[w]); fcTail = ld_cnt(&sm.outTail[w]);
         if (lastPub) fcPub = ld_cnt(&sm.pubTail);
         if (hasNext) fcNext = ld_cnt(&sm.outHead[w + 1]);
-        if (++spins > kSpinLimit2 || (((spins & 255) == 0) && ld_cnt(&sm.abort))) return false;
+        if (spin_expired(spins, sm) || (((spins & 255) == 0) && ld_cnt(&sm.abort))) return false;
       }
 #ifdef PF_SWEEP_STATS
       if (spins) { ++statSlowChunks; statChunkSpins += spins; }
@@ -438,7 +447,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
             for (;;) {
               avail = __builtin_amdgcn_readfirstlane(ld_cnt(topHead)) - kBias;
               if (avail >= need) break;
-              if (++spins > kSpinLimit2 || (((spins & 255) == 0) && ld_cnt(&sm.abort))) { dead = true; avail = 0x7fffffff; break; }
+              if (spin_expired(spins, sm) || (((spins & 255) == 0) && ld_cnt(&sm.abort))) { dead = true; avail = 0x7fffffff; break; }
             }
 #ifdef PF_SWEEP_STATS
             statSpins += spins;
@@ -585,7 +594,7 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
 template <bool TR, bool FWD, bool SPARSE>
 __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
                                                 unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H,
-                                                int nstepsPad, int nbands, float rW, float rEps, int uLo, int LSv, int bandLo) {
+                                                int nstepsPad, int nbands, float rW, float rEps, int uLo, int LSv, int bandLo, long long budgetTicks) {
   // Active window of this sweep (everything outside it holds pixels that are not updated and keeps its flow):
   // nbands bands starting at band bandLo, sweep-order columns [uLo, uLo + LSv) along the step axis.  Steps, ring
   // indices and granule columns are relative to uLo; image coordinates are formed from uLo + relative column.
@@ -600,6 +609,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
   if (tid == 0) {
     sm.wg = atomicAdd(&ctrl[0], 1);
     sm.bndHead = 0; sm.abort = 0; sm.pubTail = 0; sm.statHits = 0; sm.statSpins = 0;
+    sm.deadline = (long long)wall_clock64() + budgetTicks;
   }
   if (tid < kWaves) { sm.recHead[tid] = 0; sm.outHead[tid] = 0; sm.outTail[tid] = 0; }
   __syncthreads();
@@ -720,7 +730,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
       if (progress) idle = 0;
       else {
         __builtin_amdgcn_s_sleep(4);
-        if (++idle > kSpinLimit2 || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
     }
     return;
@@ -760,7 +770,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
       if (progress) idle = 0;
       else {
         __builtin_amdgcn_s_sleep(4);
-        if (++idle > kSpinLimit2 || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
     }
     return;
@@ -788,7 +798,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
         idle = 0;
       } else {
         __builtin_amdgcn_s_sleep(1);
-        if (++idle > kSpinLimit2 || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
     }
     return;
@@ -818,7 +828,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
       } else {
         __builtin_amdgcn_s_sleep(8);
       }
-      if (++idle > kSpinLimit2 || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
   }
 }
@@ -848,10 +858,12 @@ void launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
   const float rW = (float)(1.0 / (double)(float)a.W), rEps = (float)(1.0 / (double)kGradEpsilon);
   hipLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((prepThreads + 255) / 256)), dim3(256), 0, st, a.g0, a.g1, a.blurred, a.gate, a.flow, a.W, a.H, a.forward, tr,
                      nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo, bandLo > 0 ? a.boundary : nullptr);
+  // wall-clock budget of every wait inside the launch, in 100 MHz ticks: 2 s + 1000 x the expected duration (~0.5 us per step)
+  const long long budget = 200000000ll + 1000ll * 50ll * (long long)(nstepsPad + 9 * nbands);
   const dim3 grid(nwg), block(64 * (2 * kWaves + 3));
   const float4* r4 = reinterpret_cast<const float4*>(rec);
-#define PF_LAUNCH_SWEEP2(TRV, FWV) do { if (a.sparse) hipLaunchKernelGGL((k_sweep2<TRV, FWV, true>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo); \
-    else hipLaunchKernelGGL((k_sweep2<TRV, FWV, false>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo); } while (0)
+#define PF_LAUNCH_SWEEP2(TRV, FWV) do { if (a.sparse) hipLaunchKernelGGL((k_sweep2<TRV, FWV, true>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget); \
+    else hipLaunchKernelGGL((k_sweep2<TRV, FWV, false>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget); } while (0)
   if (tr) { if (a.forward) PF_LAUNCH_SWEEP2(true, true); else PF_LAUNCH_SWEEP2(true, false); }
   else { if (a.forward) PF_LAUNCH_SWEEP2(false, true); else PF_LAUNCH_SWEEP2(false, false); }
 #undef PF_LAUNCH_SWEEP2

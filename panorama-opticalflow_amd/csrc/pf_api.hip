@@ -9,6 +9,7 @@
 
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/panoflow.h"
@@ -42,6 +43,7 @@ struct pf_ctx {
   int sweep_version = 2;
   int chain_cols = 0, chain_rows = 0;   // size of the stitch-chain result resident in "ch_final"
   long long last_swept_steps = 0;       // wavefront steps of one direction of the last solve (both sweeps, all levels, gated windows)
+  std::vector<pf_ctx*> lanes;           // throughput mode: further stream/buffer sets on the same device (pf_novel_view_batch_dev)
   int* h_status = nullptr;              // mapped pinned host word: bit d set = a sweep band of direction d timed out
   int* d_status = nullptr;              // the same word as the device sees it
   std::vector<std::string> prof_names;
@@ -438,6 +440,8 @@ pf_ctx* pf_create(int device, int max_cols, int max_rows) {
 
 void pf_destroy(pf_ctx* c) {
   if (!c) return;
+  for (pf_ctx* l : c->lanes) pf_destroy(l);
+  c->lanes.clear();
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   for (auto& kv : c->bufs) if (kv.second.p) hipFree(kv.second.p);
@@ -524,6 +528,42 @@ int pf_novel_view_dev(pf_ctx* c, const uint8_t* d_l, const uint8_t* d_r, int col
   HIPCHK(c, hipGetLastError());
   if (int e = finish(c)) return e;
   return check_sweeps(c, cols, rows, pad, 2);
+}
+
+// ---- throughput mode ----
+// One pair keeps ~70 workgroups of a sweep busy (two directions x ~35 bands-of-4): the exact sweeps are a dependency chain, so
+// most of the 256 CUs idle.  When pairs are plentiful, `in_flight` of them run side by side on the same GPU, each on its
+// own stream / buffer set ("lane", created on first use and kept) driven by its own host thread; pair i goes to lane
+// i % in_flight.  Results are identical to n_pairs calls of pf_novel_view_dev.  Set GPU_MAX_HW_QUEUES >= 4 * in_flight
+// before the first HIP call (the runtime's default of 4 hardware queues would serialise the lanes' streams).
+int pf_novel_view_batch_dev(pf_ctx* c, int n_pairs, const uint8_t* const* d_l, const uint8_t* const* d_r, int cols, int rows, int max_pct,
+                            const float* const* d_blend, uint8_t* const* d_out, float* const* d_l2r, float* const* d_r2l, int in_flight) {
+  if (int e = use(c)) return e;
+  if (n_pairs < 0 || !d_l || !d_r || !d_blend || !d_out) return fail(c, PF_ERR_ARG, "bad argument");
+  if (in_flight < 1) in_flight = 1;
+  if (in_flight > 16) in_flight = 16;
+  if (in_flight > n_pairs) in_flight = n_pairs > 0 ? n_pairs : 1;
+  while ((int)c->lanes.size() < in_flight - 1) {
+    pf_ctx* l = pf_create(c->device, cols, rows);
+    if (!l) return fail(c, PF_ERR_NOMEM, "cannot create lane %d: %s", (int)c->lanes.size() + 1, g_err.c_str());
+    l->sweep_version = c->sweep_version;
+    c->lanes.push_back(l);
+  }
+  std::vector<int> rc(in_flight, 0);
+  std::vector<std::string> msg(in_flight);
+  auto run = [&](int k) {
+    pf_ctx* lane = k == 0 ? c : c->lanes[k - 1];
+    for (int i = k; i < n_pairs; i += in_flight) {
+      const int e = pf_novel_view_dev(lane, d_l[i], d_r[i], cols, rows, max_pct, d_blend[i], d_out[i], d_l2r ? d_l2r[i] : nullptr, d_r2l ? d_r2l[i] : nullptr);
+      if (e) { rc[k] = e; msg[k] = lane->err; return; }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int k = 1; k < in_flight; ++k) th.emplace_back(run, k);
+  run(0);
+  for (auto& t : th) t.join();
+  for (int k = 0; k < in_flight; ++k) if (rc[k]) return fail(c, rc[k], "lane %d: %s", k, msg[k].c_str());
+  return 0;
 }
 
 // ---- host-buffer entry points ----

@@ -6,6 +6,7 @@
 // RCCL is bound at run time (dlopen): single-GPU users of libpanoflow.so carry no dependency on it, and a process
 // that already loaded a copy (e.g. PyTorch's) keeps using that one.
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>
 #include <stdio.h>
 #include <string.h>
@@ -36,8 +37,16 @@ Rccl* rccl() {
   static bool tried = false;
   if (tried) return &r;
   tried = true;
+  // A process must hold ONE copy of RCCL (two copies interpose each other's globals): if one is already mapped -- e.g. the
+  // one PyTorch ships and loads for torch.distributed -- bind to exactly that file; otherwise load ROCm's.
+  std::string loaded;
+  dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* out) -> int {
+    if (info->dlpi_name && strstr(info->dlpi_name, "librccl.so")) { *static_cast<std::string*>(out) = info->dlpi_name; return 1; }
+    return 0;
+  }, &loaded);
+  if (!loaded.empty()) r.h = dlopen(loaded.c_str(), RTLD_NOW | RTLD_LOCAL);
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) { r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
+  for (const char* n : names) { if (r.h) break; r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
   if (!r.h) { r.err = std::string("cannot load RCCL: ") + dlerror(); return &r; }
 #define PF_SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.h, sym)); if (!r.field) { r.err = std::string("RCCL symbol missing: ") + sym; r.h = nullptr; return &r; }
   PF_SYM(GetUniqueId, "ncclGetUniqueId") PF_SYM(CommInitRank, "ncclCommInitRank") PF_SYM(CommDestroy, "ncclCommDestroy") PF_SYM(GroupStart, "ncclGroupStart")

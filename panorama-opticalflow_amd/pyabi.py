@@ -64,7 +64,7 @@ EXPORTS = [
     "pf_device_count", "pf_create", "pf_destroy", "pf_last_error", "pf_version", "pf_max_percentage_by_name",
     "pf_flow", "pf_flow_bidir", "pf_blend", "pf_novel_view", "pf_stitch_prepare", "pf_stitch_raw_blend", "pf_stitch_gather", "pf_stitch_step",
     "pf_dev_alloc", "pf_dev_free", "pf_upload", "pf_download", "pf_sync",
-    "pf_flow_bidir_dev", "pf_blend_dev", "pf_novel_view_dev",
+    "pf_flow_bidir_dev", "pf_blend_dev", "pf_novel_view_dev", "pf_novel_view_batch_dev",
     "pf_stage_preprocess", "pf_stage_pyr_down", "pf_stage_gradients", "pf_stage_gauss", "pf_stage_median5", "pf_stage_sweep",
     "pf_stage_diffusion", "pf_stage_upsample_cubic", "pf_stage_final", "pf_stage_adjust_initial_flow", "pf_stage_level",
     "pf_stage_blend_smooth",
@@ -250,6 +250,13 @@ class Context:
     def novel_view_dev(self, d_l, d_r, cols, rows, max_pct, d_blend, d_out, d_f0=None, d_f1=None):
         self._chk(self.l.pf_novel_view_dev(self.h, C.c_void_p(d_l), C.c_void_p(d_r), cols, rows, max_pct, C.c_void_p(d_blend), C.c_void_p(d_out),
                                            C.c_void_p(d_f0) if d_f0 else None, C.c_void_p(d_f1) if d_f1 else None))
+
+    def novel_view_batch_dev(self, d_l, d_r, cols, rows, max_pct, d_blend, d_out, d_f0=None, d_f1=None, in_flight=4):
+        """throughput mode: lists of device pointers, `in_flight` pairs side by side on this GPU"""
+        n = len(d_l)
+        arr = lambda v: (C.c_void_p * n)(*[C.c_void_p(int(x)) if x else None for x in v])
+        self._chk(self.l.pf_novel_view_batch_dev(self.h, n, arr(d_l), arr(d_r), cols, rows, max_pct, arr(d_blend), arr(d_out),
+                                                 arr(d_f0) if d_f0 else None, arr(d_f1) if d_f1 else None, in_flight))
 
     def flow_bidir_dev(self, d_l, d_r, cols, rows, max_pct, d_f0, d_f1):
         self._chk(self.l.pf_flow_bidir_dev(self.h, C.c_void_p(d_l), C.c_void_p(d_r), cols, rows, max_pct, C.c_void_p(d_f0), C.c_void_p(d_f1)))

@@ -4,6 +4,10 @@ import sys
 
 import pytest
 
+# several contexts / lanes drive 4 HIP streams each: the runtime's default of 4 hardware queues would serialise them.
+# Read by the HIP runtime at initialisation, i.e. before the first test touches the GPU.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "panorama-opticalflow_amd")
 sys.path.insert(0, ROOT)

@@ -1,0 +1,88 @@
+"""Throughput mode and its safety: several pairs in flight on one GPU must give the very
+bits a lone pair gives, every time, with every wait inside the sweep kernels bounded by wall-clock time (oversubscription
+must never surface as PF_ERR_TIMEOUT).  The former tests/gpu_soak.py script, as collected tests."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev_pair(pf, c, synth, cols, rows, seed):
+    L, R, blend = synth.make_pair_np(cols, rows, seed)
+    n = cols * rows
+    d = {"L": c.dev_alloc(n * 4), "R": c.dev_alloc(n * 4), "b": c.dev_alloc(n * 4), "o": c.dev_alloc(n * 4), "f0": c.dev_alloc(n * 8), "f1": c.dev_alloc(n * 8)}
+    c.upload(d["L"], L); c.upload(d["R"], R); c.upload(d["b"], blend)
+    return d
+
+
+def _fetch(c, d, cols, rows):
+    return (c.download(np.empty((rows, cols, 4), np.uint8), d["o"]), c.download(np.empty((rows, cols, 2), np.float32), d["f0"]),
+            c.download(np.empty((rows, cols, 2), np.float32), d["f1"]))
+
+
+def test_batch_entry_point_equals_single_calls(pf, synth):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    cols, rows, n = 1000, 1400, 6
+    c = pf.Context(0)
+    pairs = [_dev_pair(pf, c, synth, cols, rows, 100 + i) for i in range(n)]
+    ref = []
+    for d in pairs:
+        c.novel_view_dev(d["L"], d["R"], cols, rows, 20, d["b"], d["o"], d["f0"], d["f1"])
+        ref.append(_fetch(c, d, cols, rows))
+    for rep in range(3):
+        for d in pairs:   # scrub the outputs so a stale result cannot pass
+            c.upload(d["o"], np.zeros((rows, cols, 4), np.uint8))
+        c.novel_view_batch_dev([d["L"] for d in pairs], [d["R"] for d in pairs], cols, rows, 20, [d["b"] for d in pairs], [d["o"] for d in pairs],
+                               [d["f0"] for d in pairs], [d["f1"] for d in pairs], in_flight=4)
+        for d, r in zip(pairs, ref):
+            got = _fetch(c, d, cols, rows)
+            assert all(np.array_equal(a, b) for a, b in zip(got, r))
+    c.close()
+
+
+def test_two_contexts_soak_bit_identical(pf, synth):
+    """two host threads, two contexts, different sizes and algorithms, 60 solves each: every result equals the first"""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    specs = [(2000, 4000, 0, 1234), (1500, 3000, 20, 77)]
+    bad = [0, 0]; runs = [0, 0]; errs = []
+
+    def work(k):
+        try:
+            cols, rows, pct, seed = specs[k]
+            c = pf.Context(0, cols, rows)
+            d = _dev_pair(pf, c, synth, cols, rows, seed)
+            first = None
+            for _ in range(60):
+                c.novel_view_dev(d["L"], d["R"], cols, rows, pct, d["b"], d["o"], d["f0"], d["f1"])
+                got = _fetch(c, d, cols, rows)
+                h = tuple(int(a.view(np.uint8).astype(np.uint64).sum()) for a in got) + (hash(got[1].tobytes()),)
+                if first is None:
+                    first = h
+                bad[k] += h != first; runs[k] += 1
+            c.close()
+        except Exception as e:   # a PF_ERR_TIMEOUT would land here
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in (0, 1)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    assert runs == [60, 60] and bad == [0, 0]
+
+
+def test_oversubscribed_gpu_does_not_time_out(pf, synth):
+    """8 pairs in flight on one GPU (beyond what is co-resident at the large levels): slow is fine, PF_ERR_TIMEOUT is not"""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    cols, rows, n = 2000, 4000, 8
+    c = pf.Context(0)
+    d0 = _dev_pair(pf, c, synth, cols, rows, 1234)
+    outs = [(c.dev_alloc(cols * rows * 4), c.dev_alloc(cols * rows * 8), c.dev_alloc(cols * rows * 8)) for _ in range(n)]
+    c.novel_view_dev(d0["L"], d0["R"], cols, rows, 0, d0["b"], d0["o"], d0["f0"], d0["f1"])
+    ref = _fetch(c, d0, cols, rows)
+    c.novel_view_batch_dev([d0["L"]] * n, [d0["R"]] * n, cols, rows, 0, [d0["b"]] * n, [o[0] for o in outs], [o[1] for o in outs], [o[2] for o in outs], in_flight=8)
+    for o in outs:
+        got = _fetch(c, {"o": o[0], "f0": o[1], "f1": o[2]}, cols, rows)
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+    c.close()
