@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void k_spec_init(const float2* __restrict__ g0
   const float2 f = flow[idx];
   float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
   float2 o = f;
-  uint8_t c = 0;
+  const uint8_t c = 1;   // P_0 used no proposal at all: round 1 has to evaluate every updated pixel against its real neighbours, updated or not
   if (gate[idx]) {
     const float2 g = g0[idx], bl = blurred[idx];
     const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
@@ -612,7 +612,6 @@ __global__ __launch_bounds__(256) void k_spec_init(const float2* __restrict__ g0
     e.z = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
     e.w = 1.0f;
     o = d_update_px(g1, W, wm2, hm2, fW, rW, x, y, g, bl, f, e.x, e.y, e.z, false, f, false, f);
-    c = 1;   // round 1 evaluates every updated pixel
   }
   ec[idx] = e; p0[idx] = o; ch0[idx] = c;
 }
