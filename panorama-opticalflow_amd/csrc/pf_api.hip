@@ -41,7 +41,6 @@ struct pf_ctx {
   Gauss g5, g3_05, g3_1, g15;
   int prof = 0;   // 0 off, 1 every kernel family, 2 only the dominant family (the sweeps): fewer events in a timed region
   int sweep_version = 2;
-  int spec_rounds = 16;   // parallel relaxation rounds before each sequential sweep kernel (PANOFLOW_SPEC_ROUNDS; 0 = none); results do not depend on it
   int chain_cols = 0, chain_rows = 0;   // size of the stitch-chain result resident in "ch_final"
   long long last_swept_steps = 0;       // wavefront steps of one direction of the last solve (both sweeps, all levels, gated windows)
   std::vector<pf_ctx*> lanes;           // throughput mode: further stream/buffer sets on the same device (pf_novel_view_batch_dev)
@@ -160,7 +159,7 @@ int check_dims(pf_ctx* c, int cols, int rows, int pad) {
 
 // One level of one direction (PixFlow.hpp:272-340, gradients excluded: they are precomputed for all levels).
 // flow_a holds the incoming flow and receives the level's result (flow_b, blurred, tmp are scratch).
-struct LevelBufs { float *flow_a, *flow_b, *blurred, *tmp, *rec; float4* spec_ec; float2* spec_p[2]; uint8_t* spec_ch[2]; };
+struct LevelBufs { float *flow_a, *flow_b, *blurred, *tmp, *rec; };
 // box = bounding box (min x, min y, max x, max y) of the gated pixels of this level, or nullptr for "everything"
 void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, const float* a0, const float* a1, const uint8_t* gate, int w, int h, int sparse,
                const int* box, const LevelBufs& b, unsigned long long* bnd_fwd, unsigned long long* bnd_bwd, int* ctrl_fwd, int* ctrl_bwd, float** result) {
@@ -169,7 +168,6 @@ void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, cons
   sa.g0 = reinterpret_cast<const float2*>(g0); sa.g1 = reinterpret_cast<const float2*>(g1);
   sa.blurred = reinterpret_cast<const float2*>(b.blurred); sa.gate = gate; sa.W = w; sa.H = h; sa.sparse = sparse;
   if (box) { sa.ax0 = box[0]; sa.ay0 = box[1]; sa.ax1 = box[2] + 1; sa.ay1 = box[3] + 1; }   // empty (max < min): the sweeps are the identity
-  sa.spec_rounds = c->spec_rounds; sa.spec_ec = b.spec_ec; sa.spec_p[0] = b.spec_p[0]; sa.spec_p[1] = b.spec_p[1]; sa.spec_ch[0] = b.spec_ch[0]; sa.spec_ch[1] = b.spec_ch[1];
   auto sweep = [&](const SweepArgs& a) { if (c->sweep_version == 1) launch_sweep(st, a); else launch_sweep2(st, a, b.rec); };
   { PROF(c, st, "sweep"); sa.flow = reinterpret_cast<float2*>(b.flow_a); sa.boundary = bnd_fwd; sa.ctrl = ctrl_fwd; sa.forward = 1; sweep(sa); }
   { PROF(c, st, "median5"); launch_median5(st, b.flow_a, b.flow_b, w, h); }
@@ -224,11 +222,6 @@ int alloc_solve(pf_ctx* c, const Geometry& g, int ndirs, SolveBufs& b) {
     b.ratio[d] = (float*)ensure(c, nb[d][6], 256);
     b.lb[d].rec = (float*)ensure(c, nb[d][7], sweep2_rec_bytes(g.w0, g.h0));
     if (!b.lb[d].rec) return PF_ERR_NOMEM;
-    const char* ns[2][5] = {{"d0_spec_ec", "d0_spec_p0", "d0_spec_p1", "d0_spec_c0", "d0_spec_c1"}, {"d1_spec_ec", "d1_spec_p0", "d1_spec_p1", "d1_spec_c0", "d1_spec_c1"}};
-    b.lb[d].spec_ec = (float4*)ensure(c, ns[d][0], n0 * 16);
-    b.lb[d].spec_p[0] = (float2*)ensure(c, ns[d][1], n0 * 8); b.lb[d].spec_p[1] = (float2*)ensure(c, ns[d][2], n0 * 8);
-    b.lb[d].spec_ch[0] = (uint8_t*)ensure(c, ns[d][3], n0); b.lb[d].spec_ch[1] = (uint8_t*)ensure(c, ns[d][4], n0);
-    if (!b.lb[d].spec_ec || !b.lb[d].spec_p[0] || !b.lb[d].spec_p[1] || !b.lb[d].spec_ch[0] || !b.lb[d].spec_ch[1]) return PF_ERR_NOMEM;
     if (!b.lb[d].flow_a || !b.lb[d].flow_b || !b.lb[d].blurred || !b.lb[d].tmp || !b.bnd[d] || !b.ctrl[d] || !b.ratio[d]) return PF_ERR_NOMEM;
   }
   if (!ensure(c, "gate_box", size_t(kLevelTableMax) * 4 * sizeof(int)) || !ensure(c, "gate_count", 256)) return PF_ERR_NOMEM;
@@ -427,7 +420,6 @@ pf_ctx* pf_create(int device, int max_cols, int max_rows) {
   if (ok) *c->h_status = 0;
   if (!ok) { fail(nullptr, PF_ERR_DEVICE, "stream/event creation failed"); delete c; return nullptr; }
   if (const char* sv = getenv("PANOFLOW_SWEEP")) c->sweep_version = atoi(sv) == 1 ? 1 : 2;
-  if (const char* sr = getenv("PANOFLOW_SPEC_ROUNDS")) { c->spec_rounds = atoi(sr); if (c->spec_rounds < 0) c->spec_rounds = 0; if (c->spec_rounds > 256) c->spec_rounds = 256; }
   c->g5 = make_gauss(5, 0.25); c->g3_05 = make_gauss(3, 0.5); c->g3_1 = make_gauss(3, 1.0); c->g15 = make_gauss(15, 8.0);
   // Pre-sizing: every buffer a bidirectional solve / a stitch step on max_cols x max_rows needs is
   // allocated now, so that the first call does not pay ~40 hipMallocs.  0 x 0 = allocate lazily (the arena only grows).
@@ -865,10 +857,6 @@ int pf_stage_sweep(pf_ctx* c, const float* g0, const float* g1, const float* blu
   }
   float* rec = (float*)ensure(c, "sg_rec", sweep2_rec_bytes(w, h));
   if (!rec) return PF_ERR_NOMEM;
-  sa.spec_rounds = c->spec_rounds; sa.spec_ec = (float4*)ensure(c, "sg_spec_ec", n * 16);
-  sa.spec_p[0] = (float2*)ensure(c, "sg_spec_p0", n * 8); sa.spec_p[1] = (float2*)ensure(c, "sg_spec_p1", n * 8);
-  sa.spec_ch[0] = (uint8_t*)ensure(c, "sg_spec_c0", n); sa.spec_ch[1] = (uint8_t*)ensure(c, "sg_spec_c1", n);
-  if (!sa.spec_ec || !sa.spec_p[0] || !sa.spec_p[1] || !sa.spec_ch[0] || !sa.spec_ch[1]) return PF_ERR_NOMEM;
   { PROF(c, sm, "sweep"); if (c->sweep_version == 1) launch_sweep(sm, sa); else launch_sweep2(sm, sa, rec); }
   int hc[4] = {0, 0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(hc, ctrl, 16, hipMemcpyDeviceToHost, sm));
@@ -919,9 +907,6 @@ int pf_stage_level(pf_ctx* c, const float* i0, const float* i1, const float* a0,
   float* da1 = (float*)stage_up(c, "sg_d", a1, n * 4);
   float* g0 = (float*)ensure(c, "sg_e", n * 8); float* g1 = (float*)ensure(c, "sg_f", n * 8); uint8_t* gate = (uint8_t*)ensure(c, "sg_g", n);
   LevelBufs b; b.rec = (float*)ensure(c, "sg_rec", sweep2_rec_bytes(w, h)); if (!b.rec) return PF_ERR_NOMEM;
-  b.spec_ec = (float4*)ensure(c, "sg_spec_ec", n * 16); b.spec_p[0] = (float2*)ensure(c, "sg_spec_p0", n * 8); b.spec_p[1] = (float2*)ensure(c, "sg_spec_p1", n * 8);
-  b.spec_ch[0] = (uint8_t*)ensure(c, "sg_spec_c0", n); b.spec_ch[1] = (uint8_t*)ensure(c, "sg_spec_c1", n);
-  if (!b.spec_ec || !b.spec_p[0] || !b.spec_p[1] || !b.spec_ch[0] || !b.spec_ch[1]) return PF_ERR_NOMEM;
   b.flow_a = (float*)ensure(c, "sg_h", n * 8); b.flow_b = (float*)ensure(c, "sg_i", n * 8); b.blurred = (float*)ensure(c, "sg_j", n * 8); b.tmp = (float*)ensure(c, "sg_k", n * 8);
   const size_t nb = sweep_boundary_elems(w, h);
   unsigned long long* bnd = (unsigned long long*)ensure(c, "sg_l", nb * 16); int* ctrl = (int*)ensure(c, "sg_m", 16); float* rt = (float*)ensure(c, "sg_n", 256);

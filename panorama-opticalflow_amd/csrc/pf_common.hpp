@@ -110,11 +110,6 @@ struct SweepArgs {
   int W, H, forward;
   int sparse;             // few pixels gated (full-canvas inputs): use the kernel variant that skips ungated anti-diagonals
   int ax0 = 0, ay0 = 0, ax1 = 1 << 30, ay1 = 1 << 30;   // bounding box [ax0,ax1) x [ay0,ay1) of the gated pixels (default: everything); v2 sweep only
-  // speculation (v2 sweep only): relaxation rounds run before the sequential kernel, and their scratch planes (W*H each)
-  int spec_rounds = 0;
-  float4* spec_ec = nullptr;            // (E(C), E(C+dx), E(C+dy), gate) per pixel
-  float2* spec_p[2] = {nullptr, nullptr};   // ping-pong planes P_k
-  uint8_t* spec_ch[2] = {nullptr, nullptr}; // "changed in this round" flags
 };
 size_t sweep_boundary_elems(int W, int H);   // hand-off granules needed per sweep launch (covers both sweep kernels)
 void launch_sweep(hipStream_t st, const SweepArgs& a);          // v1: 64 rows per wave, kept as a cross-check (PANOFLOW_SWEEP=1)
