@@ -302,6 +302,7 @@ def main():
                 t1 = time.perf_counter()
                 for i, im in enumerate(imgs):
                     last = i == len(imgs) - 1
+                    cx.stitch_prefetch(None if last else imgs[i + 1])      # image i+1 goes up while step i computes
                     o = cx.stitch_step(im, top if i == 0 else None, 20, want_out=last)
                 return time.perf_counter() - t1, o
 

@@ -100,6 +100,11 @@ int pf_stitch_gather(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, 
 int pf_stitch_step(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, int cols, int rows, size_t step_bytes,
                    int max_percentage, uint8_t* out_bgra, size_t out_step_bytes);
 
+/* Hint: l_bgra of the NEXT pf_stitch_step call.  Its host->device upload is then issued inside the current step, after that
+ * step's kernels are enqueued, so it overlaps the compute (CPU/main.cpp:66-69 reads image i+1 only after step i).  The
+ * buffer must stay valid and unchanged until that next call; NULL cancels.  Purely an optimisation: results are identical. */
+int pf_stitch_prefetch(pf_ctx* ctx, const uint8_t* next_l_bgra, int cols, int rows, size_t step_bytes);
+
 /* ---- device-resident entry points (packed buffers already in this context's HBM) -----------
  * Same semantics as above; used by bench.py (inputs resident when the clock starts) and by the
  * multi-GPU driver.  Pointers are device pointers on the context's device. */

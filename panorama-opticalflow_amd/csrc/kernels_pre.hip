@@ -132,6 +132,14 @@ void launch_pyr_down4(hipStream_t st, const float* s0, const float* s1, const fl
   hipLaunchKernelGGL(k_pyr_down4, grid, dim3(256), 0, st, p, sw, sh, dw, dh, sx, sy);
 }
 
+// two planes per launch: the alpha pyramids and the grey pyramids are built on different streams (pf_api.hip: solve)
+void launch_pyr_down2(hipStream_t st, const float* s0, const float* s1, int sw, int sh, float* d0, float* d1, int dw, int dh) {
+  Ptr4 p{{s0, s1, s0, s1}, {d0, d1, d0, d1}};
+  const double sx = 1. / ((double)dw / sw), sy = 1. / ((double)dh / sh);
+  dim3 grid((dw + 255) / 256, dh, 2);
+  hipLaunchKernelGGL(k_pyr_down4, grid, dim3(256), 0, st, p, sw, sh, dw, dh, sx, sy);
+}
+
 __global__ void k_fill_u64(unsigned long long* p, size_t n, unsigned long long v) {
   size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t stride = size_t(gridDim.x) * blockDim.x;

@@ -34,6 +34,8 @@ struct ProfPending { int id; hipEvent_t a, b; };
 struct pf_ctx {
   int device = 0;
   hipStream_t s_main = nullptr, s_dir[2] = {nullptr, nullptr}, s_aux = nullptr;
+  hipStream_t s_gate = nullptr;                        // alpha pyramid -> gate -> bounding boxes, beside the grey path of the front end
+  hipEvent_t ev_alpha = nullptr, ev_gate = nullptr;
   hipEvent_t ev_aux_go = nullptr, ev_aux_done = nullptr;
   hipEvent_t ev_pre = nullptr, ev_dir[2] = {nullptr, nullptr};
   std::string err;
@@ -43,6 +45,9 @@ struct pf_ctx {
   int sweep_version = 2;
   int chain_cols = 0, chain_rows = 0;   // size of the stitch-chain result resident in "ch_final"
   long long last_swept_steps = 0;       // wavefront steps of one direction of the last solve (both sweeps, all levels, gated windows)
+  const uint8_t* prefetch_src = nullptr; int prefetch_cols = 0, prefetch_rows = 0; size_t prefetch_step = 0;   // pf_stitch_prefetch: next step's left image
+  bool prefetched = false;              // ... and whether it already sits in "ch_l_next"
+  hipStream_t s_copy = nullptr;         // uploads that overlap compute
   std::vector<pf_ctx*> lanes;           // throughput mode: further stream/buffer sets on the same device (pf_novel_view_batch_dev)
   int* h_status = nullptr;              // mapped pinned host word: bit d set = a sweep band of direction d timed out
   int* d_status = nullptr;              // the same word as the device sees it
@@ -243,32 +248,37 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   LevelBufs* lb = sb.lb; unsigned long long** bnd = sb.bnd; int** ctrl = sb.ctrl; float** ratio = sb.ratio;
   *c->h_status = 0;
   hipStream_t sm = c->s_main;
-  // --- shared front end on the main stream: half-res planes, pyramids, gradients + gate of ALL levels ---
+  // --- shared front end: half-res planes, pyramids, gradients + gate of ALL levels.  Two chains side by side:
+  //   s_main: grey path  (downscale, pre-blur, grey pyramids, gradients of all levels, hand-off init)
+  //   s_gate: alpha path (alpha pyramids, gate of all levels, bounding box of the gate per level, level-0 gate count)
+  // The host needs the boxes (they size the sweep launches) and the count (dense / sparse sweep variant): it waits for
+  // s_gate only, i.e. the sync and the enqueueing of the directions overlap the grey path still running on s_main. ---
   const uint8_t* imgs[2] = {d_img0, d_img1};
+  hipStream_t sg = c->s_gate;
   for (int i = 0; i < 2; ++i) {
     { PROF(c, sm, "downscale_gray"); launch_downscale_gray(sm, imgs[i], cols, rows, pad, half_tmp, pyrA[i], g.w0, g.h0); }
+    if (i == 1) HIPCHK(c, hipEventRecord(c->ev_alpha, sm));   // both alpha planes of level 0 exist
     { PROF(c, sm, "preblur5"); launch_gauss_small(sm, half_tmp, pyrI[i], g.w0, g.h0, 1, c->g5); }
   }
+  HIPCHK(c, hipStreamWaitEvent(sg, c->ev_alpha, 0));
   for (int l = 1; l < g.n; ++l) {
-    PROF(c, sm, "pyr_down");
-    launch_pyr_down4(sm, pyrI[0] + g.off[l - 1], pyrI[1] + g.off[l - 1], pyrA[0] + g.off[l - 1], pyrA[1] + g.off[l - 1], g.ws[l - 1], g.hs[l - 1],
-                     pyrI[0] + g.off[l], pyrI[1] + g.off[l], pyrA[0] + g.off[l], pyrA[1] + g.off[l], g.ws[l], g.hs[l]);
+    { PROF(c, sm, "pyr_down"); launch_pyr_down2(sm, pyrI[0] + g.off[l - 1], pyrI[1] + g.off[l - 1], g.ws[l - 1], g.hs[l - 1], pyrI[0] + g.off[l], pyrI[1] + g.off[l], g.ws[l], g.hs[l]); }
+    { PROF(c, sg, "pyr_down"); launch_pyr_down2(sg, pyrA[0] + g.off[l - 1], pyrA[1] + g.off[l - 1], g.ws[l - 1], g.hs[l - 1], pyrA[0] + g.off[l], pyrA[1] + g.off[l], g.ws[l], g.hs[l]); }
   }
   bool have_table = false; LevelTable table;
   if (g.n <= kLevelTableMax && g.P < (size_t(1) << 31)) {
     // gradients and gates of all levels in two launches (the level planes are contiguous; padding between them is skipped / harmless)
-    PROF(c, sm, "gradients");
     LevelTable t; t.n = g.n;
     for (int l = 0; l < g.n; ++l) { t.w[l] = g.ws[l]; t.h[l] = g.hs[l]; t.off[l] = (unsigned)g.off[l]; }
-    launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], t, g.P, c->g3_05);
-    launch_gate(sm, pyrA[0], pyrA[1], (int)g.P, gate);
+    { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], t, g.P, c->g3_05); }
+    { PROF(c, sg, "gate"); launch_gate(sg, pyrA[0], pyrA[1], (int)g.P, gate); }
     have_table = true; table = t;
   } else {
     for (int l = 0; l < g.n; ++l) {
       PROF(c, sm, "gradients");
       launch_gradients(sm, pyrI[0] + g.off[l], g.ws[l], g.hs[l], grad[0] + 2 * g.off[l], c->g3_05);
       launch_gradients(sm, pyrI[1] + g.off[l], g.ws[l], g.hs[l], grad[1] + 2 * g.off[l], c->g3_05);
-      launch_gate(sm, pyrA[0] + g.off[l], pyrA[1] + g.off[l], g.ws[l] * g.hs[l], gate + g.off[l]);
+      launch_gate(sg, pyrA[0] + g.off[l], pyrA[1] + g.off[l], g.ws[l] * g.hs[l], gate + g.off[l]);
     }
   }
   for (int d = 0; d < ndirs; ++d) {
@@ -276,25 +286,24 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
     launch_fill_u64(sm, bnd[d], bnd_total * 2, kNotReady);
     HIPCHK(c, hipMemsetAsync(ctrl[d], 0, size_t(g.n) * 2 * 2 * sizeof(int), sm));
   }
+  HIPCHK(c, hipEventRecord(c->ev_pre, sm));
   // One host decision per pair: are the inputs sparse (full-canvas images whose overlap is a small part,
-  // CPU/StitchTool.cpp:17-33)?  Then the sweep variant that skips ungated anti-diagonals is used.  Costs one
-  // stream sync (the level-0 gate count) before the directions are launched; results are identical either way.
+  // CPU/StitchTool.cpp:17-33)?  Then the sweep variant that skips ungated anti-diagonals is used (results are identical
+  // either way).  In the same sync: the bounding box of the gated pixels of every level -- the sweeps only cover that
+  // window (everything outside keeps its flow, PixFlow.hpp:317), which removes the wavefront skew of the no-data borders.
   unsigned* d_cnt = (unsigned*)ensure(c, "gate_count", 256);
   if (!d_cnt) return PF_ERR_NOMEM;
-  HIPCHK(c, hipMemsetAsync(d_cnt, 0, 4, sm));
-  launch_count_gate(sm, gate, g.ws[0] * g.hs[0], d_cnt);
+  HIPCHK(c, hipMemsetAsync(d_cnt, 0, 4, sg));
+  launch_count_gate(sg, gate, g.ws[0] * g.hs[0], d_cnt);
   unsigned h_cnt = 0;
-  HIPCHK(c, hipMemcpyAsync(&h_cnt, d_cnt, 4, hipMemcpyDeviceToHost, sm));
-  // ... and, in the same sync, the bounding box of the gated pixels of every level: the sweeps only cover that window
-  // (everything outside keeps its flow, PixFlow.hpp:317), which removes the wavefront skew of the no-data borders.
+  HIPCHK(c, hipMemcpyAsync(&h_cnt, d_cnt, 4, hipMemcpyDeviceToHost, sg));
   std::vector<int> boxes;
-  if (have_table && !getenv("PANOFLOW_NO_WINDOW")) { if (int e = gate_boxes_to_host(c, sm, gate, table, g.P, boxes)) return e; }
-  else HIPCHK(c, hipStreamSynchronize(sm));
+  if (have_table && !getenv("PANOFLOW_NO_WINDOW")) { if (int e = gate_boxes_to_host(c, sg, gate, table, g.P, boxes)) return e; }
+  else HIPCHK(c, hipStreamSynchronize(sg));
   double area0 = (double)g.ws[0] * g.hs[0];   // the sweeps only cover the window of gated pixels: density inside that window is what counts
   if (!boxes.empty() && boxes[2] >= boxes[0] && boxes[3] >= boxes[1]) area0 = double(boxes[2] - boxes[0] + 1) * double(boxes[3] - boxes[1] + 1);
   int sparse = (double)h_cnt < 0.5 * area0 ? 1 : 0;
   if (const char* e = getenv("PANOFLOW_SPARSE")) sparse = atoi(e) ? 1 : 0;   // experiment switch: results are identical either way
-  HIPCHK(c, hipEventRecord(c->ev_pre, sm));
   // critical path of the exact sweeps given the windows: (w + h - 1) anti-diagonals per sweep, two sweeps per level
   c->last_swept_steps = 0;
   for (int l = 0; l < g.n; ++l) {
@@ -356,6 +365,7 @@ int finish(pf_ctx* c) {
   HIPCHK(c, hipStreamSynchronize(c->s_dir[0]));
   HIPCHK(c, hipStreamSynchronize(c->s_dir[1]));
   HIPCHK(c, hipStreamSynchronize(c->s_aux));
+  HIPCHK(c, hipStreamSynchronize(c->s_gate));
   if (c->prof) prof_collect(c);
   return 0;
 }
@@ -369,6 +379,7 @@ struct CallGuard {
   ~CallGuard() {
     if (!c) return;
     hipStreamSynchronize(c->s_main); hipStreamSynchronize(c->s_dir[0]); hipStreamSynchronize(c->s_dir[1]); hipStreamSynchronize(c->s_aux);
+    hipStreamSynchronize(c->s_gate); hipStreamSynchronize(c->s_copy);
   }
 };
 
@@ -413,6 +424,9 @@ pf_ctx* pf_create(int device, int max_cols, int max_rows) {
   bool ok = hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking) == hipSuccess;
   for (int d = 0; d < 2 && ok; ++d) ok = hipStreamCreateWithFlags(&c->s_dir[d], hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&c->s_aux, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&c->s_gate, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_alpha, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_aux_go, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) == hipSuccess;
   for (int d = 0; d < 2 && ok; ++d) ok = hipEventCreateWithFlags(&c->ev_dir[d], hipEventDisableTiming) == hipSuccess;
@@ -452,6 +466,10 @@ void pf_destroy(pf_ctx* c) {
   if (c->ev_aux_go) hipEventDestroy(c->ev_aux_go);
   if (c->ev_aux_done) hipEventDestroy(c->ev_aux_done);
   if (c->s_aux) hipStreamDestroy(c->s_aux);
+  if (c->ev_alpha) hipEventDestroy(c->ev_alpha);
+  if (c->ev_gate) hipEventDestroy(c->ev_gate);
+  if (c->s_gate) hipStreamDestroy(c->s_gate);
+  if (c->s_copy) hipStreamDestroy(c->s_copy);
   if (c->s_main) hipStreamDestroy(c->s_main);
   if (c->h_status) hipHostFree(c->h_status);
   delete c;
@@ -752,7 +770,15 @@ int pf_stitch_step(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int 
   float* f0 = (float*)ensure(c, "nv_flow_l2r", n * 8); float* f1 = (float*)ensure(c, "nv_flow_r2l", n * 8);
   if (!dl || !dr || !dfin || !dm || !dol || !dor || !db || !dmd || !dmerged || !f0 || !f1) return PF_ERR_NOMEM;
   hipStream_t sm = c->s_main;
-  if (int e = up2d(c, dl, size_t(cols) * 4, l, step, size_t(cols) * 4, rows)) return e;
+  uint8_t* dnext = (uint8_t*)ensure(c, "ch_l_next", n * 4);
+  if (!dnext) return PF_ERR_NOMEM;
+  if (c->prefetched && c->prefetch_src == l && c->prefetch_cols == cols && c->prefetch_rows == rows && c->prefetch_step == step) {
+    // this step's left image was uploaded while the previous step computed (pf_stitch_prefetch)
+    HIPCHK(c, hipMemcpyAsync(dl, dnext, n * 4, hipMemcpyDeviceToDevice, sm));
+  } else {
+    if (int e = up2d(c, dl, size_t(cols) * 4, l, step, size_t(cols) * 4, rows)) return e;
+  }
+  c->prefetched = false;
   if (r) { if (int e = up2d(c, dr, size_t(cols) * 4, r, step, size_t(cols) * 4, rows)) return e; }
   else {
     if (c->chain_cols != cols || c->chain_rows != rows) return fail(c, PF_ERR_ARG, "pf_stitch_step: no previous result of this size to chain on");
@@ -774,10 +800,27 @@ int pf_stitch_step(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int 
   { PROF(c, sm, "blend"); launch_blend(sm, dol, dor, f0, f1, db, cols, rows, dmerged); }
   { PROF(c, sm, "gather"); launch_gather(sm, dl, dr, dmerged, dm, cols, rows, dfin); }
   if (out) if (int e = down2d(c, out, ostep, dfin, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
+  // everything of this step is enqueued: upload the NEXT step's left image now (announced with pf_stitch_prefetch); the
+  // host-side staging of a pageable source runs while the GPU computes
+  if (c->prefetch_src && c->prefetch_src != l && c->prefetch_cols == cols && c->prefetch_rows == rows) {
+    HIPCHK(c, hipMemcpy2DAsync(dnext, size_t(cols) * 4, c->prefetch_src, c->prefetch_step, size_t(cols) * 4, rows, hipMemcpyHostToDevice, c->s_copy));
+    HIPCHK(c, hipStreamSynchronize(c->s_copy));
+    c->prefetched = true;
+  }
   HIPCHK(c, hipGetLastError());
   if (int e = finish(c)) return e;
   c->chain_cols = cols; c->chain_rows = rows;
   return check_sweeps(c, cols, rows, pad, 2);
+}
+
+// Announce the left image of the NEXT pf_stitch_step call: its upload then overlaps the current step's compute (the copy is
+// issued inside the current step after its kernels are enqueued).  The buffer must stay valid and unchanged until that
+// next call, which must pass the same pointer / size / step; anything else simply uploads as usual.  NULL cancels.
+int pf_stitch_prefetch(pf_ctx* c, const uint8_t* next_l, int cols, int rows, size_t step) {
+  if (!c) return fail(nullptr, PF_ERR_ARG, "null context");
+  if (next_l && (cols <= 0 || rows <= 0 || step < size_t(cols) * 4)) return fail(c, PF_ERR_ARG, "bad argument");
+  c->prefetch_src = next_l; c->prefetch_cols = cols; c->prefetch_rows = rows; c->prefetch_step = step; c->prefetched = false;
+  return 0;
 }
 
 // ---- stage-level entry points (tests) ----

@@ -62,7 +62,7 @@ def lib():
 
 EXPORTS = [
     "pf_device_count", "pf_create", "pf_destroy", "pf_last_error", "pf_version", "pf_max_percentage_by_name",
-    "pf_flow", "pf_flow_bidir", "pf_blend", "pf_novel_view", "pf_stitch_prepare", "pf_stitch_raw_blend", "pf_stitch_gather", "pf_stitch_step",
+    "pf_flow", "pf_flow_bidir", "pf_blend", "pf_novel_view", "pf_stitch_prepare", "pf_stitch_raw_blend", "pf_stitch_gather", "pf_stitch_step", "pf_stitch_prefetch",
     "pf_dev_alloc", "pf_dev_free", "pf_upload", "pf_download", "pf_sync",
     "pf_flow_bidir_dev", "pf_blend_dev", "pf_novel_view_dev", "pf_novel_view_batch_dev",
     "pf_stage_preprocess", "pf_stage_pyr_down", "pf_stage_gradients", "pf_stage_gauss", "pf_stage_median5", "pf_stage_sweep",
@@ -220,6 +220,15 @@ class Context:
         self._chk(self.l.pf_stitch_gather(self.h, _p(a), _p(_u8(R)), _p(_u8(merged)), C.c_size_t(cols * 4), _p(_u8(mp)), C.c_size_t(cols), cols, rows,
                                           _p(out), C.c_size_t(cols * 4)))
         return out
+
+    def stitch_prefetch(self, next_L):
+        """announce the NEXT stitch_step's left image (must be a contiguous uint8 array kept alive and unchanged until then)"""
+        if next_L is None:
+            self._chk(self.l.pf_stitch_prefetch(self.h, None, 0, 0, C.c_size_t(0)))
+            return
+        assert next_L.dtype == np.uint8 and next_L.flags["C_CONTIGUOUS"]
+        rows, cols, _ = next_L.shape
+        self._chk(self.l.pf_stitch_prefetch(self.h, _p(next_L), cols, rows, C.c_size_t(cols * 4)))
 
     def stitch_step(self, L, R, max_pct, want_out=True):
         """One iteration of main.cpp's loop on the device; R=None chains on the previous result kept in HBM."""

@@ -199,3 +199,27 @@ def test_flow_bidir_fuzz_alpha_shapes(ctx, orc, synth):
         g0, g1 = ctx.flow_bidir(L, R, max_pct)
         assert np.array_equal(g0.view(np.uint32), r0.view(np.uint32)) and np.array_equal(g1.view(np.uint32), r1.view(np.uint32)), \
             "case %d (%dx%d, max_pct %d): %d / %d mismatches" % (case, cols, rows, max_pct, (g0 != r0).sum(), (g1 != r1).sum())
+
+
+def test_stitch_prefetch_is_result_neutral(ctx, synth):
+    """pf_stitch_prefetch only moves the next image's upload under the current step's compute: same composites, also when
+    the announced buffer is then NOT the one passed (the hint is ignored)."""
+    cols, rows = 480, 320
+    top, imgs = synth.make_stitch_set(cols, rows, 12, 4)
+    top = top.numpy(); imgs = [np.ascontiguousarray(im.numpy()) for im in imgs]
+
+    def chain(mode):
+        outs = []
+        for i, im in enumerate(imgs):
+            if mode == "prefetch":
+                ctx.stitch_prefetch(imgs[i + 1] if i + 1 < len(imgs) else None)
+            elif mode == "wrong":
+                ctx.stitch_prefetch(imgs[0])        # never the next image (except by accident at i = -1)
+            outs.append(ctx.stitch_step(im, top if i == 0 else None, 20, want_out=True))
+        ctx.stitch_prefetch(None)
+        return outs
+
+    ref = chain("plain")
+    for mode in ("prefetch", "wrong"):
+        got = chain(mode)
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref)), mode
