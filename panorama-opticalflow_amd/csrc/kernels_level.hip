@@ -116,6 +116,83 @@ void launch_gate_bbox(hipStream_t st, const uint8_t* gate, const LevelTable& t, 
   hipLaunchKernelGGL(k_gate_bbox, dim3((unsigned)((total + 16383) / 16384)), dim3(256), 0, st, gate, t, (unsigned)total, box);
 }
 
+// Gate + bounding boxes + level-0 count of ALL levels in ONE launch, published straight into mapped pinned host memory:
+//   gate[i] = alpha0 > 0.9 && alpha1 > 0.9 (PixFlow.hpp:317,330); work[4*l..] = bounding box of level l's gated pixels,
+//   work[4*kLevelTableMax] = number of gated pixels of level 0, work[4*kLevelTableMax + 1] = blocks finished.
+// The last block to finish copies boxes + count to `host` (system-scope stores), stores the call's epoch behind them as the
+// "ready" flag, and resets the work area for the next call -- the host polls that flag instead of synchronising the stream
+// (no pageable copies, no blocking wait: the round trip costs microseconds).
+__global__ __launch_bounds__(256) void k_gate_bbox_all(const float* __restrict__ a0, const float* __restrict__ a1, uint8_t* __restrict__ gate, LevelTable t,
+                                                       unsigned total, int* __restrict__ work, int* __restrict__ host, int epoch) {
+  __shared__ int sbox[4];
+  __shared__ int scnt, slast;
+  constexpr unsigned kPer = 4096;
+  const unsigned base = blockIdx.x * kPer;
+  if (threadIdx.x == 0) scnt = 0;
+  int lvl = -1, w = 1, mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -1, mxy = -1, cnt0 = 0;
+  unsigned off = 0, cnt = 0;
+  auto flush = [&]() {   // block-level reduction of one level's partial box, then the atomics
+    if (threadIdx.x < 4) sbox[threadIdx.x] = (threadIdx.x < 2) ? 0x7fffffff : -1;
+    for (int o = 32; o > 0; o >>= 1) {   // wave-level reduction first: four LDS atomics per wave, not per thread
+      mnx = min(mnx, __shfl_xor(mnx, o)); mny = min(mny, __shfl_xor(mny, o)); mxx = max(mxx, __shfl_xor(mxx, o)); mxy = max(mxy, __shfl_xor(mxy, o));
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && mxx >= 0) { atomicMin(&sbox[0], mnx); atomicMin(&sbox[1], mny); atomicMax(&sbox[2], mxx); atomicMax(&sbox[3], mxy); }
+    __syncthreads();
+    if (threadIdx.x == 0 && sbox[2] >= 0) {
+      atomicMin(&work[4 * lvl + 0], sbox[0]); atomicMin(&work[4 * lvl + 1], sbox[1]);
+      atomicMax(&work[4 * lvl + 2], sbox[2]); atomicMax(&work[4 * lvl + 3], sbox[3]);
+    }
+    __syncthreads();
+    mnx = 0x7fffffff; mny = 0x7fffffff; mxx = -1; mxy = -1;
+  };
+  int l0 = 0, hi = t.n - 1;
+  while (l0 < hi) { const int mid = (l0 + hi + 1) >> 1; if (base >= t.off[mid]) l0 = mid; else hi = mid - 1; }
+  const unsigned end = (base + kPer < total) ? base + kPer : total;
+  for (int l = l0; l < t.n && t.off[l] < end; ++l) {
+    lvl = l; w = t.w[l]; off = t.off[l]; cnt = unsigned(t.w[l]) * unsigned(t.h[l]);
+    const unsigned lo = off > base ? off : base, hiE = (off + cnt < end) ? off + cnt : end;
+    for (unsigned i = lo + threadIdx.x; i < hiE; i += 256) {
+      const bool gt = a0[i] > kUpdateAlphaThreshold && a1[i] > kUpdateAlphaThreshold;
+      gate[i] = gt ? 1 : 0;
+      if (gt) {
+        const unsigned local = i - off;
+        const int y = int(local / unsigned(w)), x = int(local - unsigned(y) * unsigned(w));
+        mnx = min(mnx, x); mny = min(mny, y); mxx = max(mxx, x); mxy = max(mxy, y);
+        if (l == 0) ++cnt0;
+      }
+    }
+    flush();
+  }
+  // padding between levels: keep the gate defined (0) there
+  for (int o = 32; o > 0; o >>= 1) cnt0 += __shfl_down(cnt0, o);
+  if ((threadIdx.x & 63) == 0 && cnt0) atomicAdd(&scnt, cnt0);
+  __syncthreads();
+  constexpr int kCnt = 4 * kLevelTableMax, kDone = kCnt + 1;
+  if (threadIdx.x == 0) {
+    if (scnt) atomicAdd(&work[kCnt], scnt);
+    __threadfence();
+    slast = (atomicAdd(&work[kDone], 1) == int(gridDim.x) - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!slast) return;
+  __threadfence();
+  for (int i = threadIdx.x; i <= kCnt; i += 256) {
+    const int v = __hip_atomic_load(&work[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&host[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    work[i] = (i == kCnt) ? 0 : (((i & 3) < 2) ? 0x7fffffff : -1);   // reset for the next call
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    work[kDone] = 0;
+    __atomic_thread_fence(__ATOMIC_RELEASE);   // the boxes are visible to the host before the flag
+    __hip_atomic_store(&host[kDone], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+void launch_gate_bbox_all(hipStream_t st, const float* a0, const float* a1, uint8_t* gate, const LevelTable& t, size_t total, int* work, int* host_mapped, int epoch) {
+  hipLaunchKernelGGL(k_gate_bbox_all, dim3((unsigned)((total + 4095) / 4096)), dim3(256), 0, st, a0, a1, gate, t, (unsigned)total, work, host_mapped, epoch);
+}
+
 __global__ __launch_bounds__(256) void k_count_gate(const uint8_t* __restrict__ gate, int n, unsigned* __restrict__ count) {
   int c = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c += gate[i];

@@ -7,7 +7,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -48,13 +50,16 @@ struct pf_ctx {
   const uint8_t* prefetch_src = nullptr; int prefetch_cols = 0, prefetch_rows = 0; size_t prefetch_step = 0;   // pf_stitch_prefetch: next step's left image
   bool prefetched = false;              // ... and whether it already sits in "ch_l_next"
   hipStream_t s_copy = nullptr;         // uploads that overlap compute
+  bool drained = true;                  // false between "work enqueued" and finish(): what CallGuard looks at
   std::vector<pf_ctx*> lanes;           // throughput mode: further stream/buffer sets on the same device (pf_novel_view_batch_dev)
+  int* h_gate = nullptr; int* d_gate = nullptr; int gate_epoch = 0;   // mapped pinned: per-level gate boxes + count + epoch flag (k_gate_bbox_all)
   int* h_status = nullptr;              // mapped pinned host word: bit d set = a sweep band of direction d timed out
   int* d_status = nullptr;              // the same word as the device sees it
   std::vector<std::string> prof_names;
   std::vector<ProfEntry> prof_tot;
   std::vector<ProfPending> prof_pending;
   std::vector<hipEvent_t> ev_pool;
+  std::mutex prof_mu;   // the two directions may be enqueued from two host threads
 };
 
 namespace {
@@ -108,10 +113,10 @@ struct ProfScope {
   pf_ctx* c; hipStream_t st; ProfPending p; bool on;
   ProfScope(pf_ctx* c_, hipStream_t st_, const char* name) : c(c_), st(st_), on(c_->prof == 1 || (c_->prof == 2 && strncmp(name, "sweep", 5) == 0)) {
     if (!on) return;
-    p.id = prof_id(c, name); p.a = prof_event(c); p.b = prof_event(c);
+    { std::lock_guard<std::mutex> lk(c->prof_mu); p.id = prof_id(c, name); p.a = prof_event(c); p.b = prof_event(c); }
     hipEventRecord(p.a, st);
   }
-  ~ProfScope() { if (on) { hipEventRecord(p.b, st); c->prof_pending.push_back(p); } }
+  ~ProfScope() { if (on) { hipEventRecord(p.b, st); std::lock_guard<std::mutex> lk(c->prof_mu); c->prof_pending.push_back(p); } }
 };
 void prof_collect(pf_ctx* c) {
   for (auto& p : c->prof_pending) {
@@ -233,6 +238,34 @@ int alloc_solve(pf_ctx* c, const Geometry& g, int ndirs, SolveBufs& b) {
   return 0;
 }
 
+// device work area of k_gate_bbox_all (self-resetting: initialised once)
+int* gate_work(pf_ctx* c) {
+  const bool fresh = c->bufs.find("gate_work") == c->bufs.end() || !c->bufs["gate_work"].p;
+  int* w = (int*)ensure(c, "gate_work", (4 * kLevelTableMax + 2) * sizeof(int));
+  if (w && fresh) {
+    std::vector<int> init(4 * kLevelTableMax + 2, 0);
+    for (int l = 0; l < kLevelTableMax; ++l) { init[4 * l] = 0x7fffffff; init[4 * l + 1] = 0x7fffffff; init[4 * l + 2] = -1; init[4 * l + 3] = -1; }
+    if (hipMemcpy(w, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  }
+  return w;
+}
+// Host side of k_gate_bbox_all: poll the epoch flag in mapped pinned memory (microseconds) instead of synchronising the
+// stream; boxes (4 ints per level) and the level-0 count are then already in host memory.
+int wait_gate_boxes(pf_ctx* c, hipStream_t st, int epoch, int nlevels, std::vector<int>& box, unsigned& count0) {
+  volatile int* flag = c->h_gate + 4 * kLevelTableMax + 1;
+  const auto t0 = std::chrono::steady_clock::now();
+  long spins = 0;
+  while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != epoch) {
+    if ((++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
+      HIPCHK(c, hipStreamSynchronize(st));   // surfaces a launch failure, if that is what happened
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != epoch) return fail(c, PF_ERR_DEVICE, "gate bounding boxes never arrived");
+    }
+  }
+  box.assign(c->h_gate, c->h_gate + size_t(nlevels) * 4);
+  count0 = (unsigned)c->h_gate[4 * kLevelTableMax];
+  return 0;
+}
+
 // The whole solver for 1 or 2 directions on device-resident packed BGRA images.
 // dir 0: I0 = img0, I1 = img1, hint0;  dir 1: I0 = img1, I1 = img0, hint1.  out[d]: cols x rows float2 (pad cropped).
 int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int rows, int pad, int max_pct, int ndirs, const int* hints,
@@ -248,30 +281,38 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   LevelBufs* lb = sb.lb; unsigned long long** bnd = sb.bnd; int** ctrl = sb.ctrl; float** ratio = sb.ratio;
   *c->h_status = 0;
   hipStream_t sm = c->s_main;
-  // --- shared front end: half-res planes, pyramids, gradients + gate of ALL levels.  Two chains side by side:
-  //   s_main: grey path  (downscale, pre-blur, grey pyramids, gradients of all levels, hand-off init)
-  //   s_gate: alpha path (alpha pyramids, gate of all levels, bounding box of the gate per level, level-0 gate count)
-  // The host needs the boxes (they size the sweep launches) and the count (dense / sparse sweep variant): it waits for
-  // s_gate only, i.e. the sync and the enqueueing of the directions overlap the grey path still running on s_main. ---
+  // --- shared front end on the main stream: half-res planes, pyramids, gradients + gate of ALL levels.
+  // (Measured and rejected: the alpha path on a second stream -- alpha pyramids, gate, boxes beside the grey path.  The
+  // front end is bound by the HOST enqueueing its ~45 small launches, not by the GPU, so doubling the pyramid launches
+  // cost +0.3 ms per pair; profiles/r02_frontend_ab.txt.) ---
   const uint8_t* imgs[2] = {d_img0, d_img1};
-  hipStream_t sg = c->s_gate;
+  hipStream_t sg = sm;
   for (int i = 0; i < 2; ++i) {
     { PROF(c, sm, "downscale_gray"); launch_downscale_gray(sm, imgs[i], cols, rows, pad, half_tmp, pyrA[i], g.w0, g.h0); }
-    if (i == 1) HIPCHK(c, hipEventRecord(c->ev_alpha, sm));   // both alpha planes of level 0 exist
     { PROF(c, sm, "preblur5"); launch_gauss_small(sm, half_tmp, pyrI[i], g.w0, g.h0, 1, c->g5); }
   }
-  HIPCHK(c, hipStreamWaitEvent(sg, c->ev_alpha, 0));
   for (int l = 1; l < g.n; ++l) {
-    { PROF(c, sm, "pyr_down"); launch_pyr_down2(sm, pyrI[0] + g.off[l - 1], pyrI[1] + g.off[l - 1], g.ws[l - 1], g.hs[l - 1], pyrI[0] + g.off[l], pyrI[1] + g.off[l], g.ws[l], g.hs[l]); }
-    { PROF(c, sg, "pyr_down"); launch_pyr_down2(sg, pyrA[0] + g.off[l - 1], pyrA[1] + g.off[l - 1], g.ws[l - 1], g.hs[l - 1], pyrA[0] + g.off[l], pyrA[1] + g.off[l], g.ws[l], g.hs[l]); }
+    PROF(c, sm, "pyr_down");
+    launch_pyr_down4(sm, pyrI[0] + g.off[l - 1], pyrI[1] + g.off[l - 1], pyrA[0] + g.off[l - 1], pyrA[1] + g.off[l - 1], g.ws[l - 1], g.hs[l - 1],
+                     pyrI[0] + g.off[l], pyrI[1] + g.off[l], pyrA[0] + g.off[l], pyrA[1] + g.off[l], g.ws[l], g.hs[l]);
   }
+  // The host needs the per-level bounding boxes of the gate (they size the sweep launches) and the level-0 gate count (dense
+  // or sparse sweep variant; full-canvas inputs, CPU/StitchTool.cpp:17-33): one fused kernel computes gate, boxes and count
+  // and publishes them into mapped pinned memory; the host polls its epoch flag (microseconds, no blocking sync, no pageable
+  // copies) while the gradients of all levels and the hand-off initialisation are still running behind it.
   bool have_table = false; LevelTable table;
+  unsigned h_cnt = 0;
+  std::vector<int> boxes;
+  int epoch = 0;
   if (g.n <= kLevelTableMax && g.P < (size_t(1) << 31)) {
-    // gradients and gates of all levels in two launches (the level planes are contiguous; padding between them is skipped / harmless)
     LevelTable t; t.n = g.n;
     for (int l = 0; l < g.n; ++l) { t.w[l] = g.ws[l]; t.h[l] = g.hs[l]; t.off[l] = (unsigned)g.off[l]; }
+    int* work = gate_work(c);
+    if (!work) return PF_ERR_NOMEM;
+    epoch = ++c->gate_epoch;
+    { PROF(c, sg, "gate"); launch_gate_bbox_all(sg, pyrA[0], pyrA[1], gate, t, g.P, work, c->d_gate, epoch); }
+    // gradients of all levels in one launch (the level planes are contiguous; padding between them is skipped / harmless)
     { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], t, g.P, c->g3_05); }
-    { PROF(c, sg, "gate"); launch_gate(sg, pyrA[0], pyrA[1], (int)g.P, gate); }
     have_table = true; table = t;
   } else {
     for (int l = 0; l < g.n; ++l) {
@@ -287,19 +328,17 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
     HIPCHK(c, hipMemsetAsync(ctrl[d], 0, size_t(g.n) * 2 * 2 * sizeof(int), sm));
   }
   HIPCHK(c, hipEventRecord(c->ev_pre, sm));
-  // One host decision per pair: are the inputs sparse (full-canvas images whose overlap is a small part,
-  // CPU/StitchTool.cpp:17-33)?  Then the sweep variant that skips ungated anti-diagonals is used (results are identical
-  // either way).  In the same sync: the bounding box of the gated pixels of every level -- the sweeps only cover that
-  // window (everything outside keeps its flow, PixFlow.hpp:317), which removes the wavefront skew of the no-data borders.
-  unsigned* d_cnt = (unsigned*)ensure(c, "gate_count", 256);
-  if (!d_cnt) return PF_ERR_NOMEM;
-  HIPCHK(c, hipMemsetAsync(d_cnt, 0, 4, sg));
-  launch_count_gate(sg, gate, g.ws[0] * g.hs[0], d_cnt);
-  unsigned h_cnt = 0;
-  HIPCHK(c, hipMemcpyAsync(&h_cnt, d_cnt, 4, hipMemcpyDeviceToHost, sg));
-  std::vector<int> boxes;
-  if (have_table && !getenv("PANOFLOW_NO_WINDOW")) { if (int e = gate_boxes_to_host(c, sg, gate, table, g.P, boxes)) return e; }
-  else HIPCHK(c, hipStreamSynchronize(sg));
+  if (have_table) {
+    if (int e = wait_gate_boxes(c, sg, epoch, g.n, boxes, h_cnt)) return e;
+    if (getenv("PANOFLOW_NO_WINDOW")) boxes.clear();
+  } else {
+    unsigned* d_cnt = (unsigned*)ensure(c, "gate_count", 256);
+    if (!d_cnt) return PF_ERR_NOMEM;
+    HIPCHK(c, hipMemsetAsync(d_cnt, 0, 4, sg));
+    launch_count_gate(sg, gate, g.ws[0] * g.hs[0], d_cnt);
+    HIPCHK(c, hipMemcpyAsync(&h_cnt, d_cnt, 4, hipMemcpyDeviceToHost, sg));
+    HIPCHK(c, hipStreamSynchronize(sg));
+  }
   double area0 = (double)g.ws[0] * g.hs[0];   // the sweeps only cover the window of gated pixels: density inside that window is what counts
   if (!boxes.empty() && boxes[2] >= boxes[0] && boxes[3] >= boxes[1]) area0 = double(boxes[2] - boxes[0] + 1) * double(boxes[3] - boxes[1] + 1);
   int sparse = (double)h_cnt < 0.5 * area0 ? 1 : 0;
@@ -316,33 +355,34 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   // level in turn (a direction's ~430 launches take the host >1 ms: enqueued one after the other, the second
   // direction's stream would sit idle that long) ---
   for (int d = 0; d < ndirs; ++d) HIPCHK(c, hipStreamWaitEvent(c->s_dir[d], c->ev_pre, 0));
-  for (int level = g.n - 1; level >= 0; --level) {
+  auto enqueue_level = [&](int d, int level) {
+    hipStream_t st = c->s_dir[d];
+    const int i0 = d, i1 = 1 - d;
+    LevelBufs& b = lb[d];
     const int w = g.ws[level], h = g.hs[level];
     const size_t o = g.off[level];
-    for (int d = 0; d < ndirs; ++d) {
-      hipStream_t st = c->s_dir[d];
-      const int i0 = d, i1 = 1 - d;
-      LevelBufs& b = lb[d];
-      if (level == g.n - 1) {
-        HIPCHK(c, hipMemsetAsync(b.flow_a, 0, size_t(w) * h * 8, st));  // PixFlow.hpp:298
-        if (max_pct > 0 && hints[d] != PF_HINT_UNKNOWN) {
-          PROF(c, st, "adjust_initial_flow");
-          launch_adjust_initial_flow(st, pyrI[i0] + o, pyrI[i1] + o, pyrA[i0] + o, pyrA[i1] + o, w, h, hints[d], max_pct, ratio[d], b.flow_a);
-        }
-      }
-      float* res = nullptr;
-      run_level(c, st, grad[i0] + 2 * o, grad[i1] + 2 * o, pyrA[i0] + o, pyrA[i1] + o, gate + o, w, h, sparse, boxes.empty() ? nullptr : &boxes[4 * level], b,
-                bnd[d] + bnd_off[level],
-                bnd[d] + bnd_total + bnd_off[level], ctrl[d] + level * 4, ctrl[d] + level * 4 + 2, &res);
-      if (level > 0) {
-        PROF(c, st, "upsample_cubic");
-        launch_upsample_cubic(st, res, w, h, b.flow_a, g.ws[level - 1], g.hs[level - 1], 1.0f / kPyrScaleFactor);
-      } else {
-        PROF(c, st, "final_flow");
-        launch_final_flow(st, res, w, h, g.ce, rows, pad, 1.0f / kDownscaleFactor, c->g3_1, d_out[d]);
+    if (level == g.n - 1) {
+      hipMemsetAsync(b.flow_a, 0, size_t(w) * h * 8, st);  // PixFlow.hpp:298
+      if (max_pct > 0 && hints[d] != PF_HINT_UNKNOWN) {
+        PROF(c, st, "adjust_initial_flow");
+        launch_adjust_initial_flow(st, pyrI[i0] + o, pyrI[i1] + o, pyrA[i0] + o, pyrA[i1] + o, w, h, hints[d], max_pct, ratio[d], b.flow_a);
       }
     }
-  }
+    float* res = nullptr;
+    run_level(c, st, grad[i0] + 2 * o, grad[i1] + 2 * o, pyrA[i0] + o, pyrA[i1] + o, gate + o, w, h, sparse, boxes.empty() ? nullptr : &boxes[4 * level], b,
+              bnd[d] + bnd_off[level],
+              bnd[d] + bnd_total + bnd_off[level], ctrl[d] + level * 4, ctrl[d] + level * 4 + 2, &res);
+    if (level > 0) {
+      PROF(c, st, "upsample_cubic");
+      launch_upsample_cubic(st, res, w, h, b.flow_a, g.ws[level - 1], g.hs[level - 1], 1.0f / kPyrScaleFactor);
+    } else {
+      PROF(c, st, "final_flow");
+      launch_final_flow(st, res, w, h, g.ce, rows, pad, 1.0f / kDownscaleFactor, c->g3_1, d_out[d]);
+    }
+  };
+  // (Measured and rejected: one host thread per direction -- +0.1 ms per pair; the GPU, not the host, paces the launches.)
+  for (int level = g.n - 1; level >= 0; --level)
+    for (int d = 0; d < ndirs; ++d) enqueue_level(d, level);
   for (int d = 0; d < ndirs; ++d) {
     launch_collect_status(c->s_dir[d], ctrl[d], g.n * 4, c->d_status, 1 << d);
     HIPCHK(c, hipEventRecord(c->ev_dir[d], c->s_dir[d]));
@@ -366,6 +406,8 @@ int finish(pf_ctx* c) {
   HIPCHK(c, hipStreamSynchronize(c->s_dir[1]));
   HIPCHK(c, hipStreamSynchronize(c->s_aux));
   HIPCHK(c, hipStreamSynchronize(c->s_gate));
+  HIPCHK(c, hipStreamSynchronize(c->s_copy));
+  c->drained = true;
   if (c->prof) prof_collect(c);
   return 0;
 }
@@ -375,9 +417,10 @@ int finish(pf_ctx* c) {
 // caller may free or reuse its buffers and the next call starts from a clean pipeline.
 struct CallGuard {
   pf_ctx* c;
-  explicit CallGuard(pf_ctx* c_) : c(c_) {}
+  explicit CallGuard(pf_ctx* c_) : c(c_) { if (c) c->drained = false; }
   ~CallGuard() {
-    if (!c) return;
+    if (!c || c->drained) return;   // the normal exit went through finish(): nothing is in flight
+    c->drained = true;
     hipStreamSynchronize(c->s_main); hipStreamSynchronize(c->s_dir[0]); hipStreamSynchronize(c->s_dir[1]); hipStreamSynchronize(c->s_aux);
     hipStreamSynchronize(c->s_gate); hipStreamSynchronize(c->s_copy);
   }
@@ -431,7 +474,9 @@ pf_ctx* pf_create(int device, int max_cols, int max_rows) {
   ok = ok && hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) == hipSuccess;
   for (int d = 0; d < 2 && ok; ++d) ok = hipEventCreateWithFlags(&c->ev_dir[d], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_status, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void**)&c->d_status, c->h_status, 0) == hipSuccess;
-  if (ok) *c->h_status = 0;
+  ok = ok && hipHostMalloc((void**)&c->h_gate, (4 * kLevelTableMax + 2) * sizeof(int), hipHostMallocMapped) == hipSuccess &&
+       hipHostGetDevicePointer((void**)&c->d_gate, c->h_gate, 0) == hipSuccess;
+  if (ok) { *c->h_status = 0; memset(c->h_gate, 0, (4 * kLevelTableMax + 2) * sizeof(int)); }
   if (!ok) { fail(nullptr, PF_ERR_DEVICE, "stream/event creation failed"); delete c; return nullptr; }
   if (const char* sv = getenv("PANOFLOW_SWEEP")) c->sweep_version = atoi(sv) == 1 ? 1 : 2;
   c->g5 = make_gauss(5, 0.25); c->g3_05 = make_gauss(3, 0.5); c->g3_1 = make_gauss(3, 1.0); c->g15 = make_gauss(15, 8.0);
@@ -472,6 +517,7 @@ void pf_destroy(pf_ctx* c) {
   if (c->s_copy) hipStreamDestroy(c->s_copy);
   if (c->s_main) hipStreamDestroy(c->s_main);
   if (c->h_status) hipHostFree(c->h_status);
+  if (c->h_gate) hipHostFree(c->h_gate);
   delete c;
 }
 

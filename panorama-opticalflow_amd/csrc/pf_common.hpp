@@ -91,6 +91,10 @@ void launch_gate_bbox(hipStream_t st, const uint8_t* gate, const LevelTable& t, 
 void launch_gradients_all(hipStream_t st, const float* pyr0, const float* pyr1, float* grad0, float* grad1, const LevelTable& t, size_t total,
                           const Gauss& g3);
 void launch_gate(hipStream_t st, const float* a0, const float* a1, int n, uint8_t* gate);
+// gate + per-level bounding boxes + level-0 count in one launch, published to mapped pinned host memory behind an epoch flag
+// (work: 4*kLevelTableMax + 2 ints, initialised once to (INT_MAX, INT_MAX, -1, -1)*, 0, 0; host_mapped: same size)
+void launch_gate_bbox_all(hipStream_t st, const float* a0, const float* a1, uint8_t* gate, const LevelTable& t, size_t total, int* work, int* host_mapped,
+                          int epoch);
 void launch_count_gate(hipStream_t st, const uint8_t* gate, int n, unsigned* count /* zeroed by the caller */);
 void launch_gauss15(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const Gauss& g15);
 void launch_gauss15_mix(hipStream_t st, float* flow, float* tmp, const float* a0, const float* a1, int w, int h, const Gauss& g15,
