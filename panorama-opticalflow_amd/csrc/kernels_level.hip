@@ -237,10 +237,67 @@ __global__ __launch_bounds__(256) void k_gauss15_col(const float2* __restrict__ 
   if (x >= w) return;
   dst[size_t(y) * w + x] = d_gauss15_col(tmp, w, h, x, y, g);
 }
+// Row + column pass in ONE launch, staged through LDS: a block owns a 64 x 32 output tile.  (1) the source tile with its
+// 7-pixel ring (reflect-101 on both indices) is loaded once, coalesced, into LDS; (2) the row pass (RowFilter: plain
+// left-to-right accumulation) of the 46 rows the column pass needs goes from LDS to LDS; (3) the column pass
+// (SymmColumnFilter: centre, then symmetric pairs outward) reads LDS.  Same operations in the same order as the two-kernel
+// form => identical bits; one launch instead of two, every source pixel read ~1.7x instead of 15x + 15x, and no round trip
+// of the row-pass plane through HBM.  MIX fuses lowAlphaFlowDiffusion's alpha mix (PixFlow.hpp:396-403) into the epilogue.
+constexpr int kG15TX = 64, kG15TY = 32, kG15R = 7;
+template <bool MIX>
+__global__ __launch_bounds__(256) void k_gauss15_fused(const float2* __restrict__ src, float2* __restrict__ dst, int w, int h, Gauss g,
+                                                        const float* __restrict__ a0, const float* __restrict__ a1) {
+  constexpr int SW = kG15TX + 2 * kG15R, SH = kG15TY + 2 * kG15R;   // 78 x 46
+  __shared__ float2 srct[SH][SW + 1];
+  __shared__ float2 rowp[SH][kG15TX];
+  const int x0 = blockIdx.x * kG15TX, y0 = blockIdx.y * kG15TY;
+  const int rowsNeeded = min(SH, h + kG15R - (y0 - kG15R));   // rows past (h - 1) + 7 are read by no output of this tile
+  // ---- (1) source tile ----
+  for (int t = threadIdx.x; t < rowsNeeded * SW; t += 256) {
+    const int r = t / SW, cidx = t - r * SW;
+    srct[r][cidx] = src[size_t(d_reflect101(y0 - kG15R + r, h)) * w + d_reflect101(min(x0 - kG15R + cidx, w - 1 + kG15R), w)];
+  }
+  __syncthreads();
+  // ---- (2) row pass ----
+  const int tx = threadIdx.x & (kG15TX - 1), ty4 = threadIdx.x >> 6;   // 64 columns x 4 row groups
+  for (int j = ty4; j < rowsNeeded; j += 4) {
+    float2 v = srct[j][tx];
+    float sx = g.k[0] * v.x, sy = g.k[0] * v.y;
+#pragma unroll
+    for (int t = 1; t < 15; ++t) {
+      v = srct[j][tx + t];
+      sx += g.k[t] * v.x; sy += g.k[t] * v.y;
+    }
+    rowp[j][tx] = make_float2(sx, sy);
+  }
+  __syncthreads();
+  const int x = x0 + tx;
+  if (x >= w) return;
+  // ---- (3) column pass: the row pass of source row reflect101(y + d) sits at LDS row (y - y0) + 7 + d ----
+  for (int oy = ty4; oy < kG15TY; oy += 4) {
+    const int y = y0 + oy;
+    if (y >= h) break;
+    const float2 c = rowp[oy + kG15R][tx];
+    float sx = g.k[7] * c.x + 0.0f, sy = g.k[7] * c.y + 0.0f;
+#pragma unroll
+    for (int j = 1; j <= 7; ++j) {
+      const float2 a = rowp[oy + kG15R + j][tx], b = rowp[oy + kG15R - j][tx];
+      sx += g.k[7 + j] * (a.x + b.x); sy += g.k[7 + j] * (a.y + b.y);
+    }
+    const size_t i = size_t(y) * w + x;
+    if (MIX) {
+      const float2 f = srct[oy + kG15R][tx + kG15R];
+      const float diffusionCoef = 1.0f - a0[i] * a1[i];
+      dst[i] = make_float2(diffusionCoef * sx + (1.0f - diffusionCoef) * f.x, diffusionCoef * sy + (1.0f - diffusionCoef) * f.y);
+    } else {
+      dst[i] = make_float2(sx, sy);
+    }
+  }
+}
 void launch_gauss15(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const Gauss& g15) {
-  dim3 grid((w + 255) / 256, h);
-  hipLaunchKernelGGL(k_gauss15_row, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(tmp), w, h, g15);
-  hipLaunchKernelGGL(k_gauss15_col, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(tmp), reinterpret_cast<float2*>(dst), w, h, g15);
+  (void)tmp;
+  dim3 grid((w + kG15TX - 1) / kG15TX, (h + kG15TY - 1) / kG15TY);
+  hipLaunchKernelGGL((k_gauss15_fused<false>), grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h, g15, nullptr, nullptr);
 }
 
 // K8 lowAlphaFlowDiffusion (PixFlow.hpp:388-405): column pass fused with the alpha mix.
@@ -255,10 +312,9 @@ __global__ __launch_bounds__(256) void k_gauss15_col_mix(const float2* __restric
   out[i] = make_float2(diffusionCoef * b.x + (1.0f - diffusionCoef) * f.x, diffusionCoef * b.y + (1.0f - diffusionCoef) * f.y);
 }
 void launch_gauss15_mix(hipStream_t st, float* flow, float* tmp, const float* a0, const float* a1, int w, int h, const Gauss& g15, float* out) {
-  dim3 grid((w + 255) / 256, h);
-  hipLaunchKernelGGL(k_gauss15_row, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(flow), reinterpret_cast<float2*>(tmp), w, h, g15);
-  hipLaunchKernelGGL(k_gauss15_col_mix, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(tmp), reinterpret_cast<const float2*>(flow), a0, a1,
-                     reinterpret_cast<float2*>(out), w, h, g15);
+  (void)tmp;
+  dim3 grid((w + kG15TX - 1) / kG15TX, (h + kG15TY - 1) / kG15TY);
+  hipLaunchKernelGGL((k_gauss15_fused<true>), grid, dim3(256), 0, st, reinterpret_cast<const float2*>(flow), reinterpret_cast<float2*>(out), w, h, g15, a0, a1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -352,35 +408,46 @@ void launch_upsample_cubic(hipStream_t st, const float* src, int sw, int sh, flo
 // (PixFlow.hpp:128-134), then crop `pad` columns each side (OpticalFlow.cpp:143-144).  Fused: each
 // output evaluates the 3x3 neighbourhood of the (virtual) upsampled image.
 // ------------------------------------------------------------------------------------------------
+// Tiled: a block owns a 64 x 16 output tile; the (virtual) upsampled image is evaluated ONCE per pixel of the tile plus a
+// one-pixel ring (reflect-101) into LDS, then the 3x3 Gaussian (row pass SymmRowSmallFilter, column pass SymmColumnFilter,
+// same expressions as before) reads LDS -- 1.2 bilinear samples per output instead of 9.
+constexpr int kFFX = 64, kFFY = 16;
 __global__ __launch_bounds__(256) void k_final_flow(const float* __restrict__ flow0, int sw, int sh, int pad_cols, int rows, int pad, double scale_x,
                                                     double scale_y, float mul, Gauss g, float2* __restrict__ out) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  __shared__ float2 up[kFFY + 2][kFFX + 2];
   const int cols = pad_cols - 2 * pad;
-  if (x >= cols) return;
-  const float k0 = g.k[1], k1 = g.k[2];
-  float tx[3], ty[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int yy = d_reflect101(y - 1 + j, rows);
-    float ux[3], uy[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int xx = d_reflect101(x + pad - 1 + i, pad_cols);
-      float v[2];
-      d_resize_linear_px<2>(flow0, sw, sh, pad_cols, rows, scale_x, scale_y, xx, yy, v);
-      ux[i] = v[0] * mul + 0.0f; uy[i] = v[1] * mul + 0.0f;
-    }
-    tx[j] = ux[1] * k0 + (ux[0] + ux[2]) * k1;
-    ty[j] = uy[1] * k0 + (uy[0] + uy[2]) * k1;
+  const int x0 = blockIdx.x * kFFX, y0 = blockIdx.y * kFFY;
+  for (int t = threadIdx.x; t < (kFFY + 2) * (kFFX + 2); t += 256) {
+    const int r = t / (kFFX + 2), cc = t - r * (kFFX + 2);
+    const int yy = d_reflect101(y0 - 1 + r, rows), xx = d_reflect101(x0 + pad - 1 + cc, pad_cols);
+    float v[2];
+    d_resize_linear_px<2>(flow0, sw, sh, pad_cols, rows, scale_x, scale_y, xx, yy, v);
+    up[r][cc] = make_float2(v[0] * mul + 0.0f, v[1] * mul + 0.0f);
   }
-  float ox = k0 * tx[1] + 0.0f; ox += k1 * (tx[2] + tx[0]);
-  float oy = k0 * ty[1] + 0.0f; oy += k1 * (ty[2] + ty[0]);
-  out[size_t(y) * cols + x] = make_float2(ox, oy);
+  __syncthreads();
+  const float k0 = g.k[1], k1 = g.k[2];
+  const int tx = threadIdx.x & (kFFX - 1);
+  const int x = x0 + tx;
+  if (x >= cols) return;
+  for (int oy = threadIdx.x >> 6; oy < kFFY; oy += 4) {
+    const int y = y0 + oy;
+    if (y >= rows) break;
+    float tx3[3], ty3[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float2 u0 = up[oy + j][tx], u1 = up[oy + j][tx + 1], u2 = up[oy + j][tx + 2];
+      tx3[j] = u1.x * k0 + (u0.x + u2.x) * k1;
+      ty3[j] = u1.y * k0 + (u0.y + u2.y) * k1;
+    }
+    float ox = k0 * tx3[1] + 0.0f; ox += k1 * (tx3[2] + tx3[0]);
+    float oy2 = k0 * ty3[1] + 0.0f; oy2 += k1 * (ty3[2] + ty3[0]);
+    out[size_t(y) * cols + x] = make_float2(ox, oy2);
+  }
 }
 void launch_final_flow(hipStream_t st, const float* flow0, int sw, int sh, int pad_cols, int rows, int pad, float mul, const Gauss& g3, float* out) {
   const double sx = 1. / ((double)pad_cols / sw), sy = 1. / ((double)rows / sh);
   const int cols = pad_cols - 2 * pad;
-  dim3 grid((cols + 255) / 256, rows);
+  dim3 grid((cols + kFFX - 1) / kFFX, (rows + kFFY - 1) / kFFY);
   hipLaunchKernelGGL(k_final_flow, grid, dim3(256), 0, st, flow0, sw, sh, pad_cols, rows, pad, sx, sy, mul, g3, reinterpret_cast<float2*>(out));
 }
 
