@@ -418,8 +418,53 @@ __global__ __launch_bounds__(256) void k_upsample_cubic(const float2* __restrict
   const float oy = hy[0] * b[0] + hy[1] * b[1] + hy[2] * b[2] + hy[3] * b[3];
   dst[size_t(dy) * dw + dx] = make_float2(ox * mul + 0.0f, oy * mul + 0.0f);
 }
+// Tiled form: a block owns a 64 x 16 output tile.  The horizontal pass (HResizeCubic) of every source row the tile's vertical
+// pass touches (at most kUpRows: 16 * 0.9 + 4 at the pyramid's scale) is computed once per output column into LDS, then the
+// vertical pass (VResizeCubic) reads four LDS rows: ~5 global loads per output instead of 16, same expressions.
+constexpr int kUpX = 64, kUpY = 16, kUpRows = 24;
+__global__ __launch_bounds__(256) void k_upsample_cubic_tiled(const float2* __restrict__ src, int sw, int sh, float2* __restrict__ dst, int dw, int dh,
+                                                              double scale_x, double scale_y, float mul) {
+  __shared__ float2 hp[kUpRows][kUpX];
+  const int x0 = blockIdx.x * kUpX, y0 = blockIdx.y * kUpY;
+  const int tx = threadIdx.x & (kUpX - 1), ty4 = threadIdx.x >> 6;
+  const int dx = min(x0 + tx, dw - 1);
+  int syLo, syHi; float fdummy;
+  d_src_coord(y0, scale_y, syLo, fdummy);
+  d_src_coord(min(y0 + kUpY, dh) - 1, scale_y, syHi, fdummy);
+  const int rowLo = syLo - 1, nrows = syHi + 2 - rowLo + 1;   // block-uniform; the host only launches this kernel when nrows <= kUpRows
+  int sx; float fx;
+  d_src_coord(dx, scale_x, sx, fx);
+  float a[4];
+  d_cubic_coeffs(fx, a);
+  const int xa = d_replicate(sx - 1, sw), xb = d_replicate(sx, sw), xc = d_replicate(sx + 1, sw), xd = d_replicate(sx + 2, sw);
+  for (int j = ty4; j < nrows; j += 4) {
+    const float2* r = src + size_t(d_replicate(rowLo + j, sh)) * sw;
+    const float2 p0 = r[xa], p1 = r[xb], p2 = r[xc], p3 = r[xd];
+    hp[j][tx] = make_float2(p0.x * a[0] + p1.x * a[1] + p2.x * a[2] + p3.x * a[3], p0.y * a[0] + p1.y * a[1] + p2.y * a[2] + p3.y * a[3]);
+  }
+  __syncthreads();
+  if (x0 + tx >= dw) return;
+  for (int oy = ty4; oy < kUpY; oy += 4) {
+    const int dy = y0 + oy;
+    if (dy >= dh) break;
+    int sy; float fy;
+    d_src_coord(dy, scale_y, sy, fy);
+    float b[4];
+    d_cubic_coeffs(fy, b);
+    const int j0 = sy - 1 - rowLo;
+    const float2 h0 = hp[j0][tx], h1 = hp[j0 + 1][tx], h2 = hp[j0 + 2][tx], h3 = hp[j0 + 3][tx];
+    const float ox = h0.x * b[0] + h1.x * b[1] + h2.x * b[2] + h3.x * b[3];
+    const float oy2 = h0.y * b[0] + h1.y * b[1] + h2.y * b[2] + h3.y * b[3];
+    dst[size_t(dy) * dw + x0 + tx] = make_float2(ox * mul + 0.0f, oy2 * mul + 0.0f);
+  }
+}
 void launch_upsample_cubic(hipStream_t st, const float* src, int sw, int sh, float* dst, int dw, int dh, float mul) {
   const double sx = 1. / ((double)dw / sw), sy = 1. / ((double)dh / sh);
+  if (kUpY * sy + 5.0 <= kUpRows) {   // source rows a 16-row output tile can touch: floor(15 * sy) + 4 (+1 for rounding)
+    dim3 grid((dw + kUpX - 1) / kUpX, (dh + kUpY - 1) / kUpY);
+    hipLaunchKernelGGL(k_upsample_cubic_tiled, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), sw, sh, reinterpret_cast<float2*>(dst), dw, dh, sx, sy, mul);
+    return;
+  }
   dim3 grid((dw + 255) / 256, dh);
   hipLaunchKernelGGL(k_upsample_cubic, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), sw, sh, reinterpret_cast<float2*>(dst), dw, dh, sx,
                      sy, mul);

@@ -560,13 +560,15 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
     const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
     top0[tid] = pack2(flow[size_t(y) * W + x]);
   }
-  if (tid >= total) return;
+  // (no early return: the block stages its 256 records in LDS so that they leave as three fully coalesced 4 KB stores instead
+  // of 16-byte pieces at a 48-byte stride)
+  __shared__ float4 stage[256 * 3];
   const int r = int(tid % kRows);
   const int s = int((tid / kRows) % nstepsPad);
   const int band = int(tid / (size_t(kRows) * nstepsPad));
   const int ia = uLo + s - r, ib = (bandLo + band) * kRows + r;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = make_float4(0.f, -1.0f, 0.f, 0.f);
-  if (s - r >= 0 && ia < uHi && ia < LS && ib < LB) {
+  if (tid < total && s - r >= 0 && ia < uHi && ia < LS && ib < LB) {
     const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;   // position in sweep order
     const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
     const size_t idx = size_t(y) * W + x;
@@ -582,7 +584,14 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
       c.y = 1.0f;
     }
   }
-  rec[tid * 3 + 0] = a; rec[tid * 3 + 1] = b; rec[tid * 3 + 2] = c;
+  stage[threadIdx.x * 3 + 0] = a; stage[threadIdx.x * 3 + 1] = b; stage[threadIdx.x * 3 + 2] = c;
+  __syncthreads();
+  const size_t base = size_t(blockIdx.x) * blockDim.x * 3, lim = total * 3;   // in float4 units
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const size_t o = base + size_t(k) * 256 + threadIdx.x;
+    if (o < lim) rec[o] = stage[k * 256 + threadIdx.x];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
