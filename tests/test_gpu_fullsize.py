@@ -140,16 +140,24 @@ def _psnr(a, b):
 # PSNR floor of step i of the chain vs the oracle chain, on the fixture's stride-8 subsample.  Step 1 sees identical
 # inputs (<= 1 LSB off in rare pixels); from step 2 on the inputs differ in those LSBs and the solver's strict '<'
 # decisions amplify them.  Measured values are printed by the test and kept in DESIGN.md.
-CHAIN_PSNR_FLOOR = (60.0, 45.0, 42.0, 40.0, 40.0)
+CHAIN_PSNR_FLOOR = (75.0, 60.0, 50.0, 50.0, 50.0)   # measured on MI355X (round 2): 85.0, 69.2, 55.8, 56.2, 55.9 dB
 
 
 def test_config4_chain_vs_oracle_fixture(pf, synth):
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chain_9000x4000.npz")
     g = np.load(path)
     cols, rows, stride, pct = int(g["cols"]), int(g["rows"]), int(g["stride"]), int(g["max_pct"])
-    top, imgs = synth.make_stitch_set(cols, rows, int(g["seed"]), 5, "cpu")       # CPU: the generator the fixture used
-    top = top.numpy(); imgs = [im.numpy() for im in imgs]
-    shas = [_sha(top)] + [_sha(im) for im in imgs]
+    # The fixture's canvases were generated with torch on the CPU (minutes at this size).  The same float64 formulas on the
+    # GPU give the same u8 images unless a value lands within an ulp of a rounding boundary, so generate there (seconds)
+    # and check the SHA-256 of every canvas; only on a mismatch fall back to the CPU generator.
+    def gen(device):
+        t, ims = synth.make_stitch_set(cols, rows, int(g["seed"]), 5, device)
+        t = t.cpu().numpy(); ims = [im.cpu().numpy() for im in ims]
+        return t, ims, [_sha(t)] + [_sha(im) for im in ims]
+
+    top, imgs, shas = gen("cuda")
+    if shas != list(g["sha_inputs"]):
+        top, imgs, shas = gen("cpu")
     assert shas == list(g["sha_inputs"]), "synthetic canvases differ from the ones the fixture was computed on"
     c = pf.Context(0)
     # ---- step 1, stage by stage: everything up to the flows is bit-identical to the oracle ----
