@@ -1,7 +1,7 @@
 """Diagnostic (not a test): BASELINE config 4 -- the 5+top stitch chain at 9000x4000, pixflow_search_20, end to end
 from host images to the final composite on the host (fused device-resident steps)."""
 import sys, os, time, numpy as np
-sys.path.insert(0, os.path.dirname(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from conftest import load_pkg_module
 pf = load_pkg_module("pyabi"); synth = load_pkg_module("synth")
 cols, rows = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (9000, 4000)

@@ -1,5 +1,5 @@
 import sys, os, numpy as np
-sys.path.insert(0, os.path.dirname(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from conftest import load_pkg_module
 import orc
 pf = load_pkg_module("pyabi"); synth = load_pkg_module("synth"); orc.build()

@@ -1,6 +1,6 @@
 """Diagnostic (not a test): sweep time of one flow direction alone vs both directions concurrently (2000x4000 strip)."""
 import sys, os, numpy as np
-sys.path.insert(0, os.path.dirname(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from conftest import load_pkg_module
 pf = load_pkg_module("pyabi"); synth = load_pkg_module("synth")
 L, R, blend = synth.make_pair_np(2000, 4000, 1234)

@@ -1,6 +1,6 @@
 """Diagnostic (not a test): sweep time vs displacement magnitude (how often proposals leave the +-7 texel LDS window)."""
 import sys, os, numpy as np
-sys.path.insert(0, os.path.dirname(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from conftest import load_pkg_module
 pf = load_pkg_module("pyabi"); synth = load_pkg_module("synth")
 ctx = pf.Context(0)

@@ -1,12 +1,12 @@
 """Diagnostics for DESIGN.md (not a test): host CPU, measured HBM copy bandwidth, CPU-port timings.
 
-Run on the GPU box:  python tests/gpu_host_info.py   ("confirm the peak with a device
+Run on the GPU box:  python tests/micro/gpu_host_info.py   ("confirm the peak with a device
 stream benchmark", "state nproc, CPU model and both [1-thread, 2-thread] numbers").
 """
 import json, os, subprocess, sys, threading, time
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_pkg_module  # noqa: E402

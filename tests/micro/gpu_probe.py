@@ -1,6 +1,6 @@
 """Diagnostic (not a test): prints per-stage GPU-vs-oracle deltas and timings on the GPU box."""
 import sys, time, os, numpy as np
-sys.path.insert(0, os.path.dirname(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from conftest import load_pkg_module
 import orc
 pf = load_pkg_module("pyabi"); synth = load_pkg_module("synth")

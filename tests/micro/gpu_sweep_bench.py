@@ -1,6 +1,6 @@
 """Diagnostic (not a test): per-step time of the sweep kernel for several (W,H) shapes."""
 import sys, os, numpy as np
-sys.path.insert(0, os.path.dirname(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from conftest import load_pkg_module
 pf = load_pkg_module("pyabi")
 ctx = pf.Context(0)

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/lt
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/lt -o t -- python tests/gpu_dir_probe.py > gpurun_out/lt.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/lt -o t -- python tests/micro/gpu_dir_probe.py > gpurun_out/lt.log 2>&1
 python - <<PY
 import csv, glob
 f = glob.glob('gpurun_out/lt/**/*kernel_trace.csv', recursive=True)[0]

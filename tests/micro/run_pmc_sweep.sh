@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmcs_$c
-  timeout 150 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcs_$c -o p -- python tests/gpu_sweep_bench.py 1100x2000 > gpurun_out/pmcs_$c.log 2>&1
+  timeout 150 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcs_$c -o p -- python tests/micro/gpu_sweep_bench.py 1100x2000 > gpurun_out/pmcs_$c.log 2>&1
   echo "$c rc=$?"
 done
 python - <<PY

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc1 -o clk -- python tests/gpu_sweep_bench.py 4000x8 1100x2000 > gpurun_out/pmc1.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc1 -o clk -- python tests/micro/gpu_sweep_bench.py 4000x8 1100x2000 > gpurun_out/pmc1.log 2>&1
 python - <<'PY'
 import csv,glob
 for f in glob.glob('gpurun_out/pmc1/**/*counter_collection.csv', recursive=True):
