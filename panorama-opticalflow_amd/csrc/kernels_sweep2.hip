@@ -25,6 +25,8 @@
 //     arithmetic that a loop-carried register or an immediate can replace, no LDS-order stalls).
 // Workgroups take their band index from an atomic ticket (a band only waits for bands already
 // running), every spin is bounded and raises ctrl[1] instead of hanging.
+#include <stdlib.h>
+
 #include "pf_common.hpp"
 #include "sweep_window.hpp"
 
@@ -600,10 +602,15 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
 // granules, wave 10 drains results.  Waves land on SIMD (wave % 4): every compute wave shares its SIMD with its
 // own loader; three waves per SIMD cap the kernel at 168 VGPRs.
 // ------------------------------------------------------------------------------------------------
-template <bool TR, bool FWD, bool SPARSE>
+template <bool TR, bool FWD, bool SPARSE, bool FUSED>
 __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
                                                 unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H,
-                                                int nstepsPad, int nbands, float rW, float rEps, int uLo, int LSv, int bandLo, long long budgetTicks) {
+                                                int nstepsPad, int nbands, float rW, float rEps, int uLo, int LSv, int bandLo, long long budgetTicks,
+                                                const float2* __restrict__ g0, const float2* __restrict__ blurred, const uint8_t* __restrict__ gate) {
+  // FUSED (rec == nullptr): FUSED PREPASS -- the loader waves compute the records themselves (same expressions as k_sweep_prep) while they
+  // run ahead of the wavefront: no prepass launch in front of the sweep, and the 2 x 48 B per level-pixel of record traffic
+  // through HBM (written by the prepass, read back here) disappears.  A pixel's own flow C is read before its step is
+  // computed and overwritten (by the drainer) only afterwards, so reading it from the plane being updated is safe.
   // Active window of this sweep (everything outside it holds pixels that are not updated and keeps its flow):
   // nbands bands starting at band bandLo, sweep-order columns [uLo, uLo + LSv) along the step axis.  Steps, ring
   // indices and granule columns are relative to uLo; image coordinates are formed from uLo + relative column.
@@ -675,8 +682,13 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
       const int x = FWD ? cxc : W - 1 - cxc, y = FWD ? cyc : H - 1 - cyc;
       return g1 + (y * W + x);
     };
-    const float4* recw = rec + size_t(band0 + w) * nstepsPad * (kRows * 3);
+    constexpr bool fused = FUSED;
+    const float4* recw = fused ? nullptr : rec + size_t(band0 + w) * nstepsPad * (kRows * 3);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
+    // fused prepass: this lane's slot inside a chunk is (step offset lane >> 3, row lane & 7)
+    const int lj = lane >> 3, lr = lane & 7;
+    const int lib = (bandLo + band0 + w) * kRows + lr;       // position across the bands (absolute)
     int rh = 0, idle = 0;
     bool first = true;
     for (;;) {
@@ -684,22 +696,52 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
       float4 va[kLoadAhead], vb[kLoadAhead], vc[kLoadAhead];
       float2 wv[kLoadAhead][4]; int ws[kLoadAhead][4]; bool wok[kLoadAhead][4]; bool ld[kLoadAhead];
       float2 pv[4][4]; int ps[4][4]; bool pk[4][4];   // first round only: batches 0..3 (0 and 1 lie before the window: they exist when the window does not start at the image border)
+      // fused prepass, phase 1: the inputs of up to kLoadAhead chunks are requested together (one round trip)
+      float2 qf[kLoadAhead], qg[kLoadAhead], qb[kLoadAhead]; int qgate[kLoadAhead], qx[kLoadAhead], qy[kLoadAhead]; bool qvalid[kLoadAhead];
 #pragma unroll
       for (int c = 0; c < kLoadAhead; ++c) {
         const int r0 = rh + c * kChunk;
         va[c] = z4; vb[c] = z4; vc[c] = z4;
         ld[c] = r0 < nsteps && (r0 + kChunk - oh <= kRS);
+        qf[c] = make_float2(0.f, 0.f); qg[c] = qf[c]; qb[c] = qf[c]; qgate[c] = 0; qx[c] = 0; qy[c] = 0; qvalid[c] = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { wv[c][k] = make_float2(0.f, 0.f); ws[c][k] = 0; wok[c][k] = false; }
         if (ld[c]) {
-          const float4* src = recw + size_t(r0) * (kRows * 3);
-          va[c] = src[lane]; vb[c] = src[lane + 64]; vc[c] = src[lane + 128];
+          if (!fused) {
+            const float4* src = recw + size_t(r0) * (kRows * 3);
+            va[c] = src[lane]; vb[c] = src[lane + 64]; vc[c] = src[lane + 128];
+          } else {
+            const int sstep = r0 + lj, ia = uLo + sstep - lr;
+            qvalid[c] = sstep - lr >= 0 && ia < uLo + LSv && ia < LS && lib < LB;
+            const int cxs = TR ? lib : ia, cys = TR ? ia : lib;   // position in sweep order
+            qx[c] = qvalid[c] ? (FWD ? cxs : W - 1 - cxs) : 0; qy[c] = qvalid[c] ? (FWD ? cys : H - 1 - cys) : 0;
+            const int idx = qy[c] * W + qx[c];
+            qf[c] = flow[idx]; qgate[c] = gate[idx]; qg[c] = g0[idx]; qb[c] = blurred[idx];
+          }
           const int b = r0 / kChunk + 4;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const float2* q = win_addr(b, k, ws[c][k]);
             wok[c][k] = q != nullptr;
             if (wok[c][k]) wv[c][k] = *q;
+          }
+        }
+      }
+      // fused prepass, phase 2: own-flow terms E(C), E(C+dx), E(C+dy) -- the expressions of k_sweep_prep -- straight into the record
+      // ring (the slots are free: ld[c] checked the ring room; they are published further down)
+      if (fused) {
+#pragma unroll
+        for (int c = 0; c < kLoadAhead; ++c) {
+          if (ld[c]) {
+            const float2 f = qf[c], g = qg[c], bl = qb[c];
+            const bool on = qvalid[c] && qgate[c] != 0;
+            const float e0 = d_error2g(g1, W, wm2, hm2, fW, rW, qx[c], qy[c], g.x, g.y, bl.x, bl.y, f.x, f.y);
+            const float e1 = d_error2g(g1, W, wm2, hm2, fW, rW, qx[c], qy[c], g.x, g.y, bl.x, bl.y, f.x + kGradEpsilon, f.y + 0.0f);
+            const float e2 = d_error2g(g1, W, wm2, hm2, fW, rW, qx[c], qy[c], g.x, g.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
+            float4* dst = &sm.rec[w][(rh + c * kChunk) % kRS][0][0] + lane * 3;   // slot (lane >> 3, lane & 7) = linear slot `lane`
+            dst[0] = on ? make_float4(g.x, g.y, bl.x, bl.y) : z4;
+            dst[1] = make_float4(qvalid[c] ? f.x : 0.f, qvalid[c] ? f.y : 0.f, on ? e0 : 0.f, on ? e1 : 0.f);
+            dst[2] = make_float4(on ? e2 : 0.f, qvalid[c] ? (on ? 1.0f : 0.0f) : -1.0f, 0.f, 0.f);
           }
         }
       }
@@ -727,7 +769,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
       for (int c = 0; c < kLoadAhead; ++c) {
         if (ld[c]) {
           float4* dst = &sm.rec[w][rh % kRS][0][0];
-          dst[lane] = va[c]; dst[lane + 64] = vb[c]; dst[lane + 128] = vc[c];
+          if (!fused) { dst[lane] = va[c]; dst[lane + 64] = vb[c]; dst[lane + 128] = vc[c]; }
 #pragma unroll
           for (int k = 0; k < 4; ++k) if (wok[c][k]) winw[ws[c][k]] = wv[c][k];
           rh += kChunk;
@@ -817,12 +859,23 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
   {
     if ((wg == 0 && !staticTop) || wave != 2 * kWaves + 1) return;
     const unsigned long long* bnd_in = boundary + size_t(wg) * LSv;
+    const bool topFromPlane = FUSED && wg == 0;   // (wg == 0 only gets here with a static top row)
     int bh = 0, idle = 0;
     while (bh < LSv) {
       const int oh0 = ld_cnt(&sm.outHead[0]);
       if (bh + 64 - oh0 <= kBS) {
         unsigned long long g = kNotReady;
-        if (bh + lane < LSv) g = __hip_atomic_load(bnd_in + bh + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bh + lane < LSv) {
+          if (topFromPlane) {
+            // fused prepass: the row above the window never changes during this sweep -- read it from the flow plane itself
+            const int ia = uLo + bh + lane, ib = bandLo * kRows - 1;
+            const int cxs = TR ? ib : ia, cys = TR ? ia : ib;
+            const int x = FWD ? cxs : W - 1 - cxs, y = FWD ? cys : H - 1 - cys;
+            g = pack2(flow[y * W + x]);
+          } else {
+            g = __hip_atomic_load(bnd_in + bh + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
         const bool ready = (g != kNotReady) || (bh + lane >= LSv);
         const unsigned long long m = __ballot(ready);
         const int n = (m == ~0ull) ? 64 : __builtin_ctzll(~m);
@@ -865,16 +918,23 @@ void launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
   const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
   const size_t prepThreads = total > size_t(LSv) ? total : size_t(LSv);
   const float rW = (float)(1.0 / (double)(float)a.W), rEps = (float)(1.0 / (double)kGradEpsilon);
-  hipLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((prepThreads + 255) / 256)), dim3(256), 0, st, a.g0, a.g1, a.blurred, a.gate, a.flow, a.W, a.H, a.forward, tr,
-                     nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo, bandLo > 0 ? a.boundary : nullptr);
+  // PANOFLOW_FUSED_PREP=1: no prepass kernel, the loader waves compute the records themselves (no record traffic through HBM,
+  // one launch fewer per sweep).  Bit-identical, but measured 8 % SLOWER (profiles/r02_fused_prepass_ab.txt): ~900 extra VALU
+  // instructions per round on the SIMD a latency-critical compute wave lives on.  Off by default; kept as an experiment switch.
+  static const bool fusedPrep = [] { const char* e = getenv("PANOFLOW_FUSED_PREP"); return e && atoi(e) == 1; }();
+  if (!fusedPrep)
+    hipLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((prepThreads + 255) / 256)), dim3(256), 0, st, a.g0, a.g1, a.blurred, a.gate, a.flow, a.W, a.H, a.forward, tr,
+                       nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo, bandLo > 0 ? a.boundary : nullptr);
   // wall-clock budget of every wait inside the launch, in 100 MHz ticks: 2 s + 1000 x the expected duration (~0.5 us per step)
   const long long budget = 200000000ll + 1000ll * 50ll * (long long)(nstepsPad + 9 * nbands);
   const dim3 grid(nwg), block(64 * (2 * kWaves + 3));
-  const float4* r4 = reinterpret_cast<const float4*>(rec);
-#define PF_LAUNCH_SWEEP2(TRV, FWV) do { if (a.sparse) hipLaunchKernelGGL((k_sweep2<TRV, FWV, true>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget); \
-    else hipLaunchKernelGGL((k_sweep2<TRV, FWV, false>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget); } while (0)
+  const float4* r4 = fusedPrep ? nullptr : reinterpret_cast<const float4*>(rec);
+#define PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, FUV) hipLaunchKernelGGL((k_sweep2<TRV, FWV, SPV, FUV>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.g0, a.blurred, a.gate)
+#define PF_LAUNCH_SWEEP2(TRV, FWV) do { if (a.sparse) { if (fusedPrep) PF_LAUNCH_SWEEP2_(TRV, FWV, true, true); else PF_LAUNCH_SWEEP2_(TRV, FWV, true, false); } \
+    else { if (fusedPrep) PF_LAUNCH_SWEEP2_(TRV, FWV, false, true); else PF_LAUNCH_SWEEP2_(TRV, FWV, false, false); } } while (0)
   if (tr) { if (a.forward) PF_LAUNCH_SWEEP2(true, true); else PF_LAUNCH_SWEEP2(true, false); }
   else { if (a.forward) PF_LAUNCH_SWEEP2(false, true); else PF_LAUNCH_SWEEP2(false, false); }
+#undef PF_LAUNCH_SWEEP2_
 #undef PF_LAUNCH_SWEEP2
 }
 
