@@ -298,12 +298,14 @@ def main():
             top = top.cpu().numpy(); imgs = [im.cpu().numpy() for im in imgs]
             torch.cuda.empty_cache()
 
+            final = np.zeros((cr, cc, 4), np.uint8)       # the caller's result buffer, reused across runs (like the reference's Mat)
+
             def chain():
                 t1 = time.perf_counter()
                 for i, im in enumerate(imgs):
                     last = i == len(imgs) - 1
                     cx.stitch_prefetch(None if last else imgs[i + 1])      # image i+1 goes up while step i computes
-                    o = cx.stitch_step(im, top if i == 0 else None, 20, want_out=last)
+                    o = cx.stitch_step(im, top if i == 0 else None, 20, want_out=last, out=final if last else None)
                 return time.perf_counter() - t1, o
 
             chain()

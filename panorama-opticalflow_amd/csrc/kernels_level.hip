@@ -152,15 +152,19 @@ __global__ __launch_bounds__(256) void k_gate_bbox_all(const float* __restrict__
   for (int l = l0; l < t.n && t.off[l] < end; ++l) {
     lvl = l; w = t.w[l]; off = t.off[l]; cnt = unsigned(t.w[l]) * unsigned(t.h[l]);
     const unsigned lo = off > base ? off : base, hiE = (off + cnt < end) ? off + cnt : end;
-    for (unsigned i = lo + threadIdx.x; i < hiE; i += 256) {
+    // one division per thread and level; the following elements (256 apart) advance (x, y) incrementally
+    unsigned i = lo + threadIdx.x;
+    int y = 0, x = 0;
+    if (i < hiE) { const unsigned local = i - off; y = int(local / unsigned(w)); x = int(local - unsigned(y) * unsigned(w)); }
+    for (; i < hiE; i += 256) {
       const bool gt = a0[i] > kUpdateAlphaThreshold && a1[i] > kUpdateAlphaThreshold;
       gate[i] = gt ? 1 : 0;
       if (gt) {
-        const unsigned local = i - off;
-        const int y = int(local / unsigned(w)), x = int(local - unsigned(y) * unsigned(w));
         mnx = min(mnx, x); mny = min(mny, y); mxx = max(mxx, x); mxy = max(mxy, y);
         if (l == 0) ++cnt0;
       }
+      x += 256;
+      while (x >= w) { x -= w; ++y; }
     }
     flush();
   }

@@ -230,10 +230,15 @@ class Context:
         rows, cols, _ = next_L.shape
         self._chk(self.l.pf_stitch_prefetch(self.h, _p(next_L), cols, rows, C.c_size_t(cols * 4)))
 
-    def stitch_step(self, L, R, max_pct, want_out=True):
-        """One iteration of main.cpp's loop on the device; R=None chains on the previous result kept in HBM."""
+    def stitch_step(self, L, R, max_pct, want_out=True, out=None):
+        """One iteration of main.cpp's loop on the device; R=None chains on the previous result kept in HBM.
+        out: optional preallocated (rows, cols, 4) uint8 array for the composite (a caller that reuses its buffer, like
+        the reference's Mat, does not pay a fresh 144 MB allocation + first-touch page faults per call)."""
         a = _u8(L); rows, cols, _ = a.shape
-        out = np.empty((rows, cols, 4), np.uint8) if want_out else None
+        if out is not None:
+            assert out.dtype == np.uint8 and out.shape == (rows, cols, 4) and out.flags["C_CONTIGUOUS"]
+        elif want_out:
+            out = np.empty((rows, cols, 4), np.uint8)
         self._chk(self.l.pf_stitch_step(self.h, _p(a), None if R is None else _p(_u8(R)), cols, rows, C.c_size_t(cols * 4), max_pct,
                                         None if out is None else _p(out), C.c_size_t(cols * 4)))
         return out
