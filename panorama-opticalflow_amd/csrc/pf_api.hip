@@ -452,7 +452,7 @@ int pf_device_count(void) {
   return n;
 }
 
-const char* pf_version(void) { return "panoflow-mi355x r1 (gfx950)"; }
+const char* pf_version(void) { return "panoflow-mi355x r2 (gfx950)"; }
 
 pf_ctx* pf_create(int device, int max_cols, int max_rows) {
   int n = 0;
