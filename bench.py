@@ -264,20 +264,8 @@ def main():
                 res["roofline"]["latency_bound"] = {"swept_steps": swept, "t_step_us": round(t_step, 4), "bound_ms": round(bound_ms, 3),
                                                     "measured_sweep_ms_per_direction": round(sweep_ms_per_dir, 3), "frac_of_bound": round(bound_ms / sweep_ms_per_dir, 4),
                                                     "note": "bound = swept_steps x t_step of ONE lone band (8 rows x 4096, HIP events); the two directions run concurrently"}
-            # ---- throughput mode (never `value`): 12 independent strips, 6 in flight on this GPU, through the C ABI's batch entry ----
-            del extra[:]
-            nb, infl = 12, 6
-            pairs_b = [synth.make_pair(cols, rows, 5000 + i, dev) for i in range(nb)]
-            outs_b = [torch.empty_like(out) for _ in range(nb)]
-            torch.cuda.synchronize()
-            call_b = lambda: ctx.novel_view_batch_dev([p[0].data_ptr() for p in pairs_b], [p[1].data_ptr() for p in pairs_b], cols, rows, max_pct,
-                                                      [p[2].data_ptr() for p in pairs_b], [o.data_ptr() for o in outs_b], None, None, in_flight=infl)
-            call_b()
-            t1 = time.perf_counter(); call_b(); tb = time.perf_counter() - t1
-            res["throughput_mode"] = {"value": round(nb * mpix / tb, 3), "unit": "Mpix/s", "pairs": nb, "in_flight": infl, "entry": "pf_novel_view_batch_dev",
-                                      "note": "several independent pairs side by side on one GPU; an extra figure, not the BASELINE single-strip config"}
-            del pairs_b, outs_b
             # ---- north_star's target size: one 9000x4000 pair through the same entry point ----
+            del extra[:]
             cc, cr = 9000, 4000
             cx = pf.Context(local_rank, cc, cr)
             Lc, Rc, bc, _ = synth.make_pair(cc, cr, 1234, dev)
@@ -313,6 +301,20 @@ def main():
             res["config4_chain"] = {"seconds": round(tc, 4), "unit": "s", "workload": "5+top stitch chain, 9000x4000, pixflow_search_20, pf_stitch_step x5 (host images in, host composite out)",
                                     "Mpix/s_canvas": round(5 * cc * cr / 1e6 / tc, 2), "runs": 3, "warmup": 1}
             cx.close()
+            # ---- throughput mode (never `value`): 12 independent strips, 6 in flight on this GPU, through the C ABI's batch entry ----
+            nb, infl = 12, 6
+            pairs_b = [synth.make_pair(cols, rows, 5000 + i, dev) for i in range(nb)]
+            outs_b = [torch.empty_like(out) for _ in range(nb)]
+            torch.cuda.synchronize()
+            ct = pf.Context(local_rank, cols, rows)          # its own context: the lanes it creates go away with it
+            call_b = lambda: ct.novel_view_batch_dev([p[0].data_ptr() for p in pairs_b], [p[1].data_ptr() for p in pairs_b], cols, rows, max_pct,
+                                                      [p[2].data_ptr() for p in pairs_b], [o.data_ptr() for o in outs_b], None, None, in_flight=infl)
+            call_b()
+            t1 = time.perf_counter(); call_b(); tb = time.perf_counter() - t1
+            res["throughput_mode"] = {"value": round(nb * mpix / tb, 3), "unit": "Mpix/s", "pairs": nb, "in_flight": infl, "entry": "pf_novel_view_batch_dev",
+                                      "note": "several independent pairs side by side on one GPU; an extra figure, not the BASELINE single-strip config"}
+            del pairs_b, outs_b
+            ct.close()
         if world == 1 and not args.no_cpu_baseline:
             Lh, Rh, bh = L.cpu().numpy(), R.cpu().numpy(), blend.cpu().numpy()
             t1, t2, r0, r1, rout = cpu_baseline(Lh, Rh, bh, max_pct)

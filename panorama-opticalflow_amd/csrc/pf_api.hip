@@ -36,7 +36,6 @@ struct ProfPending { int id; hipEvent_t a, b; };
 struct pf_ctx {
   int device = 0;
   hipStream_t s_main = nullptr, s_dir[2] = {nullptr, nullptr}, s_aux = nullptr;
-  hipStream_t s_gate = nullptr;                        // alpha pyramid -> gate -> bounding boxes, beside the grey path of the front end
   hipEvent_t ev_alpha = nullptr, ev_gate = nullptr;
   hipEvent_t ev_aux_go = nullptr, ev_aux_done = nullptr;
   hipEvent_t ev_pre = nullptr, ev_dir[2] = {nullptr, nullptr};
@@ -49,7 +48,8 @@ struct pf_ctx {
   long long last_swept_steps = 0;       // wavefront steps of one direction of the last solve (both sweeps, all levels, gated windows)
   const uint8_t* prefetch_src = nullptr; int prefetch_cols = 0, prefetch_rows = 0; size_t prefetch_step = 0;   // pf_stitch_prefetch: next step's left image
   bool prefetched = false;              // ... and whether it already sits in "ch_l_next"
-  hipStream_t s_copy = nullptr;         // uploads that overlap compute
+  hipStream_t s_copy = nullptr;         // uploads that overlap compute (created on first use, like s_aux: a context that only solves
+                                        // pairs drives three streams, so that six lanes of the throughput mode fit the hardware queues)
   bool drained = true;                  // false between "work enqueued" and finish(): what CallGuard looks at
   std::vector<pf_ctx*> lanes;           // throughput mode: further stream/buffer sets on the same device (pf_novel_view_batch_dev)
   int* h_gate = nullptr; int* d_gate = nullptr; int gate_epoch = 0;   // mapped pinned: per-level gate boxes + count + epoch flag (k_gate_bbox_all)
@@ -404,9 +404,8 @@ int finish(pf_ctx* c) {
   HIPCHK(c, hipStreamSynchronize(c->s_main));
   HIPCHK(c, hipStreamSynchronize(c->s_dir[0]));
   HIPCHK(c, hipStreamSynchronize(c->s_dir[1]));
-  HIPCHK(c, hipStreamSynchronize(c->s_aux));
-  HIPCHK(c, hipStreamSynchronize(c->s_gate));
-  HIPCHK(c, hipStreamSynchronize(c->s_copy));
+  if (c->s_aux) HIPCHK(c, hipStreamSynchronize(c->s_aux));
+  if (c->s_copy) HIPCHK(c, hipStreamSynchronize(c->s_copy));
   c->drained = true;
   if (c->prof) prof_collect(c);
   return 0;
@@ -421,8 +420,9 @@ struct CallGuard {
   ~CallGuard() {
     if (!c || c->drained) return;   // the normal exit went through finish(): nothing is in flight
     c->drained = true;
-    hipStreamSynchronize(c->s_main); hipStreamSynchronize(c->s_dir[0]); hipStreamSynchronize(c->s_dir[1]); hipStreamSynchronize(c->s_aux);
-    hipStreamSynchronize(c->s_gate); hipStreamSynchronize(c->s_copy);
+    hipStreamSynchronize(c->s_main); hipStreamSynchronize(c->s_dir[0]); hipStreamSynchronize(c->s_dir[1]);
+    if (c->s_aux) hipStreamSynchronize(c->s_aux);
+    if (c->s_copy) hipStreamSynchronize(c->s_copy);
   }
 };
 
@@ -466,9 +466,6 @@ pf_ctx* pf_create(int device, int max_cols, int max_rows) {
   c->device = device;
   bool ok = hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking) == hipSuccess;
   for (int d = 0; d < 2 && ok; ++d) ok = hipStreamCreateWithFlags(&c->s_dir[d], hipStreamNonBlocking) == hipSuccess;
-  ok = ok && hipStreamCreateWithFlags(&c->s_aux, hipStreamNonBlocking) == hipSuccess;
-  ok = ok && hipStreamCreateWithFlags(&c->s_gate, hipStreamNonBlocking) == hipSuccess;
-  ok = ok && hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_alpha, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_aux_go, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) == hipSuccess;
@@ -513,7 +510,6 @@ void pf_destroy(pf_ctx* c) {
   if (c->s_aux) hipStreamDestroy(c->s_aux);
   if (c->ev_alpha) hipEventDestroy(c->ev_alpha);
   if (c->ev_gate) hipEventDestroy(c->ev_gate);
-  if (c->s_gate) hipStreamDestroy(c->s_gate);
   if (c->s_copy) hipStreamDestroy(c->s_copy);
   if (c->s_main) hipStreamDestroy(c->s_main);
   if (c->h_status) hipHostFree(c->h_status);
@@ -833,6 +829,8 @@ int pf_stitch_step(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int 
   { PROF(c, sm, "match_images"); launch_match_images(sm, dl, dr, cols, rows, dm, dol, dor); }
   // The blend ramp (GenerateBlend + countblend + smoothing, StitchTool.cpp:98-191) only depends on the map and is only
   // needed by the final blend: it runs on its own stream beside the two flow solves.
+  if (!c->s_aux) HIPCHK(c, hipStreamCreateWithFlags(&c->s_aux, hipStreamNonBlocking));
+  if (!c->s_copy) HIPCHK(c, hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
   hipStream_t sa = c->s_aux;
   HIPCHK(c, hipEventRecord(c->ev_aux_go, sm));
   HIPCHK(c, hipStreamWaitEvent(sa, c->ev_aux_go, 0));
