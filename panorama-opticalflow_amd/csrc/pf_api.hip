@@ -828,18 +828,20 @@ int pf_stitch_step(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int 
   }
   { PROF(c, sm, "match_images"); launch_match_images(sm, dl, dr, cols, rows, dm, dol, dor); }
   // The blend ramp (GenerateBlend + countblend + smoothing, StitchTool.cpp:98-191) only depends on the map and is only
-  // needed by the final blend: it runs on its own stream beside the two flow solves.
+  // needed by the final blend: it runs on its own stream beside the two flow solves.  Its ~850 tiny launches (the tile
+  // smoothing is one launch per anti-diagonal of tiles) are enqueued AFTER the solver's: enqueued first, they kept the
+  // host busy for >2 ms per step before the solver's first kernel could be launched.
   if (!c->s_aux) HIPCHK(c, hipStreamCreateWithFlags(&c->s_aux, hipStreamNonBlocking));
   if (!c->s_copy) HIPCHK(c, hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
   hipStream_t sa = c->s_aux;
   HIPCHK(c, hipEventRecord(c->ev_aux_go, sm));
+  const int hints[2] = {PF_HINT_LEFT, PF_HINT_RIGHT}; float* outs[2] = {f0, f1};
+  const int pad = cols / 20;
+  if (int e = solve(c, dol, dor, cols, rows, pad, max_pct, 2, hints, outs)) return e;
   HIPCHK(c, hipStreamWaitEvent(sa, c->ev_aux_go, 0));
   { PROF(c, sa, "countblend"); launch_countblend(sa, dm, cols, rows, db, dmd); }
   if (int e = blend_smooth_dev(c, db, dmd, cols, rows, sa)) return e;
   HIPCHK(c, hipEventRecord(c->ev_aux_done, sa));
-  const int hints[2] = {PF_HINT_LEFT, PF_HINT_RIGHT}; float* outs[2] = {f0, f1};
-  const int pad = cols / 20;
-  if (int e = solve(c, dol, dor, cols, rows, pad, max_pct, 2, hints, outs)) { hipStreamSynchronize(sa); return e; }
   HIPCHK(c, hipStreamWaitEvent(sm, c->ev_aux_done, 0));
   { PROF(c, sm, "blend"); launch_blend(sm, dol, dor, f0, f1, db, cols, rows, dmerged); }
   { PROF(c, sm, "gather"); launch_gather(sm, dl, dr, dmerged, dm, cols, rows, dfin); }
