@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256) void k_gradients(const float* __restrict__ img
 // All pyramid levels of both images in ONE launch (the per-level launches of the small levels are pure launch latency):
 // a thread's flat index inside the pyramid plane -> level by binary search in the offset table -> (x, y).
 __global__ __launch_bounds__(256) void k_gradients_all(const float* __restrict__ img0, const float* __restrict__ img1, float2* __restrict__ g0,
-                                                       float2* __restrict__ g1, LevelTable t, unsigned total, Gauss g) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+                                                       float2* __restrict__ g1, LevelTable t, unsigned first, unsigned total, Gauss g) {
+  const unsigned i = first + blockIdx.x * blockDim.x + threadIdx.x;   // elements [first, total) of the pyramid plane
   if (i >= total) return;
   int lo = 0, hi = t.n - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (i >= t.off[mid]) lo = mid; else hi = mid - 1; }
@@ -60,10 +60,11 @@ void launch_gradients(hipStream_t st, const float* img, int w, int h, float* gxy
   dim3 grid((w + 255) / 256, h);
   hipLaunchKernelGGL(k_gradients, grid, dim3(256), 0, st, img, w, h, reinterpret_cast<float2*>(gxy), g3);
 }
-void launch_gradients_all(hipStream_t st, const float* pyr0, const float* pyr1, float* grad0, float* grad1, const LevelTable& t, size_t total,
-                          const Gauss& g3) {
-  hipLaunchKernelGGL(k_gradients_all, dim3((unsigned)((total + 255) / 256), 2), dim3(256), 0, st, pyr0, pyr1, reinterpret_cast<float2*>(grad0),
-                     reinterpret_cast<float2*>(grad1), t, (unsigned)total, g3);
+void launch_gradients_all(hipStream_t st, const float* pyr0, const float* pyr1, float* grad0, float* grad1, const LevelTable& t, size_t first,
+                          size_t total, const Gauss& g3) {
+  if (total <= first) return;
+  hipLaunchKernelGGL(k_gradients_all, dim3((unsigned)((total - first + 255) / 256), 2), dim3(256), 0, st, pyr0, pyr1, reinterpret_cast<float2*>(grad0),
+                     reinterpret_cast<float2*>(grad1), t, (unsigned)first, (unsigned)total, g3);
 }
 
 // update gate of the sweeps (PixFlow.hpp:317,330): alpha0 > 0.9 && alpha1 > 0.9

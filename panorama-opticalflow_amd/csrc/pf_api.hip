@@ -39,6 +39,7 @@ struct pf_ctx {
   hipEvent_t ev_alpha = nullptr, ev_gate = nullptr;
   hipEvent_t ev_aux_go = nullptr, ev_aux_done = nullptr;
   hipEvent_t ev_pre = nullptr, ev_dir[2] = {nullptr, nullptr};
+  hipEvent_t ev_fine = nullptr;   // gradients of the fine levels done (the directions start on the coarse ones before that)
   std::string err;
   std::map<std::string, DevBuf> bufs;  // named grow-only arena: everything a solve needs stays resident
   Gauss g5, g3_05, g3_1, g15;
@@ -301,6 +302,7 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   // and publishes them into mapped pinned memory; the host polls its epoch flag (microseconds, no blocking sync, no pageable
   // copies) while the gradients of all levels and the hand-off initialisation are still running behind it.
   bool have_table = false; LevelTable table;
+  const int split = g.n > 10 ? 8 : 0;   // levels [0, split) are "fine": 80 % of the pixels of a 0.9x pyramid
   unsigned h_cnt = 0;
   std::vector<int> boxes;
   int epoch = 0;
@@ -311,8 +313,9 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
     if (!work) return PF_ERR_NOMEM;
     epoch = ++c->gate_epoch;
     { PROF(c, sg, "gate"); launch_gate_bbox_all(sg, pyrA[0], pyrA[1], gate, t, g.P, work, c->d_gate, epoch); }
-    // gradients of all levels in one launch (the level planes are contiguous; padding between them is skipped / harmless)
-    { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], t, g.P, c->g3_05); }
+    // gradients: the coarse levels first (a few percent of the pixels) -- the directions start on those -- the fine levels in a
+    // second launch that runs while the coarse levels are already being solved (ev_fine, waited for at level split - 1)
+    { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], t, g.off[split], g.P, c->g3_05); }
     have_table = true; table = t;
   } else {
     for (int l = 0; l < g.n; ++l) {
@@ -328,6 +331,8 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
     HIPCHK(c, hipMemsetAsync(ctrl[d], 0, size_t(g.n) * 2 * 2 * sizeof(int), sm));
   }
   HIPCHK(c, hipEventRecord(c->ev_pre, sm));
+  if (have_table && split > 0) { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], table, 0, g.off[split], c->g3_05); }
+  HIPCHK(c, hipEventRecord(c->ev_fine, sm));
   if (have_table) {
     if (int e = wait_gate_boxes(c, sg, epoch, g.n, boxes, h_cnt)) return e;
     if (getenv("PANOFLOW_NO_WINDOW")) boxes.clear();
@@ -357,6 +362,7 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   for (int d = 0; d < ndirs; ++d) HIPCHK(c, hipStreamWaitEvent(c->s_dir[d], c->ev_pre, 0));
   auto enqueue_level = [&](int d, int level) {
     hipStream_t st = c->s_dir[d];
+    if (level == split - 1) hipStreamWaitEvent(st, c->ev_fine, 0);   // first level whose gradients come from the second launch
     const int i0 = d, i1 = 1 - d;
     LevelBufs& b = lb[d];
     const int w = g.ws[level], h = g.hs[level];
@@ -468,7 +474,7 @@ pf_ctx* pf_create(int device, int max_cols, int max_rows) {
   for (int d = 0; d < 2 && ok; ++d) ok = hipStreamCreateWithFlags(&c->s_dir[d], hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_alpha, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_aux_go, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_fine, hipEventDisableTiming) == hipSuccess;
   for (int d = 0; d < 2 && ok; ++d) ok = hipEventCreateWithFlags(&c->ev_dir[d], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_status, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void**)&c->d_status, c->h_status, 0) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_gate, (4 * kLevelTableMax + 2) * sizeof(int), hipHostMallocMapped) == hipSuccess &&
@@ -504,6 +510,7 @@ void pf_destroy(pf_ctx* c) {
   for (auto e : c->ev_pool) hipEventDestroy(e);
   for (auto& p : c->prof_pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   if (c->ev_pre) hipEventDestroy(c->ev_pre);
+  if (c->ev_fine) hipEventDestroy(c->ev_fine);
   for (int d = 0; d < 2; ++d) { if (c->ev_dir[d]) hipEventDestroy(c->ev_dir[d]); if (c->s_dir[d]) hipStreamDestroy(c->s_dir[d]); }
   if (c->ev_aux_go) hipEventDestroy(c->ev_aux_go);
   if (c->ev_aux_done) hipEventDestroy(c->ev_aux_done);

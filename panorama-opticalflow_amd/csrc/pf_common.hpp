@@ -88,8 +88,9 @@ void launch_gradients(hipStream_t st, const float* img, int w, int h, float* gxy
 constexpr int kLevelTableMax = 96;
 struct LevelTable { int n; int w[kLevelTableMax]; int h[kLevelTableMax]; unsigned off[kLevelTableMax]; };
 void launch_gate_bbox(hipStream_t st, const uint8_t* gate, const LevelTable& t, size_t total, int* box);   // box[4*l..]: min x, min y, max x, max y
-void launch_gradients_all(hipStream_t st, const float* pyr0, const float* pyr1, float* grad0, float* grad1, const LevelTable& t, size_t total,
-                          const Gauss& g3);
+// elements [first, total) of the pyramid planes (levels lie back to back, level 0 first)
+void launch_gradients_all(hipStream_t st, const float* pyr0, const float* pyr1, float* grad0, float* grad1, const LevelTable& t, size_t first,
+                          size_t total, const Gauss& g3);
 void launch_gate(hipStream_t st, const float* a0, const float* a1, int n, uint8_t* gate);
 // gate + per-level bounding boxes + level-0 count in one launch, published to mapped pinned host memory behind an epoch flag
 // (work: 4*kLevelTableMax + 2 ints, initialised once to (INT_MAX, INT_MAX, -1, -1)*, 0, 0; host_mapped: same size)
