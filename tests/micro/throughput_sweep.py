@@ -1,0 +1,20 @@
+"""GPU box: Mpix/s of pf_novel_view_batch_dev on 2000x4000 strips for several lane counts (GPU_MAX_HW_QUEUES from the environment)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from conftest import load_pkg_module
+pf = load_pkg_module("pyabi"); synth = load_pkg_module("synth")
+cols, rows = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2000, 4000)
+dev = torch.device("cuda", 0)
+nb = 24
+pairs = [synth.make_pair(cols, rows, 7000 + i, dev) for i in range(nb)]
+outs = [torch.empty((rows, cols, 4), dtype=torch.uint8, device=dev) for _ in range(nb)]
+torch.cuda.synchronize()
+for infl in (1, 2, 4, 6, 8, 10, 12, 16):
+    c = pf.Context(0, cols, rows)
+    call = lambda: c.novel_view_batch_dev([p[0].data_ptr() for p in pairs], [p[1].data_ptr() for p in pairs], cols, rows, 0,
+                                          [p[2].data_ptr() for p in pairs], [o.data_ptr() for o in outs], None, None, in_flight=infl)
+    call()
+    t = time.perf_counter(); call(); dt = time.perf_counter() - t
+    print("queues %s in_flight %2d: %.1f Mpix/s (%.1f ms per pair)" % (os.environ.get("GPU_MAX_HW_QUEUES"), infl, nb * cols * rows / 1e6 / dt, 1000 * dt / nb), flush=True)
+    c.close()
