@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 
 #include "../../include/panoflow.h"
@@ -32,11 +33,14 @@ struct Rccl {
   std::string err;
 };
 
-Rccl* rccl() {
+void rccl_load(Rccl& r);
+Rccl* rccl() {   // bound once, also when the first callers are several rank threads of one process
   static Rccl r;
-  static bool tried = false;
-  if (tried) return &r;
-  tried = true;
+  static std::once_flag once;
+  std::call_once(once, [] { rccl_load(r); });
+  return &r;
+}
+void rccl_load(Rccl& r) {
   // A process must hold ONE copy of RCCL (two copies interpose each other's globals): if one is already mapped -- e.g. the
   // one PyTorch ships and loads for torch.distributed -- bind to exactly that file; otherwise load ROCm's.
   std::string loaded;
@@ -47,12 +51,11 @@ Rccl* rccl() {
   if (!loaded.empty()) r.h = dlopen(loaded.c_str(), RTLD_NOW | RTLD_LOCAL);
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* n : names) { if (r.h) break; r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
-  if (!r.h) { r.err = std::string("cannot load RCCL: ") + dlerror(); return &r; }
-#define PF_SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.h, sym)); if (!r.field) { r.err = std::string("RCCL symbol missing: ") + sym; r.h = nullptr; return &r; }
+  if (!r.h) { r.err = std::string("cannot load RCCL: ") + dlerror(); return; }
+#define PF_SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.h, sym)); if (!r.field) { r.err = std::string("RCCL symbol missing: ") + sym; r.h = nullptr; return; }
   PF_SYM(GetUniqueId, "ncclGetUniqueId") PF_SYM(CommInitRank, "ncclCommInitRank") PF_SYM(CommDestroy, "ncclCommDestroy") PF_SYM(GroupStart, "ncclGroupStart")
   PF_SYM(GroupEnd, "ncclGroupEnd") PF_SYM(Send, "ncclSend") PF_SYM(Recv, "ncclRecv") PF_SYM(AllReduce, "ncclAllReduce") PF_SYM(GetErrorString, "ncclGetErrorString")
 #undef PF_SYM
-  return &r;
 }
 
 thread_local std::string g_derr;
