@@ -152,13 +152,31 @@ def main():
     # pair's compute (two result buffers, one gather in flight); the fence waits for the last one.
     og = None
     pfd = None
+    gather_note = ""
     if world > 1 or force_dist:
         # control plane only: rank 0's ncclUniqueId reaches the other ranks through torch.distributed; the gather itself runs
         # inside libpanoflow.so (pf_dist_*: grouped ncclSend/ncclRecv on its own HIP stream)
-        ids = [pf.dist_unique_id() if rank == 0 else None]
+        try:
+            ids = [pf.dist_unique_id() if rank == 0 else None]
+        except pf.PanoflowError as e:
+            ids = [None]; gather_note = str(e)
         dist.broadcast_object_list(ids, src=0)
-        pfd = pf.Dist(local_rank, ids[0], rank, world)
-        og = shard.RcclGather(out, pfd)
+        try:
+            pfd = pf.Dist(local_rank, ids[0], rank, world) if ids[0] is not None else None
+        except pf.PanoflowError as e:
+            pfd = None; gather_note = str(e)
+        # every rank must take the same path: agree on whether the library's communicator came up everywhere
+        okt = torch.tensor([1 if pfd is not None else 0], device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 1:
+            og = shard.RcclGather(out, pfd)
+        else:
+            # reported loudly in config.final_gather; the gather then goes through torch.distributed (still RCCL)
+            if pfd is not None:
+                pfd.close()
+            pfd = None
+            og = shard.OverlappedGather(out, world, rank)
+            gather_note = "pf_dist_* unavailable (%s): torch.distributed gather used instead" % (gather_note or "another rank failed")
     step_ms = []
 
     def step():
@@ -178,7 +196,10 @@ def main():
     def fence():
         if og:
             og.wait()
-            pfd.barrier()
+            if pfd:
+                pfd.barrier()
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -193,7 +214,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
-    dt = pfd.max(dt) if pfd else dt
+    dt = pfd.max(dt) if pfd else (shard.max_over_ranks(dt, dev) if og else dt)
     gathered_ok = None
     if og and rank == 0:
         # the strip this rank produced last must be what arrived in its own slot of the receive area
@@ -219,7 +240,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %dx%d overlap pair per GPU, %s, flow L->R + R->L + novel-view blend, %d pair(s) in flight per GPU" % (which, cols, rows, args.alg, max(1, args.concurrent)),
                        "levels": nlev, "level_pixels": P, "sweep_steps_per_direction": sweep_steps, "swept_steps_per_direction_in_gated_window": swept,
-                       "final_gather": ("rccl send/recv to rank 0 inside libpanoflow.so (pf_dist_*), overlapped with the next pair; rank-0 slot verified: %s" % gathered_ok) if og else "none"},
+                       "final_gather": ((gather_note or "rccl send/recv to rank 0 inside libpanoflow.so (pf_dist_*), overlapped with the next pair") + "; rank-0 slot verified: %s" % gathered_ok) if og else "none"},
             "ms_per_step_median": round(med_ms, 3), "value_at_median": round(npairs * mpix / (med_ms * 1e-3), 3),
         }
         # roofline of the dominant kernel (the exact wavefront sweep): algorithmic bytes per launch =
