@@ -51,7 +51,19 @@ constexpr int kWC = 64;      // window ring along the step axis (columns)
 #define PF_SWEEP_UNROLL 8
 #endif
 #ifndef PF_MARGIN
-#define PF_MARGIN(top) ((top) == 2 ? 1 : 0)   // extra columns to fall behind after catching up with the producer (measured: 0 inside a workgroup, 1 across)
+#ifndef PF_MARGIN_X
+#define PF_MARGIN_X 1
+#endif
+#ifndef PF_MARGIN_IN
+#define PF_MARGIN_IN 0
+#endif
+#define PF_MARGIN(top) ((top) == 2 ? PF_MARGIN_X : PF_MARGIN_IN)   // extra columns to fall behind after catching up with the producer (measured: 0 inside a workgroup, 1 across)
+#endif
+#ifndef PF_PUB_SLEEP
+#define PF_PUB_SLEEP 1    // publisher wave: s_sleep between two looks at the last band's step counter
+#endif
+#ifndef PF_POLL_SLEEP
+#define PF_POLL_SLEEP 1   // poller wave: s_sleep between two polls of the previous workgroup's granules
 #endif
 #define PF_STR2(x) #x
 #define PF_STR(x) PF_STR2(x)   // ~0.2 s of polling: a stuck band raises ctrl[1] instead of hanging the GPU
@@ -848,7 +860,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
         st_cnt(&sm.pubTail, pt);
         idle = 0;
       } else {
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(PF_PUB_SLEEP);
         if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
     }
@@ -886,7 +898,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
           idle = 0;
           continue;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(PF_POLL_SLEEP);
       } else {
         __builtin_amdgcn_s_sleep(8);
       }
