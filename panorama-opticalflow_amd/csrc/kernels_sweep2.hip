@@ -553,35 +553,18 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   return !dead;
 }
 
-// ------------------------------------------------------------------------------------------------
-// prepass: records in wavefront order.  rec[((band*nstepsPad + s)*8 + r)*3 + j] for the ACTIVE window of the sweep:
-// band counts from bandLo, step s handles sweep-order column uLo + s - r (columns [uLo, uHi)).
-//   j=0: (I0x, I0y, blurred.x, blurred.y)   j=1: (C.x, C.y, E(C), E(C+dx))   j=2: (E(C+dy), gate, 0, 0)
-//   gate: 1 = update (alpha0,alpha1 > 0.9), 0 = keep C, -1 = no pixel at this (step,row)
-// When the window does not start at the first band, the row above it never changes during this sweep: its flow
-// is written as the granule row the first workgroup's poller reads (top0).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g0, const float2* __restrict__ g1, const float2* __restrict__ blurred,
-                                                    const uint8_t* __restrict__ gate, const float2* __restrict__ flow, int W, int H, int forward,
-                                                    int transposed, int nstepsPad, int nbandsPad, float rW, float4* __restrict__ rec, int uLo, int uHi,
-                                                    int bandLo, unsigned long long* __restrict__ top0) {
-  const size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
+// One record of the prepass (slot = linear index in wavefront order, see k_sweep_prep): shared by the prepass kernel and by
+// the prepass blocks that ride inside the sweep launch (k_sweep2, MODE 2).
+__device__ __forceinline__ void d_make_record(size_t tid, size_t total, const float2* __restrict__ g0, const float2* __restrict__ g1,
+                                              const float2* __restrict__ blurred, const uint8_t* __restrict__ gate, const float2* __restrict__ flow, int W,
+                                              int H, int forward, int transposed, int nstepsPad, float rW, int uLo, int uHi, int bandLo, float4& a,
+                                              float4& b, float4& c) {
   const int LS = transposed ? H : W, LB = transposed ? W : H;   // extent along the step axis / across the bands
-  if (top0 != nullptr && tid < size_t(uHi - uLo)) {
-    const int ia = uLo + int(tid), ib = bandLo * kRows - 1;
-    const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;
-    const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
-    top0[tid] = pack2(flow[size_t(y) * W + x]);
-  }
-  // (no early return: the block stages its 256 records in LDS so that they leave as three fully coalesced 4 KB stores instead
-  // of 16-byte pieces at a 48-byte stride)
-  __shared__ float4 stage[256 * 3];
   const int r = int(tid % kRows);
   const int s = int((tid / kRows) % nstepsPad);
   const int band = int(tid / (size_t(kRows) * nstepsPad));
   const int ia = uLo + s - r, ib = (bandLo + band) * kRows + r;
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = make_float4(0.f, -1.0f, 0.f, 0.f);
+  a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; c = make_float4(0.f, -1.0f, 0.f, 0.f);
   if (tid < total && s - r >= 0 && ia < uHi && ia < LS && ib < LB) {
     const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;   // position in sweep order
     const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
@@ -598,6 +581,33 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
       c.y = 1.0f;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// prepass: records in wavefront order.  rec[((band*nstepsPad + s)*8 + r)*3 + j] for the ACTIVE window of the sweep:
+// band counts from bandLo, step s handles sweep-order column uLo + s - r (columns [uLo, uHi)).
+//   j=0: (I0x, I0y, blurred.x, blurred.y)   j=1: (C.x, C.y, E(C), E(C+dx))   j=2: (E(C+dy), gate, 0, 0)
+//   gate: 1 = update (alpha0,alpha1 > 0.9), 0 = keep C, -1 = no pixel at this (step,row)
+// When the window does not start at the first band, the row above it never changes during this sweep: its flow
+// is written as the granule row the first workgroup's poller reads (top0).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g0, const float2* __restrict__ g1, const float2* __restrict__ blurred,
+                                                    const uint8_t* __restrict__ gate, const float2* __restrict__ flow, int W, int H, int forward,
+                                                    int transposed, int nstepsPad, int nbandsPad, float rW, float4* __restrict__ rec, int uLo, int uHi,
+                                                    int bandLo, unsigned long long* __restrict__ top0) {
+  const size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
+  if (top0 != nullptr && tid < size_t(uHi - uLo)) {
+    const int ia = uLo + int(tid), ib = bandLo * kRows - 1;
+    const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;
+    const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
+    top0[tid] = pack2(flow[size_t(y) * W + x]);
+  }
+  // (no early return: the block stages its 256 records in LDS so that they leave as three fully coalesced 4 KB stores instead
+  // of 16-byte pieces at a 48-byte stride)
+  __shared__ float4 stage[256 * 3];
+  float4 a, b, c;
+  d_make_record(tid, total, g0, g1, blurred, gate, flow, W, H, forward, transposed, nstepsPad, rW, uLo, uHi, bandLo, a, b, c);
   stage[threadIdx.x * 3 + 0] = a; stage[threadIdx.x * 3 + 1] = b; stage[threadIdx.x * 3 + 2] = c;
   __syncthreads();
   const size_t base = size_t(blockIdx.x) * blockDim.x * 3, lim = total * 3;   // in float4 units
@@ -614,12 +624,48 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
 // granules, wave 10 drains results.  Waves land on SIMD (wave % 4): every compute wave shares its SIMD with its
 // own loader; three waves per SIMD cap the kernel at 168 VGPRs.
 // ------------------------------------------------------------------------------------------------
-template <bool TR, bool FWD, bool SPARSE, bool FUSED>
+// MODE 0: records come from k_sweep_prep (launched in front).  MODE 1: the loader waves compute them (experiment, slower).
+// MODE 2: the prepass rides INSIDE this launch -- blocks [nwgSweep, gridDim.x) compute the records in wavefront order (sweep
+// workgroup 0's first) and hand them over with the write-through + counter + acquire protocol of cdna_hip_programming.md G16/R1;
+// the first bands start a few microseconds after the launch instead of after a whole prepass kernel.
+template <bool TR, bool FWD, bool SPARSE, int MODE>
 __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
                                                 unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H,
                                                 int nstepsPad, int nbands, float rW, float rEps, int uLo, int LSv, int bandLo, long long budgetTicks,
-                                                const float2* __restrict__ g0, const float2* __restrict__ blurred, const uint8_t* __restrict__ gate) {
-  // FUSED (rec == nullptr): FUSED PREPASS -- the loader waves compute the records themselves (same expressions as k_sweep_prep) while they
+                                                const float2* __restrict__ g0, const float2* __restrict__ blurred, const uint8_t* __restrict__ gate,
+                                                int nwgSweep, int* __restrict__ prepcnt) {
+  if (MODE == 2 && int(blockIdx.x) >= nwgSweep) {
+    // ======================= prepass block (MODE 2): 704 records, written through to memory, then counted in =======================
+    const int slotsPerWG = kWaves * nstepsPad * kRows;
+    const size_t total = size_t(nwgSweep) * slotsPerWG;
+    const size_t first = size_t(int(blockIdx.x) - nwgSweep) * blockDim.x, slot = first + threadIdx.x;
+    float4 a, b, c;
+    d_make_record(slot, total, g0, g1, blurred, gate, flow, W, H, FWD ? 1 : 0, TR ? 1 : 0, nstepsPad, rW, uLo, uLo + LSv, bandLo, a, b, c);
+    if (slot < total) {
+      // sc1 (write-through) 16-byte stores through a buffer descriptor built from wave-uniform values (G16 R1)
+      typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+      const unsigned long long base = reinterpret_cast<unsigned long long>(rec);
+      const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(base)), hi = __builtin_amdgcn_readfirstlane(unsigned(base >> 32));
+      void* ubase = reinterpret_cast<void*>((unsigned long long)lo | ((unsigned long long)hi << 32));
+      const unsigned nbytes = __builtin_amdgcn_readfirstlane(unsigned(total * 48));
+      auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ubase, 0, int(nbytes), 0x00020000);
+      const unsigned off = unsigned(slot) * 48u;
+      __builtin_amdgcn_raw_buffer_store_b128(u4v{__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w)}, rsrc, off, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(u4v{__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), __float_as_uint(b.w)}, rsrc, off + 16u, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(u4v{__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), __float_as_uint(c.w)}, rsrc, off + 32u, 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores ...
+    __syncthreads();                                    // ... before ONE lane counts the block in
+    if (threadIdx.x == 0 && first < total) {
+      const size_t last = (first + blockDim.x < total ? first + blockDim.x : total) - 1;
+      const int k0 = int(first / slotsPerWG), k1 = int(last / slotsPerWG);
+      const int n = int(last - first + 1), n0 = k0 == k1 ? n : int(size_t(k0 + 1) * slotsPerWG - first);
+      __hip_atomic_fetch_add(&prepcnt[k0], n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (k1 != k0) __hip_atomic_fetch_add(&prepcnt[k1], n - n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  // FUSED (MODE 1): FUSED PREPASS -- the loader waves compute the records themselves (same expressions as k_sweep_prep) while they
   // run ahead of the wavefront: no prepass launch in front of the sweep, and the 2 x 48 B per level-pixel of record traffic
   // through HBM (written by the prepass, read back here) disappears.  A pixel's own flow C is read before its step is
   // computed and overwritten (by the drainer) only afterwards, so reading it from the plane being updated is safe.
@@ -694,7 +740,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
       const int x = FWD ? cxc : W - 1 - cxc, y = FWD ? cyc : H - 1 - cyc;
       return g1 + (y * W + x);
     };
-    constexpr bool fused = FUSED;
+    constexpr bool fused = MODE == 1;
     const float4* recw = fused ? nullptr : rec + size_t(band0 + w) * nstepsPad * (kRows * 3);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
@@ -703,6 +749,17 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
     const int lib = (bandLo + band0 + w) * kRows + lr;       // position across the bands (absolute)
     int rh = 0, idle = 0;
     bool first = true;
+    if (MODE == 2) {
+      // the records of this workgroup's four bands are complete when its counter has reached their number: ONE word polled
+      // relaxed, ONE agent acquire after the match (drops this CU's stale L1 lines), then plain loads (G16 R1)
+      const int need = kWaves * nstepsPad * kRows;
+      int spins = 0;
+      while (__hip_atomic_load(&prepcnt[wg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != need) {
+        __builtin_amdgcn_s_sleep(2);
+        if (spin_expired(spins, sm) || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     for (;;) {
       const int oh = first ? 0 : ld_cnt(&sm.outHead[w]);
       float4 va[kLoadAhead], vb[kLoadAhead], vc[kLoadAhead];
@@ -871,7 +928,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
   {
     if ((wg == 0 && !staticTop) || wave != 2 * kWaves + 1) return;
     const unsigned long long* bnd_in = boundary + size_t(wg) * LSv;
-    const bool topFromPlane = FUSED && wg == 0;   // (wg == 0 only gets here with a static top row)
+    const bool topFromPlane = MODE != 0 && wg == 0;   // (wg == 0 only gets here with a static top row)
     int bh = 0, idle = 0;
     while (bh < LSv) {
       const int oh0 = ld_cnt(&sm.outHead[0]);
@@ -913,6 +970,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
 static inline int wgs_for(int LB) { const int nbands = (LB + kRows - 1) / kRows; return (nbands + kWaves - 1) / kWaves; }
 static inline int steps_pad(int LS) { return ((LS + kRows - 1) + kChunk - 1) / kChunk * kChunk; }
 int sweep2_num_wgs(int H) { return wgs_for(H); }
+int sweep2_num_wgs_max(int W, int H) { const int a = wgs_for(W), b = wgs_for(H); return a > b ? a : b; }
 size_t sweep2_boundary_elems(int W, int H) {   // hand-off granules of one sweep launch, either orientation (+1 row: the static row above the window)
   const size_t a = size_t(wgs_for(H) + 1) * W, b = size_t(wgs_for(W) + 1) * H;
   return a > b ? a : b;
@@ -930,22 +988,26 @@ void launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
   const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
   const size_t prepThreads = total > size_t(LSv) ? total : size_t(LSv);
   const float rW = (float)(1.0 / (double)(float)a.W), rEps = (float)(1.0 / (double)kGradEpsilon);
-  // PANOFLOW_FUSED_PREP=1: no prepass kernel, the loader waves compute the records themselves (no record traffic through HBM,
-  // one launch fewer per sweep).  Bit-identical, but measured 8 % SLOWER (profiles/r02_fused_prepass_ab.txt): ~900 extra VALU
-  // instructions per round on the SIMD a latency-critical compute wave lives on.  Off by default; kept as an experiment switch.
-  static const bool fusedPrep = [] { const char* e = getenv("PANOFLOW_FUSED_PREP"); return e && atoi(e) == 1; }();
-  if (!fusedPrep)
+  // How the records reach the sweep (PANOFLOW_PREP).  0 (default): k_sweep_prep in front of the sweep.  Two measured and rejected
+  // alternatives stay behind the switch, both bit-identical: 1 = the loader waves compute them (no record traffic through HBM, but
+  // 8 % slower: profiles/r02_fused_prepass_ab.txt); 2 = prepass blocks inside the sweep launch with a write-through + counter +
+  // acquire hand-off (the first bands start microseconds after the launch, yet the launch as a whole is not shorter: same file).
+  static const int prepMode = [] { const char* e = getenv("PANOFLOW_PREP"); const int m = e ? atoi(e) : 0; return (m < 0 || m > 2) ? 0 : m; }();
+  const int mode = (prepMode == 2 && (a.prepcnt == nullptr || total * 48 >= (size_t(1) << 31))) ? 0 : prepMode;
+  if (mode == 0)
     hipLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((prepThreads + 255) / 256)), dim3(256), 0, st, a.g0, a.g1, a.blurred, a.gate, a.flow, a.W, a.H, a.forward, tr,
                        nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo, bandLo > 0 ? a.boundary : nullptr);
   // wall-clock budget of every wait inside the launch, in 100 MHz ticks: 2 s + 1000 x the expected duration (~0.5 us per step)
   const long long budget = 200000000ll + 1000ll * 50ll * (long long)(nstepsPad + 9 * nbands);
-  const dim3 grid(nwg), block(64 * (2 * kWaves + 3));
-  const float4* r4 = fusedPrep ? nullptr : reinterpret_cast<const float4*>(rec);
-#define PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, FUV) hipLaunchKernelGGL((k_sweep2<TRV, FWV, SPV, FUV>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.g0, a.blurred, a.gate)
-#define PF_LAUNCH_SWEEP2(TRV, FWV) do { if (a.sparse) { if (fusedPrep) PF_LAUNCH_SWEEP2_(TRV, FWV, true, true); else PF_LAUNCH_SWEEP2_(TRV, FWV, true, false); } \
-    else { if (fusedPrep) PF_LAUNCH_SWEEP2_(TRV, FWV, false, true); else PF_LAUNCH_SWEEP2_(TRV, FWV, false, false); } } while (0)
+  const unsigned nthreads = 64 * (2 * kWaves + 3);
+  const dim3 grid(mode == 2 ? nwg + (unsigned)((total + nthreads - 1) / nthreads) : nwg), block(nthreads);
+  const float4* r4 = mode == 1 ? nullptr : reinterpret_cast<const float4*>(rec);
+#define PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, MDV) hipLaunchKernelGGL((k_sweep2<TRV, FWV, SPV, MDV>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.g0, a.blurred, a.gate, nwg, a.prepcnt)
+#define PF_LAUNCH_SWEEP2__(TRV, FWV, SPV) do { if (mode == 2) PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 2); else if (mode == 1) PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 1); else PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 0); } while (0)
+#define PF_LAUNCH_SWEEP2(TRV, FWV) do { if (a.sparse) PF_LAUNCH_SWEEP2__(TRV, FWV, true); else PF_LAUNCH_SWEEP2__(TRV, FWV, false); } while (0)
   if (tr) { if (a.forward) PF_LAUNCH_SWEEP2(true, true); else PF_LAUNCH_SWEEP2(true, false); }
   else { if (a.forward) PF_LAUNCH_SWEEP2(false, true); else PF_LAUNCH_SWEEP2(false, false); }
+#undef PF_LAUNCH_SWEEP2__
 #undef PF_LAUNCH_SWEEP2_
 #undef PF_LAUNCH_SWEEP2
 }

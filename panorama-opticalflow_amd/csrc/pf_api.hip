@@ -173,16 +173,17 @@ int check_dims(pf_ctx* c, int cols, int rows, int pad) {
 struct LevelBufs { float *flow_a, *flow_b, *blurred, *tmp, *rec; };
 // box = bounding box (min x, min y, max x, max y) of the gated pixels of this level, or nullptr for "everything"
 void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, const float* a0, const float* a1, const uint8_t* gate, int w, int h, int sparse,
-               const int* box, const LevelBufs& b, unsigned long long* bnd_fwd, unsigned long long* bnd_bwd, int* ctrl_fwd, int* ctrl_bwd, float** result) {
+               const int* box, const LevelBufs& b, unsigned long long* bnd_fwd, unsigned long long* bnd_bwd, int* ctrl_fwd, int* ctrl_bwd, float** result,
+               int* pc_fwd = nullptr, int* pc_bwd = nullptr) {
   { PROF(c, st, "gauss15_blurredFlow"); launch_gauss15(st, b.flow_a, b.tmp, b.blurred, w, h, c->g15); }
   SweepArgs sa;
   sa.g0 = reinterpret_cast<const float2*>(g0); sa.g1 = reinterpret_cast<const float2*>(g1);
   sa.blurred = reinterpret_cast<const float2*>(b.blurred); sa.gate = gate; sa.W = w; sa.H = h; sa.sparse = sparse;
   if (box) { sa.ax0 = box[0]; sa.ay0 = box[1]; sa.ax1 = box[2] + 1; sa.ay1 = box[3] + 1; }   // empty (max < min): the sweeps are the identity
   auto sweep = [&](const SweepArgs& a) { if (c->sweep_version == 1) launch_sweep(st, a); else launch_sweep2(st, a, b.rec); };
-  { PROF(c, st, "sweep"); sa.flow = reinterpret_cast<float2*>(b.flow_a); sa.boundary = bnd_fwd; sa.ctrl = ctrl_fwd; sa.forward = 1; sweep(sa); }
+  { PROF(c, st, "sweep"); sa.flow = reinterpret_cast<float2*>(b.flow_a); sa.boundary = bnd_fwd; sa.ctrl = ctrl_fwd; sa.prepcnt = pc_fwd; sa.forward = 1; sweep(sa); }
   { PROF(c, st, "median5"); launch_median5(st, b.flow_a, b.flow_b, w, h); }
-  { PROF(c, st, "sweep"); sa.flow = reinterpret_cast<float2*>(b.flow_b); sa.boundary = bnd_bwd; sa.ctrl = ctrl_bwd; sa.forward = 0; sweep(sa); }
+  { PROF(c, st, "sweep"); sa.flow = reinterpret_cast<float2*>(b.flow_b); sa.boundary = bnd_bwd; sa.ctrl = ctrl_bwd; sa.prepcnt = pc_bwd; sa.forward = 0; sweep(sa); }
   { PROF(c, st, "median5"); launch_median5(st, b.flow_b, b.flow_a, w, h); }
   { PROF(c, st, "gauss15_diffusion"); launch_gauss15_mix(st, b.flow_a, b.tmp, a0, a1, w, h, c->g15, b.flow_b); }
   *result = b.flow_b;
@@ -208,6 +209,7 @@ struct SolveBufs {
   uint8_t* gate; float* half_tmp;
   std::vector<size_t> bnd_off; size_t bnd_total;
   LevelBufs lb[2]; unsigned long long* bnd[2]; int* ctrl[2]; float* ratio[2];
+  int* prepcnt[2]; std::vector<size_t> pc_off; size_t pc_total;   // per sweep launch: one "records ready" counter per sweep workgroup
 };
 int alloc_solve(pf_ctx* c, const Geometry& g, int ndirs, SolveBufs& b) {
   const size_t n0 = size_t(g.w0) * g.h0;
@@ -223,6 +225,9 @@ int alloc_solve(pf_ctx* c, const Geometry& g, int ndirs, SolveBufs& b) {
   b.bnd_off.assign(g.n, 0);
   b.bnd_total = 0;
   for (int l = 0; l < g.n; ++l) { b.bnd_off[l] = b.bnd_total; b.bnd_total += sweep_boundary_elems(g.ws[l], g.hs[l]); }
+  b.pc_off.assign(g.n, 0);
+  b.pc_total = 0;
+  for (int l = 0; l < g.n; ++l) { b.pc_off[l] = b.pc_total; b.pc_total += 2 * size_t(sweep2_num_wgs_max(g.ws[l], g.hs[l])); }   // forward + backward sweep
   const char* nb[2][8] = {{"d0_flow_a", "d0_flow_b", "d0_blurred", "d0_tmp", "d0_bnd", "d0_ctrl", "d0_ratio", "d0_rec"},
                           {"d1_flow_a", "d1_flow_b", "d1_blurred", "d1_tmp", "d1_bnd", "d1_ctrl", "d1_ratio", "d1_rec"}};
   for (int d = 0; d < ndirs; ++d) {
@@ -231,6 +236,8 @@ int alloc_solve(pf_ctx* c, const Geometry& g, int ndirs, SolveBufs& b) {
     b.bnd[d] = (unsigned long long*)ensure(c, nb[d][4], b.bnd_total * 2 * 8);
     b.ctrl[d] = (int*)ensure(c, nb[d][5], size_t(g.n) * 2 * 2 * sizeof(int));
     b.ratio[d] = (float*)ensure(c, nb[d][6], 256);
+    b.prepcnt[d] = (int*)ensure(c, d == 0 ? "d0_prepcnt" : "d1_prepcnt", b.pc_total * sizeof(int));
+    if (!b.prepcnt[d]) return PF_ERR_NOMEM;
     b.lb[d].rec = (float*)ensure(c, nb[d][7], sweep2_rec_bytes(g.w0, g.h0));
     if (!b.lb[d].rec) return PF_ERR_NOMEM;
     if (!b.lb[d].flow_a || !b.lb[d].flow_b || !b.lb[d].blurred || !b.lb[d].tmp || !b.bnd[d] || !b.ctrl[d] || !b.ratio[d]) return PF_ERR_NOMEM;
@@ -329,6 +336,7 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
     PROF(c, sm, "init_handoff");
     launch_fill_u64(sm, bnd[d], bnd_total * 2, kNotReady);
     HIPCHK(c, hipMemsetAsync(ctrl[d], 0, size_t(g.n) * 2 * 2 * sizeof(int), sm));
+    HIPCHK(c, hipMemsetAsync(sb.prepcnt[d], 0, sb.pc_total * sizeof(int), sm));
   }
   HIPCHK(c, hipEventRecord(c->ev_pre, sm));
   if (have_table && split > 0) { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], table, 0, g.off[split], c->g3_05); }
@@ -377,7 +385,8 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
     float* res = nullptr;
     run_level(c, st, grad[i0] + 2 * o, grad[i1] + 2 * o, pyrA[i0] + o, pyrA[i1] + o, gate + o, w, h, sparse, boxes.empty() ? nullptr : &boxes[4 * level], b,
               bnd[d] + bnd_off[level],
-              bnd[d] + bnd_total + bnd_off[level], ctrl[d] + level * 4, ctrl[d] + level * 4 + 2, &res);
+              bnd[d] + bnd_total + bnd_off[level], ctrl[d] + level * 4, ctrl[d] + level * 4 + 2, &res,
+              sb.prepcnt[d] + sb.pc_off[level], sb.prepcnt[d] + sb.pc_off[level] + sweep2_num_wgs_max(w, h));
     if (level > 0) {
       PROF(c, st, "upsample_cubic");
       launch_upsample_cubic(st, res, w, h, b.flow_a, g.ws[level - 1], g.hs[level - 1], 1.0f / kPyrScaleFactor);
@@ -944,7 +953,10 @@ int pf_stage_sweep(pf_ctx* c, const float* g0, const float* g1, const float* blu
   launch_gate(sm, da0, da1, (int)n, gate);
   launch_fill_u64(sm, bnd, nb, kNotReady);
   HIPCHK(c, hipMemsetAsync(ctrl, 0, 16, sm));
-  SweepArgs sa; sa.g0 = (const float2*)dg0; sa.g1 = (const float2*)dg1; sa.blurred = (const float2*)dbl; sa.gate = gate; sa.flow = (float2*)df;
+  int* pcnt = (int*)ensure(c, "sg_pc", 2 * size_t(sweep2_num_wgs_max(w, h)) * sizeof(int));
+  if (!pcnt) return PF_ERR_NOMEM;
+  HIPCHK(c, hipMemsetAsync(pcnt, 0, 2 * size_t(sweep2_num_wgs_max(w, h)) * sizeof(int), sm));
+  SweepArgs sa; sa.prepcnt = pcnt; sa.g0 = (const float2*)dg0; sa.g1 = (const float2*)dg1; sa.blurred = (const float2*)dbl; sa.gate = gate; sa.flow = (float2*)df;
   sa.boundary = bnd; sa.ctrl = ctrl; sa.W = w; sa.H = h; sa.forward = forward; sa.sparse = (w * h) % 2;   // stage test: exercise both variants
   {
     std::vector<int> box; LevelTable t; t.n = 1; t.w[0] = w; t.h[0] = h; t.off[0] = 0;
@@ -1020,7 +1032,11 @@ int pf_stage_level(pf_ctx* c, const float* i0, const float* i1, const float* a0,
   float* res = nullptr;
   std::vector<int> box;
   { LevelTable t; t.n = 1; t.w[0] = w; t.h[0] = h; t.off[0] = 0; if (int e = gate_boxes_to_host(c, sm, gate, t, n, box)) return e; }
-  run_level(c, sm, g0, g1, da0, da1, gate, w, h, (w + h) % 2, box.data(), b, bnd, bnd + nb, ctrl, ctrl + 2, &res);
+  const size_t npc = size_t(sweep2_num_wgs_max(w, h));
+  int* pcnt = (int*)ensure(c, "sg_pc", 2 * npc * sizeof(int));
+  if (!pcnt) return PF_ERR_NOMEM;
+  HIPCHK(c, hipMemsetAsync(pcnt, 0, 2 * npc * sizeof(int), sm));
+  run_level(c, sm, g0, g1, da0, da1, gate, w, h, (w + h) % 2, box.data(), b, bnd, bnd + nb, ctrl, ctrl + 2, &res, pcnt, pcnt + npc);
   int hc[4] = {0, 0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(hc, ctrl, 16, hipMemcpyDeviceToHost, sm));
   if (int e = stage_down(c, flow_out, res, n * 8)) return e;

@@ -115,11 +115,13 @@ struct SweepArgs {
   int* ctrl;              // [0] ticket, [1] abort/timeout flag
   int W, H, forward;
   int sparse;             // few pixels gated (full-canvas inputs): use the kernel variant that skips ungated anti-diagonals
+  int* prepcnt = nullptr; // v2 sweep, prepass inside the launch: one counter per sweep workgroup (sweep2_num_wgs_max ints), ZEROED before the launch
   int ax0 = 0, ay0 = 0, ax1 = 1 << 30, ay1 = 1 << 30;   // bounding box [ax0,ax1) x [ay0,ay1) of the gated pixels (default: everything); v2 sweep only
 };
 size_t sweep_boundary_elems(int W, int H);   // hand-off granules needed per sweep launch (covers both sweep kernels)
 void launch_sweep(hipStream_t st, const SweepArgs& a);          // v1: 64 rows per wave, kept as a cross-check (PANOFLOW_SWEEP=1)
 int sweep2_num_wgs(int H);
+int sweep2_num_wgs_max(int W, int H);          // workgroups a sweep launch on a W x H level can have (either band orientation)
 size_t sweep2_boundary_elems(int W, int H);   // granules one sweep launch may need (either band orientation)
 size_t sweep2_rec_bytes(int W, int H);
 void launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec);  // v2: prepass + 8 lanes/pixel + helper wave
