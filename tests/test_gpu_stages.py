@@ -268,3 +268,37 @@ def test_level_fuzz_alpha_patterns(ctx, orc):
         ref = orc.level(I0, I1, A0, A1, fin, 0, 0)
         got = ctx.stage_level(I0, I1, A0, A1, fin, 0, 0)
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "case %d (%dx%d): %d mismatches" % (case, w, h, (got.view(np.uint32) != ref.view(np.uint32)).sum())
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_sweep_record_experiment_paths_are_bit_identical(mode):
+    """PANOFLOW_PREP=1 (loader waves compute the records) and =2 (prepass blocks inside the sweep launch, G16/R1 hand-off) are
+    rejected-on-measurement alternatives kept behind a switch; they must stay exact.  The switch is read once per process."""
+    import os, subprocess, sys
+    code = r'''
+import sys, os, numpy as np
+sys.path.insert(0, "tests"); sys.path.insert(0, "oracle")
+from conftest import load_pkg_module
+import orc
+pf = load_pkg_module("pyabi")
+c = pf.Context(0)
+for (w, h, fwd) in [(150, 131, 1), (64, 257, 0), (300, 90, 1)]:
+    r = np.random.default_rng(7 + w + fwd)
+    img0 = r.random((h, w)).astype(np.float32); img1 = np.roll(img0, 2, axis=1) + 0.05 * r.random((h, w)).astype(np.float32)
+    g0 = np.stack(orc.gradients(img0), -1); g1 = np.stack(orc.gradients(img1), -1)
+    flow = (r.standard_normal((h, w, 2)) * 1.5).astype(np.float32)
+    bl = orc.gaussian_blur(flow, 15, 8.0)
+    a0 = np.ones((h, w), np.float32); a1 = np.ones((h, w), np.float32); a0[h // 3: h // 3 + 9, w // 4: w // 2] = 0.5; a1[:, :3] = 0.0
+    ref = orc.sweep(g0[..., 0], g0[..., 1], g1[..., 0], g1[..., 1], bl, a0, a1, flow, fwd)
+    got = c.stage_sweep(g0, g1, bl, a0, a1, flow, fwd)
+    assert np.array_equal(got, ref), (w, h, fwd)
+L, R, blend = load_pkg_module("synth").make_pair_np(320, 256, 4321)
+f0, f1 = c.flow_bidir(L, R, 20)
+r0, r1 = orc.flow_bidir(L, R, 20)
+assert np.array_equal(f0, r0) and np.array_equal(f1, r1)
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PANOFLOW_PREP=mode)
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
