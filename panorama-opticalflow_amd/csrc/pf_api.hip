@@ -290,9 +290,8 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   *c->h_status = 0;
   hipStream_t sm = c->s_main;
   // --- shared front end on the main stream: half-res planes, pyramids, gradients + gate of ALL levels.
-  // (Measured and rejected: the alpha path on a second stream -- alpha pyramids, gate, boxes beside the grey path.  The
-  // front end is bound by the HOST enqueueing its ~45 small launches, not by the GPU, so doubling the pyramid launches
-  // cost +0.3 ms per pair; profiles/r02_frontend_ab.txt.) ---
+  // (Measured and rejected: the alpha path on a second stream -- alpha pyramids, gate, boxes beside the grey path: +0.3 ms
+  // per pair with 72 instead of 36 small pyramid launches in front of the boxes; profiles/r02_frontend_ab.txt.) ---
   const uint8_t* imgs[2] = {d_img0, d_img1};
   hipStream_t sg = sm;
   for (int i = 0; i < 2; ++i) {
