@@ -25,6 +25,7 @@
 //     arithmetic that a loop-carried register or an immediate can replace, no LDS-order stalls).
 // Workgroups take their band index from an atomic ticket (a band only waits for bands already
 // running), every spin is bounded and raises ctrl[1] instead of hanging.
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 
 #include "pf_common.hpp"
@@ -979,10 +980,10 @@ size_t sweep2_rec_bytes(int W, int H) {
   const size_t a = size_t(wgs_for(H)) * kWaves * steps_pad(W), b = size_t(wgs_for(W)) * kWaves * steps_pad(H);
   return (a > b ? a : b) * kRows * 48;
 }
-void launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
+bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
   // active window: bounding box of the gated pixels (pixels outside it are not updated by this sweep and keep their flow)
   const SweepWindow win = make_sweep_window(a.W, a.H, a.forward, a.ax0, a.ay0, a.ax1, a.ay1, kRows, kWaves, kChunk);
-  if (win.empty) return;   // nothing to update: the sweep is the identity
+  if (win.empty) return false;   // nothing to update: the sweep is the identity
   const int tr = win.tr, uLo = win.uLo, uHi = win.uHi, LSv = win.LSv, bandLo = win.bandLo, nbands = win.nbands;
   const int nwg = win.nwg, nbandsPad = nwg * kWaves, nstepsPad = win.nstepsPad;
   const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
@@ -995,19 +996,22 @@ void launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
   static const int prepMode = [] { const char* e = getenv("PANOFLOW_PREP"); const int m = e ? atoi(e) : 0; return (m < 0 || m > 2) ? 0 : m; }();
   const int mode = (prepMode == 2 && (a.prepcnt == nullptr || total * 48 >= (size_t(1) << 31))) ? 0 : prepMode;
   if (mode == 0)
-    hipLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((prepThreads + 255) / 256)), dim3(256), 0, st, a.g0, a.g1, a.blurred, a.gate, a.flow, a.W, a.H, a.forward, tr,
-                       nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo, bandLo > 0 ? a.boundary : nullptr);
+    hipExtLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((prepThreads + 255) / 256)), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate, a.flow,
+                          a.W, a.H, a.forward, tr, nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo,
+                          bandLo > 0 ? a.boundary : (unsigned long long*)nullptr);
+  hipEvent_t evs = mode == 0 ? nullptr : a.ev_start;   // without a prepass kernel the sweep launch carries both events
   // wall-clock budget of every wait inside the launch, in 100 MHz ticks: 2 s + 1000 x the expected duration (~0.5 us per step)
   const long long budget = 200000000ll + 1000ll * 50ll * (long long)(nstepsPad + 9 * nbands);
   const unsigned nthreads = 64 * (2 * kWaves + 3);
   const dim3 grid(mode == 2 ? nwg + (unsigned)((total + nthreads - 1) / nthreads) : nwg), block(nthreads);
   const float4* r4 = mode == 1 ? nullptr : reinterpret_cast<const float4*>(rec);
-#define PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, MDV) hipLaunchKernelGGL((k_sweep2<TRV, FWV, SPV, MDV>), grid, block, 0, st, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.g0, a.blurred, a.gate, nwg, a.prepcnt)
+#define PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, MDV) hipExtLaunchKernelGGL((k_sweep2<TRV, FWV, SPV, MDV>), grid, block, 0, st, evs, a.ev_stop, 0, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.g0, a.blurred, a.gate, nwg, a.prepcnt)
 #define PF_LAUNCH_SWEEP2__(TRV, FWV, SPV) do { if (mode == 2) PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 2); else if (mode == 1) PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 1); else PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 0); } while (0)
 #define PF_LAUNCH_SWEEP2(TRV, FWV) do { if (a.sparse) PF_LAUNCH_SWEEP2__(TRV, FWV, true); else PF_LAUNCH_SWEEP2__(TRV, FWV, false); } while (0)
   if (tr) { if (a.forward) PF_LAUNCH_SWEEP2(true, true); else PF_LAUNCH_SWEEP2(true, false); }
   else { if (a.forward) PF_LAUNCH_SWEEP2(false, true); else PF_LAUNCH_SWEEP2(false, false); }
 #undef PF_LAUNCH_SWEEP2__
+  return true;
 #undef PF_LAUNCH_SWEEP2_
 #undef PF_LAUNCH_SWEEP2
 }

@@ -115,6 +115,9 @@ struct SweepArgs {
   int* ctrl;              // [0] ticket, [1] abort/timeout flag
   int W, H, forward;
   int sparse;             // few pixels gated (full-canvas inputs): use the kernel variant that skips ungated anti-diagonals
+  // optional timing events (v2 sweep): attached to the launches themselves (hipExtLaunchKernel: start of the prepass / end of the
+  // sweep kernel come from the dispatch packets' own timestamps), so that timing a sweep puts no marker packets on its stream
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   int* prepcnt = nullptr; // v2 sweep, prepass inside the launch: one counter per sweep workgroup (sweep2_num_wgs_max ints), ZEROED before the launch
   int ax0 = 0, ay0 = 0, ax1 = 1 << 30, ay1 = 1 << 30;   // bounding box [ax0,ax1) x [ay0,ay1) of the gated pixels (default: everything); v2 sweep only
 };
@@ -124,7 +127,7 @@ int sweep2_num_wgs(int H);
 int sweep2_num_wgs_max(int W, int H);          // workgroups a sweep launch on a W x H level can have (either band orientation)
 size_t sweep2_boundary_elems(int W, int H);   // granules one sweep launch may need (either band orientation)
 size_t sweep2_rec_bytes(int W, int H);
-void launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec);  // v2: prepass + 8 lanes/pixel + helper wave
+bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec);  // v2: prepass + 8 lanes/pixel + helper waves; false = empty window, nothing launched
 // coarsest-level search
 void launch_adjust_initial_flow(hipStream_t st, const float* i0, const float* i1, const float* a0, const float* a1, int w, int h, int hint,
                                 int max_pct, float* i1eq_tmp, float* flow);
