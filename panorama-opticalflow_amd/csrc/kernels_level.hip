@@ -246,52 +246,67 @@ __global__ __launch_bounds__(256) void k_gauss15_col(const float2* __restrict__ 
 // 7-pixel ring (reflect-101 on both indices) is loaded once, coalesced, into LDS; (2) the row pass (RowFilter: plain
 // left-to-right accumulation) of the 46 rows the column pass needs goes from LDS to LDS; (3) the column pass
 // (SymmColumnFilter: centre, then symmetric pairs outward) reads LDS.  Same operations in the same order as the two-kernel
-// form => identical bits; one launch instead of two, every source pixel read ~1.7x instead of 15x + 15x, and no round trip
-// of the row-pass plane through HBM.  MIX fuses lowAlphaFlowDiffusion's alpha mix (PixFlow.hpp:396-403) into the epilogue.
+// form => identical bits.  Both passes are register-blocked along their filter axis -- a thread reads a run of 16 + 14 (row
+// pass) or 8 + 14 (column pass) values once and produces 16 / 8 outputs from registers, 1.9 / 2.75 LDS reads per output
+// instead of 15 -- because the first fused version was bound by LDS bandwidth.  In the row pass a wave's lanes run along y
+// (one source row each), so the LDS row strides are odd numbers of float2 (79, 65): at most 2-way bank conflicts.
+// MIX fuses lowAlphaFlowDiffusion's alpha mix (PixFlow.hpp:396-403) into the epilogue.
 constexpr int kG15TX = 64, kG15TY = 32, kG15R = 7;
 template <bool MIX>
 __global__ __launch_bounds__(256) void k_gauss15_fused(const float2* __restrict__ src, float2* __restrict__ dst, int w, int h, Gauss g,
                                                         const float* __restrict__ a0, const float* __restrict__ a1) {
   constexpr int SW = kG15TX + 2 * kG15R, SH = kG15TY + 2 * kG15R;   // 78 x 46
-  __shared__ float2 srct[SH][SW + 1];
-  __shared__ float2 rowp[SH][kG15TX];
+  constexpr int SS = SW + 1, RS = kG15TX + 1;                        // LDS row strides in float2: 79, 65 (odd); 53 KB in all: three blocks per CU
+  __shared__ float2 srct[SH * SS];
+  __shared__ float2 rowp[SH * RS];
   const int x0 = blockIdx.x * kG15TX, y0 = blockIdx.y * kG15TY;
   const int rowsNeeded = min(SH, h + kG15R - (y0 - kG15R));   // rows past (h - 1) + 7 are read by no output of this tile
   // ---- (1) source tile ----
   for (int t = threadIdx.x; t < rowsNeeded * SW; t += 256) {
     const int r = t / SW, cidx = t - r * SW;
-    srct[r][cidx] = src[size_t(d_reflect101(y0 - kG15R + r, h)) * w + d_reflect101(min(x0 - kG15R + cidx, w - 1 + kG15R), w)];
+    srct[r * SS + cidx] = src[size_t(d_reflect101(y0 - kG15R + r, h)) * w + d_reflect101(min(x0 - kG15R + cidx, w - 1 + kG15R), w)];
   }
   __syncthreads();
-  // ---- (2) row pass ----
-  const int tx = threadIdx.x & (kG15TX - 1), ty4 = threadIdx.x >> 6;   // 64 columns x 4 row groups
-  for (int j = ty4; j < rowsNeeded; j += 4) {
-    float2 v = srct[j][tx];
-    float sx = g.k[0] * v.x, sy = g.k[0] * v.y;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // ---- (2) row pass: lane = source row (46 of 64 lanes), wave = 16 output columns; 30 values -> 16 outputs ----
+  if (lane < rowsNeeded) {
+    const float2* sr = srct + lane * SS + wv * 16;
+    float2 v[30];
 #pragma unroll
-    for (int t = 1; t < 15; ++t) {
-      v = srct[j][tx + t];
-      sx += g.k[t] * v.x; sy += g.k[t] * v.y;
+    for (int t = 0; t < 30; ++t) v[t] = sr[t];
+    float2* rp = rowp + lane * RS + wv * 16;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      float sx = g.k[0] * v[o].x, sy = g.k[0] * v[o].y;
+#pragma unroll
+      for (int t = 1; t < 15; ++t) { sx += g.k[t] * v[o + t].x; sy += g.k[t] * v[o + t].y; }
+      rp[o] = make_float2(sx, sy);
     }
-    rowp[j][tx] = make_float2(sx, sy);
   }
   __syncthreads();
-  const int x = x0 + tx;
+  // ---- (3) column pass: lane = column, wave = 8 output rows; 22 values -> 8 outputs.  The row pass of source row
+  // reflect101(y + d) sits at LDS row (y - y0) + 7 + d ----
+  const int x = x0 + lane;
   if (x >= w) return;
-  // ---- (3) column pass: the row pass of source row reflect101(y + d) sits at LDS row (y - y0) + 7 + d ----
-  for (int oy = ty4; oy < kG15TY; oy += 4) {
-    const int y = y0 + oy;
+  const int oy0 = wv * 8;
+  if (y0 + oy0 >= h) return;
+  float2 cv[22];
+#pragma unroll
+  for (int t = 0; t < 22; ++t) cv[t] = (oy0 + t < rowsNeeded) ? rowp[(oy0 + t) * RS + lane] : make_float2(0.f, 0.f);
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    const int y = y0 + oy0 + o;
     if (y >= h) break;
-    const float2 c = rowp[oy + kG15R][tx];
+    const float2 c = cv[o + kG15R];
     float sx = g.k[7] * c.x + 0.0f, sy = g.k[7] * c.y + 0.0f;
 #pragma unroll
     for (int j = 1; j <= 7; ++j) {
-      const float2 a = rowp[oy + kG15R + j][tx], b = rowp[oy + kG15R - j][tx];
+      const float2 a = cv[o + kG15R + j], b = cv[o + kG15R - j];
       sx += g.k[7 + j] * (a.x + b.x); sy += g.k[7 + j] * (a.y + b.y);
     }
     const size_t i = size_t(y) * w + x;
     if (MIX) {
-      const float2 f = srct[oy + kG15R][tx + kG15R];
+      const float2 f = srct[(oy0 + o + kG15R) * SS + lane + kG15R];
       const float diffusionCoef = 1.0f - a0[i] * a1[i];
       dst[i] = make_float2(diffusionCoef * sx + (1.0f - diffusionCoef) * f.x, diffusionCoef * sy + (1.0f - diffusionCoef) * f.y);
     } else {
