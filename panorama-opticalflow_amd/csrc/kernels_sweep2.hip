@@ -1016,4 +1016,6 @@ bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
 #undef PF_LAUNCH_SWEEP2
 }
 
+#include "kernels_relax.inl"
+
 }  // namespace pf

@@ -185,11 +185,12 @@ void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, cons
   // roofline needs per-launch HIP events inside its timed region, so ~0.2 ms of every timed step is the measurement itself.
   auto sweep = [&](SweepArgs& a) {
     if (c->sweep_version == 1) { PROF(c, st, "sweep"); launch_sweep(st, a); return; }
-    if (!c->prof) { launch_sweep2(st, a, b.rec); return; }
+    const bool relax = c->sweep_version == 3;
+    if (!c->prof) { if (relax) launch_sweep_relax(st, a); else launch_sweep2(st, a, b.rec); return; }
     ProfPending p;
     { std::lock_guard<std::mutex> lk(c->prof_mu); p.id = prof_id(c, "sweep"); p.a = prof_event(c); p.b = prof_event(c); }
     a.ev_start = p.a; a.ev_stop = p.b;
-    const bool launched = launch_sweep2(st, a, b.rec);
+    const bool launched = relax ? launch_sweep_relax(st, a) : launch_sweep2(st, a, b.rec);
     a.ev_start = nullptr; a.ev_stop = nullptr;
     std::lock_guard<std::mutex> lk(c->prof_mu);
     if (launched) c->prof_pending.push_back(p); else { c->ev_pool.push_back(p.a); c->ev_pool.push_back(p.b); }
@@ -502,7 +503,7 @@ pf_ctx* pf_create(int device, int max_cols, int max_rows) {
        hipHostGetDevicePointer((void**)&c->d_gate, c->h_gate, 0) == hipSuccess;
   if (ok) { *c->h_status = 0; memset(c->h_gate, 0, (4 * kLevelTableMax + 2) * sizeof(int)); }
   if (!ok) { fail(nullptr, PF_ERR_DEVICE, "stream/event creation failed"); delete c; return nullptr; }
-  if (const char* sv = getenv("PANOFLOW_SWEEP")) c->sweep_version = atoi(sv) == 1 ? 1 : 2;
+  if (const char* sv = getenv("PANOFLOW_SWEEP")) { const int v = atoi(sv); c->sweep_version = (v == 1 || v == 3) ? v : 2; }
   c->g5 = make_gauss(5, 0.25); c->g3_05 = make_gauss(3, 0.5); c->g3_1 = make_gauss(3, 1.0); c->g15 = make_gauss(15, 8.0);
   // Pre-sizing: every buffer a bidirectional solve / a stitch step on max_cols x max_rows needs is
   // allocated now, so that the first call does not pay ~40 hipMallocs.  0 x 0 = allocate lazily (the arena only grows).
@@ -977,7 +978,7 @@ int pf_stage_sweep(pf_ctx* c, const float* g0, const float* g1, const float* blu
   }
   float* rec = (float*)ensure(c, "sg_rec", sweep2_rec_bytes(w, h));
   if (!rec) return PF_ERR_NOMEM;
-  { PROF(c, sm, "sweep"); if (c->sweep_version == 1) launch_sweep(sm, sa); else (void)launch_sweep2(sm, sa, rec); }
+  { PROF(c, sm, "sweep"); if (c->sweep_version == 1) launch_sweep(sm, sa); else if (c->sweep_version == 3) (void)launch_sweep_relax(sm, sa); else (void)launch_sweep2(sm, sa, rec); }
   int hc[4] = {0, 0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(hc, ctrl, 16, hipMemcpyDeviceToHost, sm));
   if (int e = stage_down(c, flow, df, n * 8)) return e;

@@ -128,6 +128,8 @@ int sweep2_num_wgs_max(int W, int H);          // workgroups a sweep launch on a
 size_t sweep2_boundary_elems(int W, int H);   // granules one sweep launch may need (either band orientation)
 size_t sweep2_rec_bytes(int W, int H);
 bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec);  // v2: prepass + 8 lanes/pixel + helper waves; false = empty window, nothing launched
+size_t sweep_relax_boundary_elems(int W, int H);
+bool launch_sweep_relax(hipStream_t st, const SweepArgs& a);   // experiment (PANOFLOW_SWEEP=3): event-driven relaxation on LDS-resident tiles, kernels_relax.inl
 // coarsest-level search
 void launch_adjust_initial_flow(hipStream_t st, const float* i0, const float* i1, const float* a0, const float* a1, int w, int h, int hint,
                                 int max_pct, float* i1eq_tmp, float* flow);
