@@ -1,0 +1,24 @@
+"""GPU box: Mpix/s of pf_novel_view_batch_dev on 2000x4000 strips for ONE lane count (environment decides queues / CU partitions):
+throughput_one.py <in_flight> [cols rows]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from conftest import load_pkg_module
+pf = load_pkg_module("pyabi"); synth = load_pkg_module("synth")
+infl = int(sys.argv[1])
+cols, rows = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (2000, 4000)
+dev = torch.device("cuda", 0)
+nb = 24
+pairs = [synth.make_pair(cols, rows, 7000 + i, dev) for i in range(nb)]
+outs = [torch.empty((rows, cols, 4), dtype=torch.uint8, device=dev) for _ in range(nb)]
+torch.cuda.synchronize()
+c = pf.Context(0, cols, rows)
+call = lambda: c.novel_view_batch_dev([p[0].data_ptr() for p in pairs], [p[1].data_ptr() for p in pairs], cols, rows, 0,
+                                      [p[2].data_ptr() for p in pairs], [o.data_ptr() for o in outs], None, None, in_flight=infl)
+call()
+best = 1e9
+for _ in range(2):
+    t = time.perf_counter(); call(); best = min(best, time.perf_counter() - t)
+ref = pf.Context(0, cols, rows) if os.environ.get("TP_CHECK") else None
+print("queues %s cu_parts %s in_flight %2d: %.1f Mpix/s (%.2f ms per pair)" % (os.environ.get("GPU_MAX_HW_QUEUES"), os.environ.get("PANOFLOW_CU_PARTS"), infl,
+                                                                             nb * cols * rows / 1e6 / best, 1000 * best / nb), flush=True)
