@@ -17,7 +17,7 @@ call = lambda: c.novel_view_batch_dev([p[0].data_ptr() for p in pairs], [p[1].da
                                       [p[2].data_ptr() for p in pairs], [o.data_ptr() for o in outs], None, None, in_flight=infl)
 call()
 best = 1e9
-for _ in range(2):
+for _ in range(int(os.environ.get("TP_LOOPS", "2"))):
     t = time.perf_counter(); call(); best = min(best, time.perf_counter() - t)
 ref = pf.Context(0, cols, rows) if os.environ.get("TP_CHECK") else None
 print("queues %s cu_parts %s in_flight %2d: %.1f Mpix/s (%.2f ms per pair)" % (os.environ.get("GPU_MAX_HW_QUEUES"), os.environ.get("PANOFLOW_CU_PARTS"), infl,
