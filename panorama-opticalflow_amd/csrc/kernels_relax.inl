@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kRXThreads) void k_sweep_relax(const float2* __rest
 #ifdef PF_RX_STATS
         stTFin = wall_clock64();
 #endif
-      }   // (no acquire fence: every later look at the predecessors is an agent-scope atomic load; a fence here invalidates the L2, ~40 us per hop)
+      }   // (no acquire fence: every later look at the predecessors is an agent-scope atomic load)
       if (nNext == 0) {
         if (r >= finSeen + kPollEvery) {
 #ifdef PF_RX_STATS
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(kRXThreads) void k_sweep_relax(const float2* __rest
     if (pubQ >= 0) { const unsigned long long cur = sm.P[pubQ]; if (cur != lastPub) __hip_atomic_store(pubDst, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(gMine + 2 * kT, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a release here would write back the whole L2: ~40 us per hop of the finish wave)
+    if (tid == 0) __hip_atomic_store(gMine + 2 * kT, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (relaxed: every edge store was drained by s_waitcnt vmcnt(0) + the barrier above)
     if (tileGated) {
       for (int q = tid; q < kTP; q += kRXThreads) {
         const int u = q % kT, v = q / kT;
