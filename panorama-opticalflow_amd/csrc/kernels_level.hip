@@ -252,72 +252,105 @@ __global__ __launch_bounds__(256) void k_gauss15_col(const float2* __restrict__ 
 // (one source row each), so the LDS row strides are odd numbers of float2 (79, 65): at most 2-way bank conflicts.
 // MIX fuses lowAlphaFlowDiffusion's alpha mix (PixFlow.hpp:396-403) into the epilogue.
 constexpr int kG15TX = 64, kG15TY = 32, kG15R = 7;
+constexpr int kG15SW = kG15TX + 2 * kG15R, kG15SH = kG15TY + 2 * kG15R;   // 78 x 46 source texels per tile
+constexpr int kG15Pre = (kG15SW * kG15SH + 255) / 256;                     // 15 texels per thread
+// The blocks are persistent (at most three per CU, the LDS limit) and walk the tiles with a stride of gridDim.x: the global
+// loads of a block's NEXT tile are issued into registers before it computes the current one, so that with only three blocks
+// per CU the load latency hides behind the two passes instead of in front of them.
 template <bool MIX>
-__global__ __launch_bounds__(256) void k_gauss15_fused(const float2* __restrict__ src, float2* __restrict__ dst, int w, int h, Gauss g,
-                                                        const float* __restrict__ a0, const float* __restrict__ a1) {
-  constexpr int SW = kG15TX + 2 * kG15R, SH = kG15TY + 2 * kG15R;   // 78 x 46
+__global__ __launch_bounds__(256, 3) void k_gauss15_fused(const float2* __restrict__ src, float2* __restrict__ dst, int w, int h, Gauss g,
+                                                        const float* __restrict__ a0, const float* __restrict__ a1, int ntx, int ntiles) {
+  constexpr int SW = kG15SW, SH = kG15SH;
   constexpr int SS = SW + 1, RS = kG15TX + 1;                        // LDS row strides in float2: 79, 65 (odd); 53 KB in all: three blocks per CU
   __shared__ float2 srct[SH * SS];
   __shared__ float2 rowp[SH * RS];
-  const int x0 = blockIdx.x * kG15TX, y0 = blockIdx.y * kG15TY;
-  const int rowsNeeded = min(SH, h + kG15R - (y0 - kG15R));   // rows past (h - 1) + 7 are read by no output of this tile
-  // ---- (1) source tile ----
-  for (int t = threadIdx.x; t < rowsNeeded * SW; t += 256) {
-    const int r = t / SW, cidx = t - r * SW;
-    srct[r * SS + cidx] = src[size_t(d_reflect101(y0 - kG15R + r, h)) * w + d_reflect101(min(x0 - kG15R + cidx, w - 1 + kG15R), w)];
-  }
-  __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // ---- (2) row pass: lane = source row (46 of 64 lanes), wave = 16 output columns; 30 values -> 16 outputs ----
-  if (lane < rowsNeeded) {
-    const float2* sr = srct + lane * SS + wv * 16;
-    float2 v[30];
+  float2 pre[kG15Pre];
+  auto fetch = [&](int tile) {
+    const int x0 = (tile % ntx) * kG15TX, y0 = (tile / ntx) * kG15TY;
+    const int rowsNeeded = min(SH, h + kG15R - (y0 - kG15R));   // rows past (h - 1) + 7 are read by no output of this tile
 #pragma unroll
-    for (int t = 0; t < 30; ++t) v[t] = sr[t];
-    float2* rp = rowp + lane * RS + wv * 16;
-#pragma unroll
-    for (int o = 0; o < 16; ++o) {
-      float sx = g.k[0] * v[o].x, sy = g.k[0] * v[o].y;
-#pragma unroll
-      for (int t = 1; t < 15; ++t) { sx += g.k[t] * v[o + t].x; sy += g.k[t] * v[o + t].y; }
-      rp[o] = make_float2(sx, sy);
+    for (int k = 0; k < kG15Pre; ++k) {
+      const int t = threadIdx.x + 256 * k;
+      const int r = t / SW, cidx = t - r * SW;
+      if (t < rowsNeeded * SW) pre[k] = src[size_t(d_reflect101(y0 - kG15R + r, h)) * w + d_reflect101(min(x0 - kG15R + cidx, w - 1 + kG15R), w)];
     }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  while (tile < ntiles) {
+    const int x0 = (tile % ntx) * kG15TX, y0 = (tile / ntx) * kG15TY;
+    const int rowsNeeded = min(SH, h + kG15R - (y0 - kG15R));
+    // ---- (1) source tile: registers -> LDS ----
+#pragma unroll
+    for (int k = 0; k < kG15Pre; ++k) {
+      const int t = threadIdx.x + 256 * k;
+      const int r = t / SW, cidx = t - r * SW;
+      if (t < rowsNeeded * SW) srct[r * SS + cidx] = pre[k];
+    }
+    __syncthreads();
+    const int next = tile + int(gridDim.x);
+    if (next < ntiles) fetch(next);
+    // ---- (2) row pass: lane = source row (46 of 64 lanes), wave = 16 output columns; 30 values -> 16 outputs ----
+    if (lane < rowsNeeded) {
+      const float2* sr = srct + lane * SS + wv * 16;
+      float2 v[30];
+#pragma unroll
+      for (int t = 0; t < 30; ++t) v[t] = sr[t];
+      float2* rp = rowp + lane * RS + wv * 16;
+#pragma unroll
+      for (int o = 0; o < 16; ++o) {
+        float sx = g.k[0] * v[o].x, sy = g.k[0] * v[o].y;
+#pragma unroll
+        for (int t = 1; t < 15; ++t) { sx += g.k[t] * v[o + t].x; sy += g.k[t] * v[o + t].y; }
+        rp[o] = make_float2(sx, sy);
+      }
+    }
+    __syncthreads();
+    // ---- (3) column pass: lane = column, wave = 8 output rows; 22 values -> 8 outputs.  The row pass of source row
+    // reflect101(y + d) sits at LDS row (y - y0) + 7 + d ----
+    const int x = x0 + lane;
+    const int oy0 = wv * 8;
+    if (x < w && y0 + oy0 < h) {
+      float2 cv[22];
+#pragma unroll
+      for (int t = 0; t < 22; ++t) cv[t] = (oy0 + t < rowsNeeded) ? rowp[(oy0 + t) * RS + lane] : make_float2(0.f, 0.f);
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        const int y = y0 + oy0 + o;
+        if (y >= h) break;
+        const float2 c = cv[o + kG15R];
+        float sx = g.k[7] * c.x + 0.0f, sy = g.k[7] * c.y + 0.0f;
+#pragma unroll
+        for (int j = 1; j <= 7; ++j) {
+          const float2 a = cv[o + kG15R + j], b = cv[o + kG15R - j];
+          sx += g.k[7 + j] * (a.x + b.x); sy += g.k[7 + j] * (a.y + b.y);
+        }
+        const size_t i = size_t(y) * w + x;
+        if (MIX) {
+          const float2 f = srct[(oy0 + o + kG15R) * SS + lane + kG15R];
+          const float diffusionCoef = 1.0f - a0[i] * a1[i];
+          dst[i] = make_float2(diffusionCoef * sx + (1.0f - diffusionCoef) * f.x, diffusionCoef * sy + (1.0f - diffusionCoef) * f.y);
+        } else {
+          dst[i] = make_float2(sx, sy);
+        }
+      }
+    }
+    tile = next;
+    if (tile < ntiles) __syncthreads();   // every read of this tile's LDS is done before the next one is stored
   }
-  __syncthreads();
-  // ---- (3) column pass: lane = column, wave = 8 output rows; 22 values -> 8 outputs.  The row pass of source row
-  // reflect101(y + d) sits at LDS row (y - y0) + 7 + d ----
-  const int x = x0 + lane;
-  if (x >= w) return;
-  const int oy0 = wv * 8;
-  if (y0 + oy0 >= h) return;
-  float2 cv[22];
-#pragma unroll
-  for (int t = 0; t < 22; ++t) cv[t] = (oy0 + t < rowsNeeded) ? rowp[(oy0 + t) * RS + lane] : make_float2(0.f, 0.f);
-#pragma unroll
-  for (int o = 0; o < 8; ++o) {
-    const int y = y0 + oy0 + o;
-    if (y >= h) break;
-    const float2 c = cv[o + kG15R];
-    float sx = g.k[7] * c.x + 0.0f, sy = g.k[7] * c.y + 0.0f;
-#pragma unroll
-    for (int j = 1; j <= 7; ++j) {
-      const float2 a = cv[o + kG15R + j], b = cv[o + kG15R - j];
-      sx += g.k[7 + j] * (a.x + b.x); sy += g.k[7 + j] * (a.y + b.y);
-    }
-    const size_t i = size_t(y) * w + x;
-    if (MIX) {
-      const float2 f = srct[(oy0 + o + kG15R) * SS + lane + kG15R];
-      const float diffusionCoef = 1.0f - a0[i] * a1[i];
-      dst[i] = make_float2(diffusionCoef * sx + (1.0f - diffusionCoef) * f.x, diffusionCoef * sy + (1.0f - diffusionCoef) * f.y);
-    } else {
-      dst[i] = make_float2(sx, sy);
-    }
-  }
+}
+static inline void gauss15_grid(int w, int h, int& ntx, int& ntiles, unsigned& blocks) {
+  ntx = (w + kG15TX - 1) / kG15TX;
+  ntiles = ntx * ((h + kG15TY - 1) / kG15TY);
+  static const int cap = [] { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 768; return 3 * p.multiProcessorCount; }();
+  blocks = (unsigned)(ntiles < cap ? ntiles : cap);
 }
 void launch_gauss15(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const Gauss& g15) {
   (void)tmp;
-  dim3 grid((w + kG15TX - 1) / kG15TX, (h + kG15TY - 1) / kG15TY);
-  hipLaunchKernelGGL((k_gauss15_fused<false>), grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h, g15, nullptr, nullptr);
+  int ntx, ntiles; unsigned blocks;
+  gauss15_grid(w, h, ntx, ntiles, blocks);
+  hipLaunchKernelGGL((k_gauss15_fused<false>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h, g15, nullptr, nullptr, ntx, ntiles);
 }
 
 // K8 lowAlphaFlowDiffusion (PixFlow.hpp:388-405): column pass fused with the alpha mix.
@@ -333,8 +366,9 @@ __global__ __launch_bounds__(256) void k_gauss15_col_mix(const float2* __restric
 }
 void launch_gauss15_mix(hipStream_t st, float* flow, float* tmp, const float* a0, const float* a1, int w, int h, const Gauss& g15, float* out) {
   (void)tmp;
-  dim3 grid((w + kG15TX - 1) / kG15TX, (h + kG15TY - 1) / kG15TY);
-  hipLaunchKernelGGL((k_gauss15_fused<true>), grid, dim3(256), 0, st, reinterpret_cast<const float2*>(flow), reinterpret_cast<float2*>(out), w, h, g15, a0, a1);
+  int ntx, ntiles; unsigned blocks;
+  gauss15_grid(w, h, ntx, ntiles, blocks);
+  hipLaunchKernelGGL((k_gauss15_fused<true>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float2*>(flow), reinterpret_cast<float2*>(out), w, h, g15, a0, a1, ntx, ntiles);
 }
 
 // ------------------------------------------------------------------------------------------------
