@@ -123,11 +123,15 @@ void launch_gate_bbox(hipStream_t st, const uint8_t* gate, const LevelTable& t, 
 // The last block to finish copies boxes + count to `host` (system-scope stores), stores the call's epoch behind them as the
 // "ready" flag, and resets the work area for the next call -- the host polls that flag instead of synchronising the stream
 // (no pageable copies, no blocking wait: the round trip costs microseconds).
+#ifndef PF_GATE_PER
+#define PF_GATE_PER 16384
+#endif
+constexpr unsigned kGatePer = PF_GATE_PER;   // level-pixels per block
 __global__ __launch_bounds__(256) void k_gate_bbox_all(const float* __restrict__ a0, const float* __restrict__ a1, uint8_t* __restrict__ gate, LevelTable t,
                                                        unsigned total, int* __restrict__ work, int* __restrict__ host, int epoch) {
   __shared__ int sbox[4];
   __shared__ int scnt, slast;
-  constexpr unsigned kPer = 4096;
+  constexpr unsigned kPer = kGatePer;
   const unsigned base = blockIdx.x * kPer;
   if (threadIdx.x == 0) scnt = 0;
   int lvl = -1, w = 1, mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -1, mxy = -1, cnt0 = 0;
@@ -153,19 +157,38 @@ __global__ __launch_bounds__(256) void k_gate_bbox_all(const float* __restrict__
   for (int l = l0; l < t.n && t.off[l] < end; ++l) {
     lvl = l; w = t.w[l]; off = t.off[l]; cnt = unsigned(t.w[l]) * unsigned(t.h[l]);
     const unsigned lo = off > base ? off : base, hiE = (off + cnt < end) ? off + cnt : end;
-    // one division per thread and level; the following elements (256 apart) advance (x, y) incrementally
-    unsigned i = lo + threadIdx.x;
+    // four consecutive level-pixels per thread and iteration (16-byte loads, one 4-byte gate store); `lo` is a multiple of 4
+    // (block bases and level offsets are multiples of 64).  One division per thread and level: the following groups (1024
+    // apart) advance (x, y) by a per-level quotient / remainder.
+    const int qStep = 1024 / w, rStep = 1024 - qStep * w;
+    unsigned i = lo + 4 * threadIdx.x;
     int y = 0, x = 0;
     if (i < hiE) { const unsigned local = i - off; y = int(local / unsigned(w)); x = int(local - unsigned(y) * unsigned(w)); }
-    for (; i < hiE; i += 256) {
-      const bool gt = a0[i] > kUpdateAlphaThreshold && a1[i] > kUpdateAlphaThreshold;
-      gate[i] = gt ? 1 : 0;
-      if (gt) {
-        mnx = min(mnx, x); mny = min(mny, y); mxx = max(mxx, x); mxy = max(mxy, y);
-        if (l == 0) ++cnt0;
+    for (; i < hiE; i += 1024) {
+      bool gt[4];
+      if (i + 3 < hiE) {
+        const float4 va = *reinterpret_cast<const float4*>(a0 + i), vb = *reinterpret_cast<const float4*>(a1 + i);
+        gt[0] = va.x > kUpdateAlphaThreshold && vb.x > kUpdateAlphaThreshold; gt[1] = va.y > kUpdateAlphaThreshold && vb.y > kUpdateAlphaThreshold;
+        gt[2] = va.z > kUpdateAlphaThreshold && vb.z > kUpdateAlphaThreshold; gt[3] = va.w > kUpdateAlphaThreshold && vb.w > kUpdateAlphaThreshold;
+        *reinterpret_cast<uchar4*>(gate + i) = make_uchar4(gt[0], gt[1], gt[2], gt[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          gt[j] = (i + j < hiE) && a0[i + j] > kUpdateAlphaThreshold && a1[i + j] > kUpdateAlphaThreshold;
+          if (i + j < hiE) gate[i + j] = gt[j] ? 1 : 0;
+        }
       }
-      x += 256;
-      while (x >= w) { x -= w; ++y; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (gt[j]) {
+          int xj = x + j, yj = y;
+          while (xj >= w) { xj -= w; ++yj; }
+          mnx = min(mnx, xj); mny = min(mny, yj); mxx = max(mxx, xj); mxy = max(mxy, yj);
+          if (l == 0) ++cnt0;
+        }
+      }
+      x += rStep; y += qStep;
+      if (x >= w) { x -= w; ++y; }
     }
     flush();
   }
@@ -195,7 +218,7 @@ __global__ __launch_bounds__(256) void k_gate_bbox_all(const float* __restrict__
   }
 }
 void launch_gate_bbox_all(hipStream_t st, const float* a0, const float* a1, uint8_t* gate, const LevelTable& t, size_t total, int* work, int* host_mapped, int epoch) {
-  hipLaunchKernelGGL(k_gate_bbox_all, dim3((unsigned)((total + 4095) / 4096)), dim3(256), 0, st, a0, a1, gate, t, (unsigned)total, work, host_mapped, epoch);
+  hipLaunchKernelGGL(k_gate_bbox_all, dim3((unsigned)((total + kGatePer - 1) / kGatePer)), dim3(256), 0, st, a0, a1, gate, t, (unsigned)total, work, host_mapped, epoch);
 }
 
 __global__ __launch_bounds__(256) void k_count_gate(const uint8_t* __restrict__ gate, int n, unsigned* __restrict__ count) {
