@@ -44,26 +44,31 @@ __global__ __launch_bounds__(256) void k_gradients(const float* __restrict__ img
 // a thread's flat index inside the pyramid plane -> level by binary search in the offset table -> (x, y).
 __global__ __launch_bounds__(256) void k_gradients_all(const float* __restrict__ img0, const float* __restrict__ img1, float2* __restrict__ g0,
                                                        float2* __restrict__ g1, LevelTable t, unsigned first, unsigned total, Gauss g) {
-  const unsigned i = first + blockIdx.x * blockDim.x + threadIdx.x;   // elements [first, total) of the pyramid plane
-  if (i >= total) return;
-  int lo = 0, hi = t.n - 1;
-  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (i >= t.off[mid]) lo = mid; else hi = mid - 1; }
-  const int w = t.w[lo], h = t.h[lo];
-  const unsigned local = i - t.off[lo];
-  if (local >= unsigned(w) * unsigned(h)) return;   // padding between levels
-  const int y = int(local / unsigned(w)), x = int(local - unsigned(y) * unsigned(w));
-  const float* img = (blockIdx.y ? img1 : img0) + t.off[lo];
-  float2* out = (blockIdx.y ? g1 : g0) + t.off[lo];
-  out[local] = d_gradient_px(img, w, h, x, y, g);
+  // elements [first, total) of the pyramid plane; grid-stride, so that a launch can be made with few blocks on purpose
+  for (unsigned i = first + blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int lo = 0, hi = t.n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (i >= t.off[mid]) lo = mid; else hi = mid - 1; }
+    const int w = t.w[lo], h = t.h[lo];
+    const unsigned local = i - t.off[lo];
+    if (local >= unsigned(w) * unsigned(h)) continue;   // padding between levels
+    const int y = int(local / unsigned(w)), x = int(local - unsigned(y) * unsigned(w));
+    const float* img = (blockIdx.y ? img1 : img0) + t.off[lo];
+    float2* out = (blockIdx.y ? g1 : g0) + t.off[lo];
+    out[local] = d_gradient_px(img, w, h, x, y, g);
+  }
 }
 void launch_gradients(hipStream_t st, const float* img, int w, int h, float* gxy, const Gauss& g3) {
   dim3 grid((w + 255) / 256, h);
   hipLaunchKernelGGL(k_gradients, grid, dim3(256), 0, st, img, w, h, reinterpret_cast<float2*>(gxy), g3);
 }
+// max_blocks > 0 caps the blocks per image: a launch that runs BESIDE latency-critical kernels (the finest levels' gradients
+// next to the coarse levels' sweeps) is made narrow so that it takes a few wave slots per CU instead of all of them.
 void launch_gradients_all(hipStream_t st, const float* pyr0, const float* pyr1, float* grad0, float* grad1, const LevelTable& t, size_t first,
-                          size_t total, const Gauss& g3) {
+                          size_t total, const Gauss& g3, int max_blocks) {
   if (total <= first) return;
-  hipLaunchKernelGGL(k_gradients_all, dim3((unsigned)((total - first + 255) / 256), 2), dim3(256), 0, st, pyr0, pyr1, reinterpret_cast<float2*>(grad0),
+  size_t blocks = (total - first + 255) / 256;
+  if (max_blocks > 0 && blocks > size_t(max_blocks)) blocks = size_t(max_blocks);
+  hipLaunchKernelGGL(k_gradients_all, dim3((unsigned)blocks, 2), dim3(256), 0, st, pyr0, pyr1, reinterpret_cast<float2*>(grad0),
                      reinterpret_cast<float2*>(grad1), t, (unsigned)first, (unsigned)total, g3);
 }
 

@@ -39,6 +39,7 @@ struct pf_ctx {
   hipEvent_t ev_alpha = nullptr, ev_gate = nullptr;
   hipEvent_t ev_aux_go = nullptr, ev_aux_done = nullptr;
   hipEvent_t ev_pre = nullptr, ev_dir[2] = {nullptr, nullptr};
+  hipEvent_t ev_fine2 = nullptr;  // ... of the finest levels (narrow launch)
   hipEvent_t ev_fine = nullptr;   // gradients of the fine levels done (the directions start on the coarse ones before that)
   std::string err;
   std::map<std::string, DevBuf> bufs;  // named grow-only arena: everything a solve needs stays resident
@@ -352,8 +353,15 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
     HIPCHK(c, hipMemsetAsync(sb.prepcnt[d], 0, sb.pc_total * sizeof(int), sm));
   }
   HIPCHK(c, hipEventRecord(c->ev_pre, sm));
-  if (have_table && split > 0) { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], table, 0, g.off[split], c->g3_05); }
+  // Fine levels in two launches behind the coarse ones: levels [split2, split) at full width (needed first, a quarter of the fine
+  // pixels), then the finest levels [0, split2) as a NARROW launch -- it runs beside the sweeps of ~30 coarser levels and is not
+  // needed for milliseconds; at full width it took every wave slot of the chip and slowed the first sweeps several times over.
+  static const int fineBlocks = [] { const char* e = getenv("PANOFLOW_FINE_GRAD_BLOCKS"); return e ? atoi(e) : 64; }();
+  const int split2 = split > 4 ? 4 : 0;
+  if (have_table && split > 0) { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], table, g.off[split2], g.off[split], c->g3_05); }
   HIPCHK(c, hipEventRecord(c->ev_fine, sm));
+  if (have_table && split2 > 0) { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], table, 0, g.off[split2], c->g3_05, fineBlocks); }
+  HIPCHK(c, hipEventRecord(c->ev_fine2, sm));
   if (have_table) {
     if (int e = wait_gate_boxes(c, sg, epoch, g.n, boxes, h_cnt)) return e;
     if (getenv("PANOFLOW_NO_WINDOW")) boxes.clear();
@@ -384,6 +392,7 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   auto enqueue_level = [&](int d, int level) {
     hipStream_t st = c->s_dir[d];
     if (level == split - 1) hipStreamWaitEvent(st, c->ev_fine, 0);   // first level whose gradients come from the second launch
+    if (split2 > 0 && level == split2 - 1) hipStreamWaitEvent(st, c->ev_fine2, 0);   // ... from the third (narrow) launch
     const int i0 = d, i1 = 1 - d;
     LevelBufs& b = lb[d];
     const int w = g.ws[level], h = g.hs[level];
@@ -496,7 +505,8 @@ pf_ctx* pf_create(int device, int max_cols, int max_rows) {
   for (int d = 0; d < 2 && ok; ++d) ok = hipStreamCreateWithFlags(&c->s_dir[d], hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_alpha, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_aux_go, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_fine, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_fine, hipEventDisableTiming) == hipSuccess &&
+       hipEventCreateWithFlags(&c->ev_fine2, hipEventDisableTiming) == hipSuccess;
   for (int d = 0; d < 2 && ok; ++d) ok = hipEventCreateWithFlags(&c->ev_dir[d], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_status, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void**)&c->d_status, c->h_status, 0) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_gate, (4 * kLevelTableMax + 2) * sizeof(int), hipHostMallocMapped) == hipSuccess &&
@@ -533,6 +543,7 @@ void pf_destroy(pf_ctx* c) {
   for (auto& p : c->prof_pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   if (c->ev_pre) hipEventDestroy(c->ev_pre);
   if (c->ev_fine) hipEventDestroy(c->ev_fine);
+  if (c->ev_fine2) hipEventDestroy(c->ev_fine2);
   for (int d = 0; d < 2; ++d) { if (c->ev_dir[d]) hipEventDestroy(c->ev_dir[d]); if (c->s_dir[d]) hipStreamDestroy(c->s_dir[d]); }
   if (c->ev_aux_go) hipEventDestroy(c->ev_aux_go);
   if (c->ev_aux_done) hipEventDestroy(c->ev_aux_done);

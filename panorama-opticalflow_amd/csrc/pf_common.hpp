@@ -90,7 +90,7 @@ struct LevelTable { int n; int w[kLevelTableMax]; int h[kLevelTableMax]; unsigne
 void launch_gate_bbox(hipStream_t st, const uint8_t* gate, const LevelTable& t, size_t total, int* box);   // box[4*l..]: min x, min y, max x, max y
 // elements [first, total) of the pyramid planes (levels lie back to back, level 0 first)
 void launch_gradients_all(hipStream_t st, const float* pyr0, const float* pyr1, float* grad0, float* grad1, const LevelTable& t, size_t first,
-                          size_t total, const Gauss& g3);
+                          size_t total, const Gauss& g3, int max_blocks = 0);
 void launch_gate(hipStream_t st, const float* a0, const float* a1, int n, uint8_t* gate);
 // gate + per-level bounding boxes + level-0 count in one launch, published to mapped pinned host memory behind an epoch flag
 // (work: 4*kLevelTableMax + 2 ints, initialised once to (INT_MAX, INT_MAX, -1, -1)*, 0, 0; host_mapped: same size)
