@@ -140,6 +140,64 @@ void launch_pyr_down2(hipStream_t st, const float* s0, const float* s1, int sw, 
   hipLaunchKernelGGL(k_pyr_down4, grid, dim3(256), 0, st, p, sw, sh, dw, dh, sx, sy);
 }
 
+// Several pyramid levels per launch.  The levels form a dependency chain (level l+1 is a bilinear resize of level l), and for the
+// small levels a launch costs ~5 us whatever it does -- 36 dependent launches are ~0.2 ms in front of everything else.  A pixel
+// of level l+2 only needs four pixels of level l+1, which are four pixels of level l each: computing them on the fly with the
+// very same expressions gives the same bits, so one launch can write levels l+1 .. l+K from level l (4^K loads per pixel of the
+// last one: only worth it where the levels are small).
+struct PyrChain { int n; int w[4], h[4]; double sx[4], sy[4]; size_t off[4]; };   // [0] = source level, [1..n] = levels written
+template <int D>
+__device__ __forceinline__ float d_pyr_virtual(const float* __restrict__ base, const PyrChain& c, int x, int y) {
+  // value of pixel (x, y) of chain level D, computed from the stored level 0
+  if constexpr (D == 0) {
+    return base[c.off[0] + size_t(y) * c.w[0] + x];
+  } else {
+    const int sw = c.w[D - 1], sh = c.h[D - 1];
+    int sx, sy; float fx, fy;
+    d_src_coord(x, c.sx[D], sx, fx);
+    d_src_coord(y, c.sy[D], sy, fy);
+    if (sx < 0) { fx = 0; sx = 0; }
+    const bool tail = (sx + 1 >= sw);
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+    const int y0 = d_replicate(sy, sh), y1 = d_replicate(sy + 1, sh);
+    float h0, h1;
+    if (tail) { h0 = d_pyr_virtual<D - 1>(base, c, sx, y0) * 1.0f; h1 = d_pyr_virtual<D - 1>(base, c, sx, y1) * 1.0f; }
+    else {
+      h0 = d_pyr_virtual<D - 1>(base, c, sx, y0) * a0 + d_pyr_virtual<D - 1>(base, c, sx + 1, y0) * a1;
+      h1 = d_pyr_virtual<D - 1>(base, c, sx, y1) * a0 + d_pyr_virtual<D - 1>(base, c, sx + 1, y1) * a1;
+    }
+    return h0 * b0 + h1 * b1;
+  }
+}
+struct Ptr4P { float* p[4]; };
+__global__ __launch_bounds__(256) void k_pyr_chain(Ptr4P planes, PyrChain c, int rows1, int rows2) {
+  // blockIdx.y walks the rows of level 1, then of level 2, then of level 3 of the chain; blockIdx.z = plane
+  float* base = planes.p[blockIdx.z];
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y, lvl = 1;
+  if (y >= rows1) { y -= rows1; lvl = 2; if (y >= rows2) { y -= rows2; lvl = 3; } }
+  if (x >= c.w[lvl]) return;
+  float v;
+  if (lvl == 1) v = d_pyr_virtual<1>(base, c, x, y);
+  else if (lvl == 2) v = d_pyr_virtual<2>(base, c, x, y);
+  else v = d_pyr_virtual<3>(base, c, x, y);
+  base[c.off[lvl] + size_t(y) * c.w[lvl] + x] = v;
+}
+// planes p0..p3 hold every level at offset off[l]; writes levels first+1 .. first+k (k = 1..3) from level `first`
+void launch_pyr_chain4(hipStream_t st, float* p0, float* p1, float* p2, float* p3, const int* ws, const int* hs, const size_t* off, int first, int k) {
+  PyrChain c; c.n = k;
+  for (int i = 0; i <= 3; ++i) {
+    const int l = first + (i <= k ? i : k);
+    c.w[i] = ws[l]; c.h[i] = hs[l]; c.off[i] = off[l];
+    c.sx[i] = i ? 1. / ((double)ws[l] / ws[l - 1]) : 1.; c.sy[i] = i ? 1. / ((double)hs[l] / hs[l - 1]) : 1.;
+  }
+  Ptr4P pl{{p0, p1, p2, p3}};
+  const int rows1 = c.h[1], rows2 = k >= 2 ? c.h[2] : 0, rows3 = k >= 3 ? c.h[3] : 0;
+  dim3 grid((c.w[1] + 255) / 256, rows1 + rows2 + rows3, 4);
+  hipLaunchKernelGGL(k_pyr_chain, grid, dim3(256), 0, st, pl, c, rows1, rows2);
+}
+
 __global__ void k_fill_u64(unsigned long long* p, size_t n, unsigned long long v) {
   size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t stride = size_t(gridDim.x) * blockDim.x;

@@ -313,10 +313,20 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
     { PROF(c, sm, "downscale_gray"); launch_downscale_gray(sm, imgs[i], cols, rows, pad, half_tmp, pyrA[i], g.w0, g.h0); }
     { PROF(c, sm, "preblur5"); launch_gauss_small(sm, half_tmp, pyrI[i], g.w0, g.h0, 1, c->g5); }
   }
-  for (int l = 1; l < g.n; ++l) {
+  // pyramids: one launch per level while the levels are large, then two and three levels per launch (the chain of dependent
+  // ~5 us launches is otherwise ~0.2 ms in front of everything; kernels_pre.hip: k_pyr_chain)
+  static const int chainMode = [] { const char* e = getenv("PANOFLOW_PYR_CHAIN"); return e ? atoi(e) : 1; }();
+  for (int l = 1; l < g.n;) {
     PROF(c, sm, "pyr_down");
-    launch_pyr_down4(sm, pyrI[0] + g.off[l - 1], pyrI[1] + g.off[l - 1], pyrA[0] + g.off[l - 1], pyrA[1] + g.off[l - 1], g.ws[l - 1], g.hs[l - 1],
-                     pyrI[0] + g.off[l], pyrI[1] + g.off[l], pyrA[0] + g.off[l], pyrA[1] + g.off[l], g.ws[l], g.hs[l]);
+    const size_t px = size_t(g.ws[l]) * g.hs[l];
+    int k = 1;
+    if (chainMode) { if (px <= 40000 && l + 2 < g.n) k = 3; else if (px <= 160000 && l + 1 < g.n) k = 2; }
+    if (k == 1)
+      launch_pyr_down4(sm, pyrI[0] + g.off[l - 1], pyrI[1] + g.off[l - 1], pyrA[0] + g.off[l - 1], pyrA[1] + g.off[l - 1], g.ws[l - 1], g.hs[l - 1],
+                       pyrI[0] + g.off[l], pyrI[1] + g.off[l], pyrA[0] + g.off[l], pyrA[1] + g.off[l], g.ws[l], g.hs[l]);
+    else
+      launch_pyr_chain4(sm, pyrI[0], pyrI[1], pyrA[0], pyrA[1], g.ws.data(), g.hs.data(), g.off.data(), l - 1, k);
+    l += k;
   }
   // The host needs the per-level bounding boxes of the gate (they size the sweep launches) and the level-0 gate count (dense
   // or sparse sweep variant; full-canvas inputs, CPU/StitchTool.cpp:17-33): one fused kernel computes gate, boxes and count

@@ -81,6 +81,7 @@ void launch_gauss_small(hipStream_t st, const float* src, float* dst, int w, int
 void launch_resize_linear(hipStream_t st, const float* src, int sw, int sh, float* dst, int dw, int dh, int cn, float mul, bool do_mul);
 void launch_pyr_down4(hipStream_t st, const float* s0, const float* s1, const float* s2, const float* s3, int sw, int sh, float* d0,
                       float* d1, float* d2, float* d3, int dw, int dh);
+void launch_pyr_chain4(hipStream_t st, float* p0, float* p1, float* p2, float* p3, const int* ws, const int* hs, const size_t* off, int first, int k);
 void launch_pyr_down2(hipStream_t st, const float* s0, const float* s1, int sw, int sh, float* d0, float* d1, int dw, int dh);
 // per level
 void launch_gradients(hipStream_t st, const float* img, int w, int h, float* gxy, const Gauss& g3);
