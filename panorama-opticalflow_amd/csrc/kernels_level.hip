@@ -237,6 +237,29 @@ void launch_count_gate(hipStream_t st, const uint8_t* gate, int n, unsigned* cou
   hipLaunchKernelGGL(k_count_gate, dim3(blocks), dim3(256), 0, st, gate, n, count);
 }
 
+// one output pixel of the inter-level upsample (K9 below: resize INTER_CUBIC on float2, then *= 1/0.9f); shared by
+// k_upsample_cubic and by the Gauss15 kernel that upsamples while it loads (small levels)
+__device__ __forceinline__ float2 d_upsample_cubic_px(const float2* __restrict__ src, int sw, int sh, int dx, int dy, double scale_x, double scale_y, float mul) {
+  int sx, sy; float fx, fy;
+  d_src_coord(dx, scale_x, sx, fx);
+  d_src_coord(dy, scale_y, sy, fy);
+  float a[4], b[4];
+  d_cubic_coeffs(fx, a);
+  d_cubic_coeffs(fy, b);
+  const int x0 = d_replicate(sx - 1, sw), x1 = d_replicate(sx, sw), x2 = d_replicate(sx + 1, sw), x3 = d_replicate(sx + 2, sw);
+  float hx[4], hy[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float2* r = src + size_t(d_replicate(sy - 1 + j, sh)) * sw;
+    const float2 p0 = r[x0], p1 = r[x1], p2 = r[x2], p3 = r[x3];
+    hx[j] = p0.x * a[0] + p1.x * a[1] + p2.x * a[2] + p3.x * a[3];
+    hy[j] = p0.y * a[0] + p1.y * a[1] + p2.y * a[2] + p3.y * a[3];
+  }
+  const float ox = hx[0] * b[0] + hx[1] * b[1] + hx[2] * b[2] + hx[3] * b[3];
+  const float oy = hy[0] * b[0] + hy[1] * b[1] + hy[2] * b[2] + hy[3] * b[3];
+  return make_float2(ox * mul + 0.0f, oy * mul + 0.0f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K5 Gaussian 15x15 s8 on the float2 flow, BORDER_REFLECT_101 (PixFlow.hpp:306-311, :389-394).
 // [OpenCV filter.cpp] row pass = RowFilter (plain left-to-right accumulation), column pass =
@@ -285,9 +308,13 @@ constexpr int kG15Pre = (kG15SW * kG15SH + 255) / 256;                     // 15
 // The blocks are persistent (at most three per CU, the LDS limit) and walk the tiles with a stride of gridDim.x: the global
 // loads of a block's NEXT tile are issued into registers before it computes the current one, so that with only three blocks
 // per CU the load latency hides behind the two passes instead of in front of them.
-template <bool MIX>
+// UPS (small levels): the source plane does not exist yet -- it is the bicubic upsample of the coarser level's result
+// (PixFlow.hpp:122-125); the tile loader computes it on the fly (same expressions as k_upsample_cubic) and writes the tile's own
+// 64 x 32 pixels of it to `up_out`, which saves the separate upsample launch where a launch costs more than its work.
+struct UpsSrc { const float2* src; int sw, sh; double scale_x, scale_y; float mul; float2* up_out; };
+template <bool MIX, bool UPS>
 __global__ __launch_bounds__(256, 3) void k_gauss15_fused(const float2* __restrict__ src, float2* __restrict__ dst, int w, int h, Gauss g,
-                                                        const float* __restrict__ a0, const float* __restrict__ a1, int ntx, int ntiles) {
+                                                        const float* __restrict__ a0, const float* __restrict__ a1, int ntx, int ntiles, UpsSrc ups) {
   constexpr int SW = kG15SW, SH = kG15SH;
   constexpr int SS = SW + 1, RS = kG15TX + 1;                        // LDS row strides in float2: 79, 65 (odd); 53 KB in all: three blocks per CU
   __shared__ float2 srct[SH * SS];
@@ -305,20 +332,31 @@ __global__ __launch_bounds__(256, 3) void k_gauss15_fused(const float2* __restri
     }
   };
   int tile = blockIdx.x;
-  if (tile < ntiles) fetch(tile);
+  if (!UPS && tile < ntiles) fetch(tile);
   while (tile < ntiles) {
     const int x0 = (tile % ntx) * kG15TX, y0 = (tile / ntx) * kG15TY;
     const int rowsNeeded = min(SH, h + kG15R - (y0 - kG15R));
     // ---- (1) source tile: registers -> LDS ----
+    if (UPS) {
+      for (int t = threadIdx.x; t < rowsNeeded * SW; t += 256) {
+        const int r = t / SW, cidx = t - r * SW;
+        const int yy = d_reflect101(y0 - kG15R + r, h), xx = d_reflect101(min(x0 - kG15R + cidx, w - 1 + kG15R), w);
+        const float2 v = d_upsample_cubic_px(ups.src, ups.sw, ups.sh, xx, yy, ups.scale_x, ups.scale_y, ups.mul);
+        srct[r * SS + cidx] = v;
+        const int oy = r - kG15R, ox = cidx - kG15R;   // the tile's own pixels are unreflected: every pixel of the plane is written once
+        if (oy >= 0 && oy < kG15TY && ox >= 0 && ox < kG15TX && y0 + oy < h && x0 + ox < w) ups.up_out[size_t(y0 + oy) * w + x0 + ox] = v;
+      }
+    } else {
 #pragma unroll
-    for (int k = 0; k < kG15Pre; ++k) {
-      const int t = threadIdx.x + 256 * k;
-      const int r = t / SW, cidx = t - r * SW;
-      if (t < rowsNeeded * SW) srct[r * SS + cidx] = pre[k];
+      for (int k = 0; k < kG15Pre; ++k) {
+        const int t = threadIdx.x + 256 * k;
+        const int r = t / SW, cidx = t - r * SW;
+        if (t < rowsNeeded * SW) srct[r * SS + cidx] = pre[k];
+      }
     }
     __syncthreads();
     const int next = tile + int(gridDim.x);
-    if (next < ntiles) fetch(next);
+    if (!UPS && next < ntiles) fetch(next);
     // ---- (2) row pass: lane = source row (46 of 64 lanes), wave = 16 output columns; 30 values -> 16 outputs ----
     if (lane < rowsNeeded) {
       const float2* sr = srct + lane * SS + wv * 16;
@@ -378,7 +416,15 @@ void launch_gauss15(hipStream_t st, const float* src, float* tmp, float* dst, in
   (void)tmp;
   int ntx, ntiles; unsigned blocks;
   gauss15_grid(w, h, ntx, ntiles, blocks);
-  hipLaunchKernelGGL((k_gauss15_fused<false>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h, g15, nullptr, nullptr, ntx, ntiles);
+  hipLaunchKernelGGL((k_gauss15_fused<false, false>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h, g15, nullptr, nullptr, ntx, ntiles, UpsSrc{});
+}
+
+// upsample (coarse sw x sh -> w x h, times mul) + Gauss15 of the upsampled plane in one launch: `up` receives the upsampled flow
+void launch_gauss15_upsample(hipStream_t st, const float* coarse, int sw, int sh, float mul, float* up, float* dst, int w, int h, const Gauss& g15) {
+  int ntx, ntiles; unsigned blocks;
+  gauss15_grid(w, h, ntx, ntiles, blocks);
+  const UpsSrc u{reinterpret_cast<const float2*>(coarse), sw, sh, 1. / ((double)w / sw), 1. / ((double)h / sh), mul, reinterpret_cast<float2*>(up)};
+  hipLaunchKernelGGL((k_gauss15_fused<false, true>), dim3(blocks), dim3(256), 0, st, nullptr, reinterpret_cast<float2*>(dst), w, h, g15, nullptr, nullptr, ntx, ntiles, u);
 }
 
 // K8 lowAlphaFlowDiffusion (PixFlow.hpp:388-405): column pass fused with the alpha mix.
@@ -396,7 +442,7 @@ void launch_gauss15_mix(hipStream_t st, float* flow, float* tmp, const float* a0
   (void)tmp;
   int ntx, ntiles; unsigned blocks;
   gauss15_grid(w, h, ntx, ntiles, blocks);
-  hipLaunchKernelGGL((k_gauss15_fused<true>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float2*>(flow), reinterpret_cast<float2*>(out), w, h, g15, a0, a1, ntx, ntiles);
+  hipLaunchKernelGGL((k_gauss15_fused<true, false>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float2*>(flow), reinterpret_cast<float2*>(out), w, h, g15, a0, a1, ntx, ntiles, UpsSrc{});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -481,24 +527,7 @@ __global__ __launch_bounds__(256) void k_upsample_cubic(const float2* __restrict
                                                         double scale_x, double scale_y, float mul) {
   const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
   if (dx >= dw) return;
-  int sx, sy; float fx, fy;
-  d_src_coord(dx, scale_x, sx, fx);
-  d_src_coord(dy, scale_y, sy, fy);
-  float a[4], b[4];
-  d_cubic_coeffs(fx, a);
-  d_cubic_coeffs(fy, b);
-  const int x0 = d_replicate(sx - 1, sw), x1 = d_replicate(sx, sw), x2 = d_replicate(sx + 1, sw), x3 = d_replicate(sx + 2, sw);
-  float hx[4], hy[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float2* r = src + size_t(d_replicate(sy - 1 + j, sh)) * sw;
-    const float2 p0 = r[x0], p1 = r[x1], p2 = r[x2], p3 = r[x3];
-    hx[j] = p0.x * a[0] + p1.x * a[1] + p2.x * a[2] + p3.x * a[3];
-    hy[j] = p0.y * a[0] + p1.y * a[1] + p2.y * a[2] + p3.y * a[3];
-  }
-  const float ox = hx[0] * b[0] + hx[1] * b[1] + hx[2] * b[2] + hx[3] * b[3];
-  const float oy = hy[0] * b[0] + hy[1] * b[1] + hy[2] * b[2] + hy[3] * b[3];
-  dst[size_t(dy) * dw + dx] = make_float2(ox * mul + 0.0f, oy * mul + 0.0f);
+  dst[size_t(dy) * dw + dx] = d_upsample_cubic_px(src, sw, sh, dx, dy, scale_x, scale_y, mul);
 }
 // Tiled form: a block owns a 64 x 16 output tile.  The horizontal pass (HResizeCubic) of every source row the tile's vertical
 // pass touches (at most kUpRows: 16 * 0.9 + 4 at the pyramid's scale) is computed once per output column into LDS, then the

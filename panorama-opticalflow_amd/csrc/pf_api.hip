@@ -46,6 +46,7 @@ struct pf_ctx {
   Gauss g5, g3_05, g3_1, g15;
   int prof = 0;   // 0 off, 1 every kernel family, 2 only the dominant family (the sweeps): fewer events in a timed region
   int sweep_version = 2;
+  long fuse_ups_px = 0;   // levels up to this many pixels get their incoming flow upsampled inside their first Gaussian (0 = never)
   int chain_cols = 0, chain_rows = 0;   // size of the stitch-chain result resident in "ch_final"
   long long last_swept_steps = 0;       // wavefront steps of one direction of the last solve (both sweeps, all levels, gated windows)
   const uint8_t* prefetch_src = nullptr; int prefetch_cols = 0, prefetch_rows = 0; size_t prefetch_step = 0;   // pf_stitch_prefetch: next step's left image
@@ -175,8 +176,11 @@ struct LevelBufs { float *flow_a, *flow_b, *blurred, *tmp, *rec; };
 // box = bounding box (min x, min y, max x, max y) of the gated pixels of this level, or nullptr for "everything"
 void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, const float* a0, const float* a1, const uint8_t* gate, int w, int h, int sparse,
                const int* box, const LevelBufs& b, unsigned long long* bnd_fwd, unsigned long long* bnd_bwd, int* ctrl_fwd, int* ctrl_bwd, float** result,
-               int* pc_fwd = nullptr, int* pc_bwd = nullptr) {
-  { PROF(c, st, "gauss15_blurredFlow"); launch_gauss15(st, b.flow_a, b.tmp, b.blurred, w, h, c->g15); }
+               int* pc_fwd = nullptr, int* pc_bwd = nullptr, const float* ups_src = nullptr, int ups_w = 0, int ups_h = 0) {
+  // ups_src: flow_a does not hold this level's incoming flow yet -- it is the upsample of the coarser level's result (ups_w x ups_h),
+  // computed by the Gaussian's tile loader on the way (small levels: one launch instead of two)
+  if (ups_src) { PROF(c, st, "gauss15_blurredFlow"); launch_gauss15_upsample(st, ups_src, ups_w, ups_h, 1.0f / kPyrScaleFactor, b.flow_a, b.blurred, w, h, c->g15); }
+  else { PROF(c, st, "gauss15_blurredFlow"); launch_gauss15(st, b.flow_a, b.tmp, b.blurred, w, h, c->g15); }
   SweepArgs sa;
   sa.g0 = reinterpret_cast<const float2*>(g0); sa.g1 = reinterpret_cast<const float2*>(g1);
   sa.blurred = reinterpret_cast<const float2*>(b.blurred); sa.gate = gate; sa.W = w; sa.H = h; sa.sparse = sparse;
@@ -399,6 +403,13 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   // level in turn (a direction's ~430 launches take the host >1 ms: enqueued one after the other, the second
   // direction's stream would sit idle that long) ---
   for (int d = 0; d < ndirs; ++d) HIPCHK(c, hipStreamWaitEvent(c->s_dir[d], c->ev_pre, 0));
+  // Fewer launches or shorter launches?  Alone, a pair is faster with the separate upsample kernel (strip 27.36 vs 27.44 ms); with
+  // several pairs in flight the time between a stream's kernels dominates and one launch fewer per level wins (+3 %): the
+  // throughput mode turns the fusion on for its lanes (pf_novel_view_batch_dev).  PANOFLOW_FUSE_UPS_PX overrides both.
+  static const long fuseUpsEnv = [] { const char* e = getenv("PANOFLOW_FUSE_UPS_PX"); return e ? atol(e) : -1l; }();
+  const long fuseUpsPx = fuseUpsEnv >= 0 ? fuseUpsEnv : c->fuse_ups_px;
+  auto fuse_ups = [&](int level) { return (long)g.ws[level] * g.hs[level] <= fuseUpsPx; };   // level whose incoming flow is upsampled inside its Gaussian
+  float* prev_res[2] = {nullptr, nullptr};
   auto enqueue_level = [&](int d, int level) {
     hipStream_t st = c->s_dir[d];
     if (level == split - 1) hipStreamWaitEvent(st, c->ev_fine, 0);   // first level whose gradients come from the second launch
@@ -415,13 +426,19 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
       }
     }
     float* res = nullptr;
+    // small levels: the upsample of the previous (coarser) level's result rides in this level's first Gaussian
+    const bool upsHere = level < g.n - 1 && fuse_ups(level);
     run_level(c, st, grad[i0] + 2 * o, grad[i1] + 2 * o, pyrA[i0] + o, pyrA[i1] + o, gate + o, w, h, sparse, boxes.empty() ? nullptr : &boxes[4 * level], b,
               bnd[d] + bnd_off[level],
               bnd[d] + bnd_total + bnd_off[level], ctrl[d] + level * 4, ctrl[d] + level * 4 + 2, &res,
-              sb.prepcnt[d] + sb.pc_off[level], sb.prepcnt[d] + sb.pc_off[level] + sweep2_num_wgs_max(w, h));
+              sb.prepcnt[d] + sb.pc_off[level], sb.prepcnt[d] + sb.pc_off[level] + sweep2_num_wgs_max(w, h),
+              upsHere ? prev_res[d] : nullptr, upsHere ? g.ws[level + 1] : 0, upsHere ? g.hs[level + 1] : 0);
+    prev_res[d] = res;
     if (level > 0) {
-      PROF(c, st, "upsample_cubic");
-      launch_upsample_cubic(st, res, w, h, b.flow_a, g.ws[level - 1], g.hs[level - 1], 1.0f / kPyrScaleFactor);
+      if (!fuse_ups(level - 1)) {
+        PROF(c, st, "upsample_cubic");
+        launch_upsample_cubic(st, res, w, h, b.flow_a, g.ws[level - 1], g.hs[level - 1], 1.0f / kPyrScaleFactor);
+      }
     } else {
       PROF(c, st, "final_flow");
       launch_final_flow(st, res, w, h, g.ce, rows, pad, 1.0f / kDownscaleFactor, c->g3_1, d_out[d]);
@@ -663,6 +680,8 @@ int pf_novel_view_batch_dev(pf_ctx* c, int n_pairs, const uint8_t* const* d_l, c
   std::vector<std::string> msg(in_flight);
   auto run = [&](int k) {
     pf_ctx* lane = k == 0 ? c : c->lanes[k - 1];
+    struct Restore { pf_ctx* l; long v; ~Restore() { l->fuse_ups_px = v; } } restore{lane, lane->fuse_ups_px};
+    if (in_flight > 1) lane->fuse_ups_px = 262144;   // side by side, launches count more than their length (see solve())
     for (int i = k; i < n_pairs; i += in_flight) {
       const int e = pf_novel_view_dev(lane, d_l[i], d_r[i], cols, rows, max_pct, d_blend[i], d_out[i], d_l2r ? d_l2r[i] : nullptr, d_r2l ? d_r2l[i] : nullptr);
       if (e) { rc[k] = e; msg[k] = lane->err; return; }
