@@ -237,6 +237,74 @@ void launch_count_gate(hipStream_t st, const uint8_t* gate, int n, unsigned* cou
   hipLaunchKernelGGL(k_count_gate, dim3(blocks), dim3(256), 0, st, gate, n, count);
 }
 
+// ------------------------------------------------------------------------------------------------
+// K7 medianBlur(5) on float2, per channel, BORDER_REPLICATE, out of place (PixFlow.hpp:325,338).
+// Exact selection by "forgetful selection": keep a pool of n/2+2 candidates, drop its min and max,
+// add the next element; the survivor of the last 3 is the median.  All in registers.
+// ------------------------------------------------------------------------------------------------
+#define PF_CE(a, b) { const float lo_ = __builtin_fminf(a, b); const float hi_ = __builtin_fmaxf(a, b); a = lo_; b = hi_; }
+template <int N>
+__device__ __forceinline__ void d_minmax(float* v) {  // afterwards v[0] = min, v[N-1] = max of v[0..N-1]
+#pragma unroll
+  for (int i = 0; i + 1 < N; i += 2) PF_CE(v[i], v[i + 1]);
+#pragma unroll
+  for (int i = 2; i < N; i += 2) PF_CE(v[0], v[i]);
+#pragma unroll
+  for (int i = 1; i < N - 1; i += 2) PF_CE(v[i], v[N - 1]);
+}
+// Two horizontally adjacent outputs per thread.  Their 5x5 windows share four columns (20 values): an element of that shared
+// set can only be the median (rank 13 of 25) of either window if its rank inside the set is 8..13 -- it has at least rank-1
+// and at most rank-1+5 values below it -- so the 7 smallest and 7 largest shared values are dropped ONCE (forgetful
+// selection), and each output then selects the median of 11 = 6 survivors + its own fifth column.  Pure selection: the value
+// is the one any exact median returns; ~80 compare-exchanges per output and channel instead of ~130.
+__device__ __forceinline__ void d_mid6of20(float* v) {   // afterwards v[1..6] hold the elements of rank 8..13 of v[0..19]
+  d_minmax<14>(v); v[0] = v[14];
+  d_minmax<13>(v); v[0] = v[15];
+  d_minmax<12>(v); v[0] = v[16];
+  d_minmax<11>(v); v[0] = v[17];
+  d_minmax<10>(v); v[0] = v[18];
+  d_minmax<9>(v); v[0] = v[19];
+  d_minmax<8>(v);
+}
+__device__ __forceinline__ float d_median11(float* v) {  // median of v[0..10]
+  d_minmax<7>(v); v[0] = v[7];
+  d_minmax<6>(v); v[0] = v[8];
+  d_minmax<5>(v); v[0] = v[9];
+  d_minmax<4>(v); v[0] = v[10];
+  d_minmax<3>(v);
+  return v[1];
+}
+// One output pixel of medianBlur(5), with exactly the operations k_median5 performs for it (that kernel computes outputs xp = x & ~1
+// and xp + 1 together; which four columns are shared depends on the parity of x) -- used by the Gaussian that takes the median
+// while it loads (small levels in the throughput mode).
+__device__ __forceinline__ float2 d_median5_px(const float2* __restrict__ src, int w, int h, int x, int y) {
+  const int o = x & 1, xp = x - o;
+  float2 col[6][5];   // columns xp-2 .. xp+3 (replicate border), rows y-2 .. y+2; output o does not use column (o ? 0 : 5)
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const float2* r = src + size_t(d_replicate(y + j - 2, h)) * w;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) col[i][j] = r[d_replicate(xp + i - 2, w)];
+  }
+  float m[2];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {
+    float s[20];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) s[i * 5 + j] = ch ? col[i + 1][j].y : col[i + 1][j].x;
+    d_mid6of20(s);
+    float t[11];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t[k] = s[k + 1];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { const float2 e = o ? col[5][j] : col[0][j]; t[6 + j] = ch ? e.y : e.x; }
+    m[ch] = d_median11(t);
+  }
+  return make_float2(m[0], m[1]);
+}
+
 // one output pixel of the inter-level upsample (K9 below: resize INTER_CUBIC on float2, then *= 1/0.9f); shared by
 // k_upsample_cubic and by the Gauss15 kernel that upsamples while it loads (small levels)
 __device__ __forceinline__ float2 d_upsample_cubic_px(const float2* __restrict__ src, int sw, int sh, int dx, int dy, double scale_x, double scale_y, float mul) {
@@ -312,7 +380,7 @@ constexpr int kG15Pre = (kG15SW * kG15SH + 255) / 256;                     // 15
 // (PixFlow.hpp:122-125); the tile loader computes it on the fly (same expressions as k_upsample_cubic) and writes the tile's own
 // 64 x 32 pixels of it to `up_out`, which saves the separate upsample launch where a launch costs more than its work.
 struct UpsSrc { const float2* src; int sw, sh; double scale_x, scale_y; float mul; float2* up_out; };
-template <bool MIX, bool UPS>
+template <bool MIX, bool UPS, bool MED>
 __global__ __launch_bounds__(256, 3) void k_gauss15_fused(const float2* __restrict__ src, float2* __restrict__ dst, int w, int h, Gauss g,
                                                         const float* __restrict__ a0, const float* __restrict__ a1, int ntx, int ntiles, UpsSrc ups) {
   constexpr int SW = kG15SW, SH = kG15SH;
@@ -332,12 +400,19 @@ __global__ __launch_bounds__(256, 3) void k_gauss15_fused(const float2* __restri
     }
   };
   int tile = blockIdx.x;
-  if (!UPS && tile < ntiles) fetch(tile);
+  constexpr bool DIRECT = UPS || MED;   // the loader computes its texels: no register prefetch of the next tile
+  if (!DIRECT && tile < ntiles) fetch(tile);
   while (tile < ntiles) {
     const int x0 = (tile % ntx) * kG15TX, y0 = (tile / ntx) * kG15TY;
     const int rowsNeeded = min(SH, h + kG15R - (y0 - kG15R));
     // ---- (1) source tile: registers -> LDS ----
-    if (UPS) {
+    if (MED) {
+      // the source is the median-filtered plane (medianBlur 5, PixFlow.hpp:338), computed here instead of by its own launch
+      for (int t = threadIdx.x; t < rowsNeeded * SW; t += 256) {
+        const int r = t / SW, cidx = t - r * SW;
+        srct[r * SS + cidx] = d_median5_px(src, w, h, d_reflect101(min(x0 - kG15R + cidx, w - 1 + kG15R), w), d_reflect101(y0 - kG15R + r, h));
+      }
+    } else if (UPS) {
       for (int t = threadIdx.x; t < rowsNeeded * SW; t += 256) {
         const int r = t / SW, cidx = t - r * SW;
         const int yy = d_reflect101(y0 - kG15R + r, h), xx = d_reflect101(min(x0 - kG15R + cidx, w - 1 + kG15R), w);
@@ -356,7 +431,7 @@ __global__ __launch_bounds__(256, 3) void k_gauss15_fused(const float2* __restri
     }
     __syncthreads();
     const int next = tile + int(gridDim.x);
-    if (!UPS && next < ntiles) fetch(next);
+    if (!DIRECT && next < ntiles) fetch(next);
     // ---- (2) row pass: lane = source row (46 of 64 lanes), wave = 16 output columns; 30 values -> 16 outputs ----
     if (lane < rowsNeeded) {
       const float2* sr = srct + lane * SS + wv * 16;
@@ -416,7 +491,7 @@ void launch_gauss15(hipStream_t st, const float* src, float* tmp, float* dst, in
   (void)tmp;
   int ntx, ntiles; unsigned blocks;
   gauss15_grid(w, h, ntx, ntiles, blocks);
-  hipLaunchKernelGGL((k_gauss15_fused<false, false>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h, g15, nullptr, nullptr, ntx, ntiles, UpsSrc{});
+  hipLaunchKernelGGL((k_gauss15_fused<false, false, false>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h, g15, nullptr, nullptr, ntx, ntiles, UpsSrc{});
 }
 
 // upsample (coarse sw x sh -> w x h, times mul) + Gauss15 of the upsampled plane in one launch: `up` receives the upsampled flow
@@ -424,7 +499,7 @@ void launch_gauss15_upsample(hipStream_t st, const float* coarse, int sw, int sh
   int ntx, ntiles; unsigned blocks;
   gauss15_grid(w, h, ntx, ntiles, blocks);
   const UpsSrc u{reinterpret_cast<const float2*>(coarse), sw, sh, 1. / ((double)w / sw), 1. / ((double)h / sh), mul, reinterpret_cast<float2*>(up)};
-  hipLaunchKernelGGL((k_gauss15_fused<false, true>), dim3(blocks), dim3(256), 0, st, nullptr, reinterpret_cast<float2*>(dst), w, h, g15, nullptr, nullptr, ntx, ntiles, u);
+  hipLaunchKernelGGL((k_gauss15_fused<false, true, false>), dim3(blocks), dim3(256), 0, st, nullptr, reinterpret_cast<float2*>(dst), w, h, g15, nullptr, nullptr, ntx, ntiles, u);
 }
 
 // K8 lowAlphaFlowDiffusion (PixFlow.hpp:388-405): column pass fused with the alpha mix.
@@ -442,46 +517,9 @@ void launch_gauss15_mix(hipStream_t st, float* flow, float* tmp, const float* a0
   (void)tmp;
   int ntx, ntiles; unsigned blocks;
   gauss15_grid(w, h, ntx, ntiles, blocks);
-  hipLaunchKernelGGL((k_gauss15_fused<true, false>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float2*>(flow), reinterpret_cast<float2*>(out), w, h, g15, a0, a1, ntx, ntiles, UpsSrc{});
+  hipLaunchKernelGGL((k_gauss15_fused<true, false, false>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float2*>(flow), reinterpret_cast<float2*>(out), w, h, g15, a0, a1, ntx, ntiles, UpsSrc{});
 }
 
-// ------------------------------------------------------------------------------------------------
-// K7 medianBlur(5) on float2, per channel, BORDER_REPLICATE, out of place (PixFlow.hpp:325,338).
-// Exact selection by "forgetful selection": keep a pool of n/2+2 candidates, drop its min and max,
-// add the next element; the survivor of the last 3 is the median.  All in registers.
-// ------------------------------------------------------------------------------------------------
-#define PF_CE(a, b) { const float lo_ = __builtin_fminf(a, b); const float hi_ = __builtin_fmaxf(a, b); a = lo_; b = hi_; }
-template <int N>
-__device__ __forceinline__ void d_minmax(float* v) {  // afterwards v[0] = min, v[N-1] = max of v[0..N-1]
-#pragma unroll
-  for (int i = 0; i + 1 < N; i += 2) PF_CE(v[i], v[i + 1]);
-#pragma unroll
-  for (int i = 2; i < N; i += 2) PF_CE(v[0], v[i]);
-#pragma unroll
-  for (int i = 1; i < N - 1; i += 2) PF_CE(v[i], v[N - 1]);
-}
-// Two horizontally adjacent outputs per thread.  Their 5x5 windows share four columns (20 values): an element of that shared
-// set can only be the median (rank 13 of 25) of either window if its rank inside the set is 8..13 -- it has at least rank-1
-// and at most rank-1+5 values below it -- so the 7 smallest and 7 largest shared values are dropped ONCE (forgetful
-// selection), and each output then selects the median of 11 = 6 survivors + its own fifth column.  Pure selection: the value
-// is the one any exact median returns; ~80 compare-exchanges per output and channel instead of ~130.
-__device__ __forceinline__ void d_mid6of20(float* v) {   // afterwards v[1..6] hold the elements of rank 8..13 of v[0..19]
-  d_minmax<14>(v); v[0] = v[14];
-  d_minmax<13>(v); v[0] = v[15];
-  d_minmax<12>(v); v[0] = v[16];
-  d_minmax<11>(v); v[0] = v[17];
-  d_minmax<10>(v); v[0] = v[18];
-  d_minmax<9>(v); v[0] = v[19];
-  d_minmax<8>(v);
-}
-__device__ __forceinline__ float d_median11(float* v) {  // median of v[0..10]
-  d_minmax<7>(v); v[0] = v[7];
-  d_minmax<6>(v); v[0] = v[8];
-  d_minmax<5>(v); v[0] = v[9];
-  d_minmax<4>(v); v[0] = v[10];
-  d_minmax<3>(v);
-  return v[1];
-}
 __global__ __launch_bounds__(256) void k_median5(const float2* __restrict__ src, float2* __restrict__ dst, int w, int h) {
   const int xp = (blockIdx.x * blockDim.x + threadIdx.x) * 2, y = blockIdx.y;   // outputs xp and xp + 1
   if (xp >= w) return;
@@ -517,6 +555,13 @@ __global__ __launch_bounds__(256) void k_median5(const float2* __restrict__ src,
 void launch_median5(hipStream_t st, const float* src, float* dst, int w, int h) {
   dim3 grid(((w + 1) / 2 + 255) / 256, h);
   hipLaunchKernelGGL(k_median5, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h);
+}
+
+// medianBlur(5) + lowAlphaFlowDiffusion in one launch: `flow` is the backward sweep's output, `out` a different plane
+void launch_median_gauss15_mix(hipStream_t st, const float* flow, const float* a0, const float* a1, int w, int h, const Gauss& g15, float* out) {
+  int ntx, ntiles; unsigned blocks;
+  gauss15_grid(w, h, ntx, ntiles, blocks);
+  hipLaunchKernelGGL((k_gauss15_fused<true, false, true>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float2*>(flow), reinterpret_cast<float2*>(out), w, h, g15, a0, a1, ntx, ntiles, UpsSrc{});
 }
 
 // ------------------------------------------------------------------------------------------------

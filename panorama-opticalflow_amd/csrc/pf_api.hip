@@ -170,6 +170,13 @@ int check_dims(pf_ctx* c, int cols, int rows, int pad) {
   return 0;
 }
 
+// Levels up to this many pixels trade launches for longer kernels (upsample inside the next Gaussian, second median inside the
+// diffusion): 0 for a lone pair, set by the throughput mode for its lanes; PANOFLOW_FUSE_UPS_PX overrides both.
+long fuse_small_px(const pf_ctx* c) {
+  static const long env = [] { const char* e = getenv("PANOFLOW_FUSE_UPS_PX"); return e ? atol(e) : -1l; }();
+  return env >= 0 ? env : c->fuse_ups_px;
+}
+
 // One level of one direction (PixFlow.hpp:272-340, gradients excluded: they are precomputed for all levels).
 // flow_a holds the incoming flow and receives the level's result (flow_b, blurred, tmp are scratch).
 struct LevelBufs { float *flow_a, *flow_b, *blurred, *tmp, *rec; };
@@ -203,6 +210,13 @@ void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, cons
   { sa.flow = reinterpret_cast<float2*>(b.flow_a); sa.boundary = bnd_fwd; sa.ctrl = ctrl_fwd; sa.prepcnt = pc_fwd; sa.forward = 1; sweep(sa); }
   { PROF(c, st, "median5"); launch_median5(st, b.flow_a, b.flow_b, w, h); }
   { sa.flow = reinterpret_cast<float2*>(b.flow_b); sa.boundary = bnd_bwd; sa.ctrl = ctrl_bwd; sa.prepcnt = pc_bwd; sa.forward = 0; sweep(sa); }
+  if ((long)w * h <= fuse_small_px(c)) {
+    // throughput mode, small levels: the second median rides in the diffusion's tile loader (one launch fewer; result in b.tmp,
+    // which nothing else uses: it must not be flow_a, the plane the next level's incoming flow is written to)
+    PROF(c, st, "gauss15_diffusion"); launch_median_gauss15_mix(st, b.flow_b, a0, a1, w, h, c->g15, b.tmp);
+    *result = b.tmp;
+    return;
+  }
   { PROF(c, st, "median5"); launch_median5(st, b.flow_b, b.flow_a, w, h); }
   { PROF(c, st, "gauss15_diffusion"); launch_gauss15_mix(st, b.flow_a, b.tmp, a0, a1, w, h, c->g15, b.flow_b); }
   *result = b.flow_b;
@@ -406,8 +420,7 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   // Fewer launches or shorter launches?  Alone, a pair is faster with the separate upsample kernel (strip 27.36 vs 27.44 ms); with
   // several pairs in flight the time between a stream's kernels dominates and one launch fewer per level wins (+3 %): the
   // throughput mode turns the fusion on for its lanes (pf_novel_view_batch_dev).  PANOFLOW_FUSE_UPS_PX overrides both.
-  static const long fuseUpsEnv = [] { const char* e = getenv("PANOFLOW_FUSE_UPS_PX"); return e ? atol(e) : -1l; }();
-  const long fuseUpsPx = fuseUpsEnv >= 0 ? fuseUpsEnv : c->fuse_ups_px;
+  const long fuseUpsPx = fuse_small_px(c);
   auto fuse_ups = [&](int level) { return (long)g.ws[level] * g.hs[level] <= fuseUpsPx; };   // level whose incoming flow is upsampled inside its Gaussian
   float* prev_res[2] = {nullptr, nullptr};
   auto enqueue_level = [&](int d, int level) {
