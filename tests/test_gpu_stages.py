@@ -270,13 +270,14 @@ def test_level_fuzz_alpha_patterns(ctx, orc):
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "case %d (%dx%d): %d mismatches" % (case, w, h, (got.view(np.uint32) != ref.view(np.uint32)).sum())
 
 
-@pytest.mark.parametrize("mode", ["1", "2", "relax"])
+@pytest.mark.parametrize("mode", ["1", "2", "relax", "fuse"])
 def test_sweep_record_experiment_paths_are_bit_identical(mode):
     """Rejected-on-measurement alternatives kept behind a switch must stay exact.  Mode relax = PANOFLOW_SWEEP=3, the event-driven
     relaxation sweep on LDS-resident tiles (kernels_relax.inl: same fixed point reached in any evaluation order; slower than the
     wavefront because the longest dependency chain, not the anti-diagonal count, still sets its time:
     profiles/r02_relaxation_sweep.txt).  PANOFLOW_PREP=1 (loader waves compute the records) and =2 (prepass blocks inside the sweep launch, G16/R1 hand-off) are
-    the two record-path experiments.  The switches are read once per process."""
+    the two record-path experiments.  Mode fuse = the throughput mode's launch fusion (upsample inside the next level's Gaussian,
+    second median inside the diffusion kernel) forced on for every level.  The switches are read once per process."""
     import os, subprocess, sys
     code = r'''
 import sys, os, numpy as np
@@ -302,6 +303,6 @@ assert np.array_equal(f0, r0) and np.array_equal(f1, r1)
 print("ok")
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, **({"PANOFLOW_SWEEP": "3"} if mode == "relax" else {"PANOFLOW_PREP": mode}))
+    env = dict(os.environ, **({"PANOFLOW_SWEEP": "3"} if mode == "relax" else {"PANOFLOW_FUSE_UPS_PX": "100000000"} if mode == "fuse" else {"PANOFLOW_PREP": mode}))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
