@@ -107,7 +107,10 @@ int pf_stitch_prefetch(pf_ctx* ctx, const uint8_t* next_l_bgra, int cols, int ro
 
 /* ---- device-resident entry points (packed buffers already in this context's HBM) -----------
  * Same semantics as above; used by bench.py (inputs resident when the clock starts) and by the
- * multi-GPU driver.  Pointers are device pointers on the context's device. */
+ * multi-GPU driver.  Pointers are device pointers on the context's device.  The calls are synchronous on
+ * return, but they run on the context's own non-blocking streams and do NOT wait for work the caller has
+ * in flight on other streams: inputs produced there (e.g. by a framework's kernels) must be complete --
+ * synchronise that stream or the device -- before the call. */
 void* pf_dev_alloc(pf_ctx* ctx, size_t bytes);
 void pf_dev_free(pf_ctx* ctx, void* dptr);
 int pf_upload(pf_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);

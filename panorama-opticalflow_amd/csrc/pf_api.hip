@@ -99,6 +99,12 @@ void* ensure(pf_ctx* c, const char* name, size_t bytes) {
   const size_t cap = (bytes + 255) & ~size_t(255);
   if (hipMalloc(&b.p, cap) != hipSuccess) { b.p = nullptr; fail(c, PF_ERR_NOMEM, "hipMalloc(%zu) for '%s' failed", cap, name); return nullptr; }
   b.cap = cap;
+  // debugging aid: PANOFLOW_POISON=all | <buffer name> fills fresh allocations with 0xFF bytes (NaNs / -1): a result that depends
+  // on it reads memory it never wrote
+  if (const char* po = getenv("PANOFLOW_POISON")) {
+    if (strcmp(po, "all") == 0 || strstr(po, name) != nullptr) { hipMemset(b.p, 0xFF, cap); hipDeviceSynchronize(); }
+    else if (strcmp(po, "zero") == 0 || po[0] == '!') { hipMemset(b.p, (po[0] == '!' && strstr(po + 1, name) != nullptr) ? 0xFF : 0x00, cap); hipDeviceSynchronize(); }
+  }
   return b.p;
 }
 

@@ -10,6 +10,7 @@ n_canvas = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 dev = torch.device("cuda", 0)
 def run(cols, rows, n, in_flight):
     L, R, B, _ = synth.make_pair(cols, rows, 4242, dev)
+    torch.cuda.synchronize()   # the library's streams do not wait for torch's: inputs must be complete before the first call
     c = pf.Context(0, cols, rows)
     nb = max(in_flight, 1) * 2
     outs = [torch.empty((rows, cols, 4), dtype=torch.uint8, device=dev) for _ in range(nb)]
