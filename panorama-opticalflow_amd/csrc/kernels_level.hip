@@ -389,9 +389,18 @@ __global__ __launch_bounds__(256, 3) void k_gauss15_fused(const float2* __restri
   __shared__ float2 rowp[SH * RS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float2 pre[kG15Pre];
+  float coef[8];   // MIX: diffusion coefficients of this thread's eight outputs of the prefetched tile
   auto fetch = [&](int tile) {
     const int x0 = (tile % ntx) * kG15TX, y0 = (tile / ntx) * kG15TY;
     const int rowsNeeded = min(SH, h + kG15R - (y0 - kG15R));   // rows past (h - 1) + 7 are read by no output of this tile
+    if (MIX) {
+      const int xq = x0 + lane, yq = y0 + wv * 8;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        const size_t i = size_t(min(yq + o, h - 1)) * w + min(xq, w - 1);
+        coef[o] = 1.0f - a0[i] * a1[i];
+      }
+    }
 #pragma unroll
     for (int k = 0; k < kG15Pre; ++k) {
       const int t = threadIdx.x + 256 * k;
@@ -430,6 +439,9 @@ __global__ __launch_bounds__(256, 3) void k_gauss15_fused(const float2* __restri
       }
     }
     __syncthreads();
+    float cf[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) cf[o] = coef[o];
     const int next = tile + int(gridDim.x);
     if (!DIRECT && next < ntiles) fetch(next);
     // ---- (2) row pass: lane = source row (46 of 64 lanes), wave = 16 output columns; 30 values -> 16 outputs ----
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(256, 3) void k_gauss15_fused(const float2* __restri
         const size_t i = size_t(y) * w + x;
         if (MIX) {
           const float2 f = srct[(oy0 + o + kG15R) * SS + lane + kG15R];
-          const float diffusionCoef = 1.0f - a0[i] * a1[i];
+          const float diffusionCoef = DIRECT ? 1.0f - a0[i] * a1[i] : cf[o];
           dst[i] = make_float2(diffusionCoef * sx + (1.0f - diffusionCoef) * f.x, diffusionCoef * sy + (1.0f - diffusionCoef) * f.y);
         } else {
           dst[i] = make_float2(sx, sy);
