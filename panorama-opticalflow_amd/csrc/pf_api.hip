@@ -39,6 +39,7 @@ struct pf_ctx {
   hipEvent_t ev_alpha = nullptr, ev_gate = nullptr;
   hipEvent_t ev_aux_go = nullptr, ev_aux_done = nullptr;
   hipEvent_t ev_pre = nullptr, ev_dir[2] = {nullptr, nullptr};
+  hipEvent_t ev_stagger = nullptr;
   hipEvent_t ev_fine2 = nullptr;  // ... of the finest levels (narrow launch)
   hipEvent_t ev_fine = nullptr;   // gradients of the fine levels done (the directions start on the coarse ones before that)
   std::string err;
@@ -46,6 +47,7 @@ struct pf_ctx {
   Gauss g5, g3_05, g3_1, g15;
   int prof = 0;   // 0 off, 1 every kernel family, 2 only the dominant family (the sweeps): fewer events in a timed region
   int sweep_version = 2;
+  bool is_lane = false;   // one of several lanes of pf_novel_view_batch_dev running side by side
   long fuse_ups_px = 0;   // levels up to this many pixels get their incoming flow upsampled inside their first Gaussian (0 = never)
   int chain_cols = 0, chain_rows = 0;   // size of the stitch-chain result resident in "ch_final"
   long long last_swept_steps = 0;       // wavefront steps of one direction of the last solve (both sweeps, all levels, gated windows)
@@ -464,8 +466,31 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
     }
   };
   // (Measured and rejected: one host thread per direction -- +0.1 ms per pair; the GPU, not the host, paces the launches.)
-  for (int level = g.n - 1; level >= 0; --level)
-    for (int d = 0; d < ndirs; ++d) enqueue_level(d, level);
+  // Direction 1 starts when direction 0 has finished its k coarsest levels.  Started together, the two directions stay in lockstep:
+  // their throughput kernels (Gaussians, medians, prepass) run beside each other, each at half speed, and their sweeps -- which
+  // leave most CUs idle -- run beside each other too.  A small offset puts one direction's throughput kernels beside the other's
+  // sweeps.  The late direction finishes k coarse levels later, which is what limits k: measured (profiles/r02_frontend_ab.txt)
+  // strip 27.36 -> 27.18 ms at k = 2, 9000x4000 pair 59.1 -> 57.7 ms at k = 4-6.  Not for the lanes of the throughput mode (they are
+  // out of phase with each other anyway: -1 %).  PANOFLOW_STAGGER overrides.
+  static const int staggerEnv = [] { const char* e = getenv("PANOFLOW_STAGGER"); return e ? atoi(e) : -1; }();
+  const int stagger = staggerEnv >= 0 ? staggerEnv : (c->is_lane ? 0 : (size_t(g.w0) * g.h0 >= 5000000 ? 4 : 2));
+  if (stagger > 0 && ndirs == 2 && g.n > 1) {
+    const int k = stagger < g.n ? stagger : g.n - 1;
+    for (int t = 0; t < g.n + k; ++t) {
+      const int l0 = g.n - 1 - t, l1 = g.n - 1 - (t - k);
+      if (l0 >= 0) {
+        enqueue_level(0, l0);
+        if (t == k - 1) HIPCHK(c, hipEventRecord(c->ev_stagger, c->s_dir[0]));
+      }
+      if (t >= k && l1 >= 0) {
+        if (t == k) HIPCHK(c, hipStreamWaitEvent(c->s_dir[1], c->ev_stagger, 0));
+        enqueue_level(1, l1);
+      }
+    }
+  } else {
+    for (int level = g.n - 1; level >= 0; --level)
+      for (int d = 0; d < ndirs; ++d) enqueue_level(d, level);
+  }
   for (int d = 0; d < ndirs; ++d) {
     launch_collect_status(c->s_dir[d], ctrl[d], g.n * 4, c->d_status, 1 << d);
     HIPCHK(c, hipEventRecord(c->ev_dir[d], c->s_dir[d]));
@@ -552,7 +577,8 @@ pf_ctx* pf_create(int device, int max_cols, int max_rows) {
   ok = ok && hipEventCreateWithFlags(&c->ev_alpha, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_aux_go, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_fine, hipEventDisableTiming) == hipSuccess &&
-       hipEventCreateWithFlags(&c->ev_fine2, hipEventDisableTiming) == hipSuccess;
+       hipEventCreateWithFlags(&c->ev_fine2, hipEventDisableTiming) == hipSuccess &&
+       hipEventCreateWithFlags(&c->ev_stagger, hipEventDisableTiming) == hipSuccess;
   for (int d = 0; d < 2 && ok; ++d) ok = hipEventCreateWithFlags(&c->ev_dir[d], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_status, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void**)&c->d_status, c->h_status, 0) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_gate, (4 * kLevelTableMax + 2) * sizeof(int), hipHostMallocMapped) == hipSuccess &&
@@ -590,6 +616,7 @@ void pf_destroy(pf_ctx* c) {
   if (c->ev_pre) hipEventDestroy(c->ev_pre);
   if (c->ev_fine) hipEventDestroy(c->ev_fine);
   if (c->ev_fine2) hipEventDestroy(c->ev_fine2);
+  if (c->ev_stagger) hipEventDestroy(c->ev_stagger);
   for (int d = 0; d < 2; ++d) { if (c->ev_dir[d]) hipEventDestroy(c->ev_dir[d]); if (c->s_dir[d]) hipStreamDestroy(c->s_dir[d]); }
   if (c->ev_aux_go) hipEventDestroy(c->ev_aux_go);
   if (c->ev_aux_done) hipEventDestroy(c->ev_aux_done);
@@ -699,8 +726,8 @@ int pf_novel_view_batch_dev(pf_ctx* c, int n_pairs, const uint8_t* const* d_l, c
   std::vector<std::string> msg(in_flight);
   auto run = [&](int k) {
     pf_ctx* lane = k == 0 ? c : c->lanes[k - 1];
-    struct Restore { pf_ctx* l; long v; ~Restore() { l->fuse_ups_px = v; } } restore{lane, lane->fuse_ups_px};
-    if (in_flight > 1) lane->fuse_ups_px = 262144;   // side by side, launches count more than their length (see solve())
+    struct Restore { pf_ctx* l; long v; bool b; ~Restore() { l->fuse_ups_px = v; l->is_lane = b; } } restore{lane, lane->fuse_ups_px, lane->is_lane};
+    if (in_flight > 1) { lane->fuse_ups_px = 262144; lane->is_lane = true; }   // side by side, launches count more than their length (see solve())
     for (int i = k; i < n_pairs; i += in_flight) {
       const int e = pf_novel_view_dev(lane, d_l[i], d_r[i], cols, rows, max_pct, d_blend[i], d_out[i], d_l2r ? d_l2r[i] : nullptr, d_r2l ? d_r2l[i] : nullptr);
       if (e) { rc[k] = e; msg[k] = lane->err; return; }
