@@ -716,6 +716,9 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
     return;
   }
 
+  // helper waves: below the compute waves (3), above another kernel's waves that share this CU -- since the two directions run
+  // out of phase, the other direction's Gaussians / medians / prepass sit on the sweep's SIMDs (strip -0.12 ms, 9000x4000 pair -0.4 ms)
+  __builtin_amdgcn_s_setprio(1);
   if (wave >= kWaves && wave < 2 * kWaves) {
     // ======================= loader of compute wave w: records + gather window HBM -> LDS, up to kRS steps ahead =======================
     // Window batch b = the 8 texel columns (along the step axis) [8b-16, 8b-8) x kWA texels across the band.
