@@ -47,6 +47,26 @@ int pf_device_count(void);
  * now (the first call then pays no allocation); 0 x 0: allocate lazily.  The arena only ever grows, so larger images
  * are still accepted later.  NULL on failure; pf_last_error(NULL) explains. */
 pf_ctx* pf_create(int device, int max_cols, int max_rows);
+/* The same with the scheduling knobs exposed.  None of them changes a result (tests hold every setting to the same bits);
+ * they exist so that a deployment can tune for its image sizes without environment variables.  pf_config_init() fills
+ * in the defaults (= what pf_create uses); set struct_size = sizeof(pf_config). */
+typedef struct pf_config {
+  int struct_size;
+  int device, max_cols, max_rows;   /* as pf_create */
+  int stagger_levels;       /* direction R->L starts this many coarse levels behind L->R (-1: 2, or 4 for >= 5 Mpix half-res) */
+  long fuse_small_level_px; /* levels up to this many pixels fold the upsample / second median into the neighbouring Gaussian
+                               launches (-1: 0 for a lone pair, 262144 for the lanes of the throughput mode) */
+  int fine_gradient_blocks; /* width of the launch that computes the gradients of the 4 finest levels beside the coarse sweeps (64) */
+  int pyramid_chaining;     /* 1: small pyramid levels are built two or three per launch, 0: one launch per level (1) */
+  int sweep_window;         /* 1: a sweep covers the bounding box of the gated pixels only, 0: the whole level (1) */
+  int sparse_sweep;         /* -1: pick the sweep variant that skips ungated anti-diagonals from the gate density, 0 / 1: force (-1) */
+  /* Cross-check implementations -- only in libpanoflow_exp.so (the -DPF_EXPERIMENTS build used by the test-suite);
+   * libpanoflow.so rejects anything but the defaults with PF_ERR_ARG. */
+  int sweep_impl;           /* 2: wavefront sweep (k_sweep_prep + k_sweep2); 1: the independent 64-rows-per-wave kernel; 3: LDS-tile relaxation */
+  int record_path;          /* 0: k_sweep_prep in front of the sweep; 1: loader waves compute the records; 2: prepass blocks inside the sweep launch */
+} pf_config;
+void pf_config_init(pf_config* cfg);
+pf_ctx* pf_create_cfg(const pf_config* cfg);
 void pf_destroy(pf_ctx* ctx);
 const char* pf_last_error(const pf_ctx* ctx);  /* ctx may be NULL (creation errors) */
 const char* pf_version(void);
@@ -100,9 +120,10 @@ int pf_stitch_gather(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, 
 int pf_stitch_step(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, int cols, int rows, size_t step_bytes,
                    int max_percentage, uint8_t* out_bgra, size_t out_step_bytes);
 
-/* Hint: l_bgra of the NEXT pf_stitch_step call.  Its host->device upload is then issued inside the current step, after that
- * step's kernels are enqueued, so it overlaps the compute (CPU/main.cpp:66-69 reads image i+1 only after step i).  The
- * buffer must stay valid and unchanged until that next call; NULL cancels.  Purely an optimisation: results are identical. */
+/* Hint, given BEFORE step i: the l_bgra of step i+1.  Step i then issues that host->device upload after its own kernels are
+ * enqueued, so it overlaps the compute (CPU/main.cpp:66-69 reads image i+1 only after step i).  One-shot: step i consumes the
+ * hint, step i+1 consumes (or, if it is called with anything else, drops) the uploaded copy; the buffer must stay valid and
+ * unchanged until step i+1 has returned.  NULL cancels.  Purely an optimisation: results are identical. */
 int pf_stitch_prefetch(pf_ctx* ctx, const uint8_t* next_l_bgra, int cols, int rows, size_t step_bytes);
 
 /* ---- device-resident entry points (packed buffers already in this context's HBM) -----------
@@ -113,9 +134,16 @@ int pf_stitch_prefetch(pf_ctx* ctx, const uint8_t* next_l_bgra, int cols, int ro
  * synchronise that stream or the device -- before the call. */
 void* pf_dev_alloc(pf_ctx* ctx, size_t bytes);
 void pf_dev_free(pf_ctx* ctx, void* dptr);
+/* Page-locked host memory for images handed to / received from the host-buffer entry points (optional: any host memory works,
+ * pinned memory is copied at the link's DMA rate instead of through the runtime's bounce buffers). */
+void* pf_host_alloc(pf_ctx* ctx, size_t bytes);
+void pf_host_free(pf_ctx* ctx, void* hptr);
 int pf_upload(pf_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int pf_download(pf_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int pf_sync(pf_ctx* ctx);
+/* 64-bit content checksum of a device buffer (8-byte aligned), computed on the device: compares or verifies results that stay in
+ * HBM (e.g. a strip at its producer and after the gather to rank 0) without moving them through the host. */
+int pf_checksum_dev(pf_ctx* ctx, const void* d_ptr, size_t bytes, uint64_t* checksum_out);
 
 int pf_flow_bidir_dev(pf_ctx* ctx, const uint8_t* d_l, const uint8_t* d_r, int cols, int rows, int max_percentage,
                       float* d_flow_l2r, float* d_flow_r2l);

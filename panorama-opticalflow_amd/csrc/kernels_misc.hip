@@ -1,6 +1,7 @@
 // K4 coarsest-level search (CPU/PixFlow.hpp:153-270), K11 novel-view blend (CPU/OpticalFlow.cpp:9-92),
 // K12-K15 StitchTool kernels (CPU/StitchTool.cpp).
 #include "pf_common.hpp"
+#include "libm_exact.hpp"
 
 namespace pf {
 
@@ -130,10 +131,12 @@ __global__ __launch_bounds__(256) void k_blend(const uchar4* __restrict__ L, con
     const float flowMagLR = sqrtf(fLR.x * fLR.x + fLR.y * fLR.y) / float(cols);
     const float flowMagRL = sqrtf(fRL.x * fRL.x + fRL.y * fRL.y) / float(cols);
     const float colorDiff = (abs(int(colorL.x) - int(colorR.x)) + abs(int(colorL.y) - int(colorR.y)) + abs(int(colorL.z) - int(colorR.z))) / 255.0f;
-    const float deghostCoef = tanhf(colorDiff * kColorDiffCoef);
+    // tanhf / exp with the host libm's roundings (libm_exact.hpp): where the two warped colours agree, c*wL + c*wR sits within
+    // an ulp of the integer c and a last-place difference in either function flips the truncated byte
+    const float deghostCoef = pf_libm::tanhf_exact(colorDiff * kColorDiffCoef);
     const float alphaL = colorL.w / 255.0f, alphaR = colorR.w / 255.0f;
-    const double expL = exp(kSoftmaxSharpness * blendL * alphaL * (1.0 + kFlowMagCoef * flowMagRL));
-    const double expR = exp(kSoftmaxSharpness * blendR * alphaR * (1.0 + kFlowMagCoef * flowMagLR));
+    const double expL = pf_libm::exp_exact(kSoftmaxSharpness * blendL * alphaL * (1.0 + kFlowMagCoef * flowMagRL), pf_libm::kExpTab);
+    const double expR = pf_libm::exp_exact(kSoftmaxSharpness * blendR * alphaR * (1.0 + kFlowMagCoef * flowMagLR), pf_libm::kExpTab);
     const double sumExp = expL + expR + 0.00001;
     const float softmaxL = float(expL / sumExp), softmaxR = float(expR / sumExp);
     const float wL = d_lerp(blendL, softmaxL, deghostCoef), wR = d_lerp(blendR, softmaxR, deghostCoef);

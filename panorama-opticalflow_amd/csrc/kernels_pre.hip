@@ -211,6 +211,33 @@ void launch_fill_u64(hipStream_t st, unsigned long long* p, size_t n, unsigned l
 
 // Did any sweep launch of a solve give up (ctrl[4*l+1], ctrl[4*l+3])?  One word in mapped pinned host memory per
 // context: the host reads it after the stream sync the call ends with -- no copy, no extra sync.
+// 64-bit content checksum of a device buffer: sum over 8-byte words of mix(word ^ index * K) (splitmix64 finaliser), so that
+// it is order-independent (one atomic add per wave) yet position-sensitive.  Lets a caller compare results that live on
+// different GPUs -- or verify a gather -- without moving them to the host (tools/pano_batch).
+__global__ __launch_bounds__(256) void k_checksum64(const unsigned long long* __restrict__ p, size_t nwords, const uint8_t* __restrict__ tail, int ntail,
+                                                    unsigned long long* __restrict__ acc) {
+  unsigned long long h = 0;
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < nwords + (ntail ? 1 : 0); i += size_t(gridDim.x) * blockDim.x) {
+    unsigned long long w = 0;
+    if (i < nwords) w = p[i];
+    else for (int k = 0; k < ntail; ++k) w |= (unsigned long long)tail[k] << (8 * k);
+    unsigned long long z = w ^ ((i + 1) * 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    h += z ^ (z >> 31);
+  }
+  for (int o = 32; o > 0; o >>= 1) h += __shfl_down(h, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(acc, h);
+}
+void launch_checksum64(hipStream_t st, const void* p, size_t bytes, unsigned long long* acc /* zeroed by the caller */) {
+  const size_t nwords = bytes / 8;
+  size_t blocks = (nwords + 1 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(k_checksum64, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const unsigned long long*>(p), nwords,
+                     static_cast<const uint8_t*>(p) + nwords * 8, int(bytes - nwords * 8), acc);
+}
+
 __global__ void k_collect_status(const int* __restrict__ ctrl, int nwords, int* __restrict__ status, int bit) {
   int bad = 0;
   for (int i = threadIdx.x; i < nwords; i += blockDim.x) if ((i & 1) && ctrl[i]) bad = 1;

@@ -16,6 +16,9 @@
 // bounded, and a timeout raises ctrl[1] instead of hanging the GPU.
 //
 // The backward sweep is the same kernel in mirrored coordinates (x -> W-1-x, y -> H-1-y).
+//
+// LAB BUILD ONLY (-DPF_EXPERIMENTS, libpanoflow_exp.so): this v1 kernel is the independent GPU cross-check of the product's
+// sweep (kernels_sweep2.hip); it is not compiled into libpanoflow.so.
 #include <algorithm>
 
 #include "pf_common.hpp"
@@ -135,8 +138,7 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
   }
 }
 
-size_t sweep_boundary_elems(int W, int H) { const size_t v1 = size_t((H + kBandRows - 1) / kBandRows) * W, v2 = sweep2_boundary_elems(W, H), v3 = sweep_relax_boundary_elems(W, H);
-  return std::max(v1, std::max(v2, v3)); }
+size_t sweep1_boundary_elems(int W, int H) { return size_t((H + kBandRows - 1) / kBandRows) * W; }
 
 void launch_sweep(hipStream_t st, const SweepArgs& a) {
   hipLaunchKernelGGL(k_sweep, dim3((a.H + kBandRows - 1) / kBandRows), dim3(64), 0, st, a);

@@ -979,6 +979,15 @@ size_t sweep2_boundary_elems(int W, int H) {   // hand-off granules of one sweep
   const size_t a = size_t(wgs_for(H) + 1) * W, b = size_t(wgs_for(W) + 1) * H;
   return a > b ? a : b;
 }
+size_t sweep_boundary_elems(int W, int H) {   // hand-off granules a sweep launch on a W x H level may need (every sweep implementation of this build)
+  size_t v = sweep2_boundary_elems(W, H);
+#ifdef PF_EXPERIMENTS
+  const size_t v1 = sweep1_boundary_elems(W, H), v3 = sweep_relax_boundary_elems(W, H);
+  if (v1 > v) v = v1;
+  if (v3 > v) v = v3;
+#endif
+  return v;
+}
 size_t sweep2_rec_bytes(int W, int H) {
   const size_t a = size_t(wgs_for(H)) * kWaves * steps_pad(W), b = size_t(wgs_for(W)) * kWaves * steps_pad(H);
   return (a > b ? a : b) * kRows * 48;
@@ -992,12 +1001,16 @@ bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
   const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
   const size_t prepThreads = total > size_t(LSv) ? total : size_t(LSv);
   const float rW = (float)(1.0 / (double)(float)a.W), rEps = (float)(1.0 / (double)kGradEpsilon);
-  // How the records reach the sweep (PANOFLOW_PREP).  0 (default): k_sweep_prep in front of the sweep.  Two measured and rejected
-  // alternatives stay behind the switch, both bit-identical: 1 = the loader waves compute them (no record traffic through HBM, but
-  // 8 % slower: profiles/r02_fused_prepass_ab.txt); 2 = prepass blocks inside the sweep launch with a write-through + counter +
-  // acquire hand-off (the first bands start microseconds after the launch, yet the launch as a whole is not shorter: same file).
-  static const int prepMode = [] { const char* e = getenv("PANOFLOW_PREP"); const int m = e ? atoi(e) : 0; return (m < 0 || m > 2) ? 0 : m; }();
-  const int mode = (prepMode == 2 && (a.prepcnt == nullptr || total * 48 >= (size_t(1) << 31))) ? 0 : prepMode;
+  // How the records reach the sweep.  0 (the product): k_sweep_prep in front of the sweep.  Two measured and rejected alternatives
+  // exist in the lab build only (-DPF_EXPERIMENTS, SweepArgs::prep_mode), both bit-identical: 1 = the loader waves compute them (no
+  // record traffic through HBM, but 8 % slower: profiles/r02_fused_prepass_ab.txt); 2 = prepass blocks inside the sweep launch with
+  // a write-through + counter + acquire hand-off (the first bands start microseconds after the launch, yet the launch as a whole
+  // is not shorter: same file).
+#ifdef PF_EXPERIMENTS
+  const int mode = (a.prep_mode == 2 && (a.prepcnt == nullptr || total * 48 >= (size_t(1) << 31))) ? 0 : a.prep_mode;
+#else
+  constexpr int mode = 0;
+#endif
   if (mode == 0)
     hipExtLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((prepThreads + 255) / 256)), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate, a.flow,
                           a.W, a.H, a.forward, tr, nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo,
@@ -1009,7 +1022,11 @@ bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
   const dim3 grid(mode == 2 ? nwg + (unsigned)((total + nthreads - 1) / nthreads) : nwg), block(nthreads);
   const float4* r4 = mode == 1 ? nullptr : reinterpret_cast<const float4*>(rec);
 #define PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, MDV) hipExtLaunchKernelGGL((k_sweep2<TRV, FWV, SPV, MDV>), grid, block, 0, st, evs, a.ev_stop, 0, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.g0, a.blurred, a.gate, nwg, a.prepcnt)
+#ifdef PF_EXPERIMENTS
 #define PF_LAUNCH_SWEEP2__(TRV, FWV, SPV) do { if (mode == 2) PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 2); else if (mode == 1) PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 1); else PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 0); } while (0)
+#else
+#define PF_LAUNCH_SWEEP2__(TRV, FWV, SPV) PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 0)   /* the product library ships the 8 MODE-0 variants only */
+#endif
 #define PF_LAUNCH_SWEEP2(TRV, FWV) do { if (a.sparse) PF_LAUNCH_SWEEP2__(TRV, FWV, true); else PF_LAUNCH_SWEEP2__(TRV, FWV, false); } while (0)
   if (tr) { if (a.forward) PF_LAUNCH_SWEEP2(true, true); else PF_LAUNCH_SWEEP2(true, false); }
   else { if (a.forward) PF_LAUNCH_SWEEP2(false, true); else PF_LAUNCH_SWEEP2(false, false); }
@@ -1019,6 +1036,8 @@ bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
 #undef PF_LAUNCH_SWEEP2
 }
 
-#include "kernels_relax.inl"
+#ifdef PF_EXPERIMENTS
+#include "kernels_relax.inl"   // rejected experiment (41 % slower), kept bit-exact under test in the lab build only
+#endif
 
 }  // namespace pf

@@ -46,13 +46,16 @@ struct pf_ctx {
   std::map<std::string, DevBuf> bufs;  // named grow-only arena: everything a solve needs stays resident
   Gauss g5, g3_05, g3_1, g15;
   int prof = 0;   // 0 off, 1 every kernel family, 2 only the dominant family (the sweeps): fewer events in a timed region
-  int sweep_version = 2;
+  pf_config cfg;  // scheduling knobs (pf_create_cfg); results never depend on them
   bool is_lane = false;   // one of several lanes of pf_novel_view_batch_dev running side by side
   long fuse_ups_px = 0;   // levels up to this many pixels get their incoming flow upsampled inside their first Gaussian (0 = never)
   int chain_cols = 0, chain_rows = 0;   // size of the stitch-chain result resident in "ch_final"
   long long last_swept_steps = 0;       // wavefront steps of one direction of the last solve (both sweeps, all levels, gated windows)
-  const uint8_t* prefetch_src = nullptr; int prefetch_cols = 0, prefetch_rows = 0; size_t prefetch_step = 0;   // pf_stitch_prefetch: next step's left image
-  bool prefetched = false;              // ... and whether it already sits in "ch_l_next"
+  // pf_stitch_prefetch: `hint` = the image announced for the NEXT step (one-shot: the next pf_stitch_step latches and clears it, uploads
+  // it into "ch_l_next" while its own kernels run, and records it as `ready`); `ready` = what sits in "ch_l_next" for the step after
+  // (one-shot as well: that step either consumes it or drops it -- a stale host pointer is never dereferenced or matched later)
+  struct HostImage { const uint8_t* src = nullptr; int cols = 0, rows = 0; size_t step = 0; };
+  HostImage hint, ready;
   hipStream_t s_copy = nullptr;         // uploads that overlap compute (created on first use, like s_aux: a context that only solves
                                         // pairs drives three streams, so that six lanes of the throughput mode fit the hardware queues)
   bool drained = true;                  // false between "work enqueued" and finish(): what CallGuard looks at
@@ -101,12 +104,14 @@ void* ensure(pf_ctx* c, const char* name, size_t bytes) {
   const size_t cap = (bytes + 255) & ~size_t(255);
   if (hipMalloc(&b.p, cap) != hipSuccess) { b.p = nullptr; fail(c, PF_ERR_NOMEM, "hipMalloc(%zu) for '%s' failed", cap, name); return nullptr; }
   b.cap = cap;
-  // debugging aid: PANOFLOW_POISON=all | <buffer name> fills fresh allocations with 0xFF bytes (NaNs / -1): a result that depends
-  // on it reads memory it never wrote
+#ifdef PF_EXPERIMENTS
+  // debugging aid (lab build only): PANOFLOW_POISON=all | <buffer name> fills fresh allocations with 0xFF bytes (NaNs / -1): a result
+  // that depends on it reads memory it never wrote
   if (const char* po = getenv("PANOFLOW_POISON")) {
     if (strcmp(po, "all") == 0 || strstr(po, name) != nullptr) { hipMemset(b.p, 0xFF, cap); hipDeviceSynchronize(); }
     else if (strcmp(po, "zero") == 0 || po[0] == '!') { hipMemset(b.p, (po[0] == '!' && strstr(po + 1, name) != nullptr) ? 0xFF : 0x00, cap); hipDeviceSynchronize(); }
   }
+#endif
   return b.p;
 }
 
@@ -179,10 +184,17 @@ int check_dims(pf_ctx* c, int cols, int rows, int pad) {
 }
 
 // Levels up to this many pixels trade launches for longer kernels (upsample inside the next Gaussian, second median inside the
-// diffusion): 0 for a lone pair, set by the throughput mode for its lanes; PANOFLOW_FUSE_UPS_PX overrides both.
-long fuse_small_px(const pf_ctx* c) {
-  static const long env = [] { const char* e = getenv("PANOFLOW_FUSE_UPS_PX"); return e ? atol(e) : -1l; }();
-  return env >= 0 ? env : c->fuse_ups_px;
+// diffusion): 0 for a lone pair, set by the throughput mode for its lanes; pf_config::fuse_small_level_px overrides both.
+long fuse_small_px(const pf_ctx* c) { return c->cfg.fuse_small_level_px >= 0 ? c->cfg.fuse_small_level_px : c->fuse_ups_px; }
+
+// the product library ships ONE sweep (k_sweep_prep + k_sweep2); the lab build (-DPF_EXPERIMENTS, libpanoflow_exp.so) adds the
+// cross-check implementations the test-suite holds it against
+inline bool launch_sweep_any(hipStream_t st, const SweepArgs& a, float* rec, bool relax) {
+#ifdef PF_EXPERIMENTS
+  if (relax) return launch_sweep_relax(st, a);
+#endif
+  (void)relax;
+  return launch_sweep2(st, a, rec);
 }
 
 // One level of one direction (PixFlow.hpp:272-340, gradients excluded: they are precomputed for all levels).
@@ -204,13 +216,18 @@ void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, cons
   // recording markers around them.  Same-box A/B, ms per step: no timing 27.38, markers 27.65, attached events 27.60 -- bench.py's
   // roofline needs per-launch HIP events inside its timed region, so ~0.2 ms of every timed step is the measurement itself.
   auto sweep = [&](SweepArgs& a) {
-    if (c->sweep_version == 1) { PROF(c, st, "sweep"); launch_sweep(st, a); return; }
-    const bool relax = c->sweep_version == 3;
-    if (!c->prof) { if (relax) launch_sweep_relax(st, a); else launch_sweep2(st, a, b.rec); return; }
+#ifdef PF_EXPERIMENTS
+    if (c->cfg.sweep_impl == 1) { PROF(c, st, "sweep"); launch_sweep(st, a); return; }
+    const bool relax = c->cfg.sweep_impl == 3;
+    a.prep_mode = c->cfg.record_path;
+#else
+    const bool relax = false;
+#endif
+    if (!c->prof) { launch_sweep_any(st, a, b.rec, relax); return; }
     ProfPending p;
     { std::lock_guard<std::mutex> lk(c->prof_mu); p.id = prof_id(c, "sweep"); p.a = prof_event(c); p.b = prof_event(c); }
     a.ev_start = p.a; a.ev_stop = p.b;
-    const bool launched = relax ? launch_sweep_relax(st, a) : launch_sweep2(st, a, b.rec);
+    const bool launched = launch_sweep_any(st, a, b.rec, relax);
     a.ev_start = nullptr; a.ev_stop = nullptr;
     std::lock_guard<std::mutex> lk(c->prof_mu);
     if (launched) c->prof_pending.push_back(p); else { c->ev_pool.push_back(p.a); c->ev_pool.push_back(p.b); }
@@ -341,7 +358,7 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   }
   // pyramids: one launch per level while the levels are large, then two and three levels per launch (the chain of dependent
   // ~5 us launches is otherwise ~0.2 ms in front of everything; kernels_pre.hip: k_pyr_chain)
-  static const int chainMode = [] { const char* e = getenv("PANOFLOW_PYR_CHAIN"); return e ? atoi(e) : 1; }();
+  const int chainMode = c->cfg.pyramid_chaining;
   for (int l = 1; l < g.n;) {
     PROF(c, sm, "pyr_down");
     const size_t px = size_t(g.ws[l]) * g.hs[l];
@@ -392,7 +409,7 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   // Fine levels in two launches behind the coarse ones: levels [split2, split) at full width (needed first, a quarter of the fine
   // pixels), then the finest levels [0, split2) as a NARROW launch -- it runs beside the sweeps of ~30 coarser levels and is not
   // needed for milliseconds; at full width it took every wave slot of the chip and slowed the first sweeps several times over.
-  static const int fineBlocks = [] { const char* e = getenv("PANOFLOW_FINE_GRAD_BLOCKS"); return e ? atoi(e) : 64; }();
+  const int fineBlocks = c->cfg.fine_gradient_blocks;
   const int split2 = split > 4 ? 4 : 0;
   if (have_table && split > 0) { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], table, g.off[split2], g.off[split], c->g3_05); }
   HIPCHK(c, hipEventRecord(c->ev_fine, sm));
@@ -400,7 +417,7 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   HIPCHK(c, hipEventRecord(c->ev_fine2, sm));
   if (have_table) {
     if (int e = wait_gate_boxes(c, sg, epoch, g.n, boxes, h_cnt)) return e;
-    if (getenv("PANOFLOW_NO_WINDOW")) boxes.clear();
+    if (!c->cfg.sweep_window) boxes.clear();
   } else {
     unsigned* d_cnt = (unsigned*)ensure(c, "gate_count", 256);
     if (!d_cnt) return PF_ERR_NOMEM;
@@ -412,7 +429,7 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   double area0 = (double)g.ws[0] * g.hs[0];   // the sweeps only cover the window of gated pixels: density inside that window is what counts
   if (!boxes.empty() && boxes[2] >= boxes[0] && boxes[3] >= boxes[1]) area0 = double(boxes[2] - boxes[0] + 1) * double(boxes[3] - boxes[1] + 1);
   int sparse = (double)h_cnt < 0.5 * area0 ? 1 : 0;
-  if (const char* e = getenv("PANOFLOW_SPARSE")) sparse = atoi(e) ? 1 : 0;   // experiment switch: results are identical either way
+  if (c->cfg.sparse_sweep >= 0) sparse = c->cfg.sparse_sweep ? 1 : 0;   // forced variant: results are identical either way
   // critical path of the exact sweeps given the windows: (w + h - 1) anti-diagonals per sweep, two sweeps per level
   c->last_swept_steps = 0;
   for (int l = 0; l < g.n; ++l) {
@@ -427,7 +444,7 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   for (int d = 0; d < ndirs; ++d) HIPCHK(c, hipStreamWaitEvent(c->s_dir[d], c->ev_pre, 0));
   // Fewer launches or shorter launches?  Alone, a pair is faster with the separate upsample kernel (strip 27.36 vs 27.44 ms); with
   // several pairs in flight the time between a stream's kernels dominates and one launch fewer per level wins (+3 %): the
-  // throughput mode turns the fusion on for its lanes (pf_novel_view_batch_dev).  PANOFLOW_FUSE_UPS_PX overrides both.
+  // throughput mode turns the fusion on for its lanes (pf_novel_view_batch_dev).  pf_config::fuse_small_level_px overrides both.
   const long fuseUpsPx = fuse_small_px(c);
   auto fuse_ups = [&](int level) { return (long)g.ws[level] * g.hs[level] <= fuseUpsPx; };   // level whose incoming flow is upsampled inside its Gaussian
   float* prev_res[2] = {nullptr, nullptr};
@@ -471,9 +488,8 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   // leave most CUs idle -- run beside each other too.  A small offset puts one direction's throughput kernels beside the other's
   // sweeps.  The late direction finishes k coarse levels later, which is what limits k: measured (profiles/r02_frontend_ab.txt)
   // strip 27.36 -> 27.18 ms at k = 2, 9000x4000 pair 59.1 -> 57.7 ms at k = 4-6.  Not for the lanes of the throughput mode (they are
-  // out of phase with each other anyway: -1 %).  PANOFLOW_STAGGER overrides.
-  static const int staggerEnv = [] { const char* e = getenv("PANOFLOW_STAGGER"); return e ? atoi(e) : -1; }();
-  const int stagger = staggerEnv >= 0 ? staggerEnv : (c->is_lane ? 0 : (size_t(g.w0) * g.h0 >= 5000000 ? 4 : 2));
+  // out of phase with each other anyway: -1 %).  pf_config::stagger_levels overrides.
+  const int stagger = c->cfg.stagger_levels >= 0 ? c->cfg.stagger_levels : (c->is_lane ? 0 : (size_t(g.w0) * g.h0 >= 5000000 ? 4 : 2));
   if (stagger > 0 && ndirs == 2 && g.n > 1) {
     const int k = stagger < g.n ? stagger : g.n - 1;
     for (int t = 0; t < g.n + k; ++t) {
@@ -502,7 +518,7 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
 
 // after the streams have drained: did any sweep band give up?  (the word lives in mapped pinned host memory and was
 // written by k_collect_status at the end of each direction's stream: no copy, no further sync)
-int check_sweeps(pf_ctx* c, int, int, int, int) {
+int check_sweeps(pf_ctx* c) {
   const int st = __atomic_load_n(c->h_status, __ATOMIC_ACQUIRE);
   if (st) { *c->h_status = 0; return fail(c, PF_ERR_TIMEOUT, "sweep band timed out (direction mask %d)", st); }
   return 0;
@@ -560,9 +576,33 @@ int pf_device_count(void) {
   return n;
 }
 
-const char* pf_version(void) { return "panoflow-mi355x r2 (gfx950)"; }
+#ifdef PF_EXPERIMENTS
+const char* pf_version(void) { return "panoflow-mi355x r3 (gfx950, lab build with the cross-check sweeps)"; }
+#else
+const char* pf_version(void) { return "panoflow-mi355x r3 (gfx950)"; }
+#endif
+
+void pf_config_init(pf_config* cfg) {
+  if (!cfg) return;
+  memset(cfg, 0, sizeof *cfg);
+  cfg->struct_size = (int)sizeof *cfg;
+  cfg->stagger_levels = -1; cfg->fuse_small_level_px = -1; cfg->fine_gradient_blocks = 64; cfg->pyramid_chaining = 1;
+  cfg->sweep_window = 1; cfg->sparse_sweep = -1; cfg->sweep_impl = 2; cfg->record_path = 0;
+}
 
 pf_ctx* pf_create(int device, int max_cols, int max_rows) {
+  pf_config cfg; pf_config_init(&cfg);
+  cfg.device = device; cfg.max_cols = max_cols; cfg.max_rows = max_rows;
+  return pf_create_cfg(&cfg);
+}
+
+}  // extern "C"
+
+namespace {
+// lane = one of the extra stream / buffer sets of the throughput mode: it only ever runs pf_novel_view_dev, so it is pre-sized
+// for a solve and the two internal flow planes, not for the stitch chain and the host-staging buffers (~93 B/px it would never use)
+pf_ctx* create_ctx(const pf_config& cfg, bool lane) {
+  const int device = cfg.device, max_cols = cfg.max_cols, max_rows = cfg.max_rows;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { fail(nullptr, PF_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)"); return nullptr; }
   if (device < 0 || device >= n) { fail(nullptr, PF_ERR_ARG, "device %d out of range (0..%d)", device, n - 1); return nullptr; }
@@ -585,7 +625,7 @@ pf_ctx* pf_create(int device, int max_cols, int max_rows) {
        hipHostGetDevicePointer((void**)&c->d_gate, c->h_gate, 0) == hipSuccess;
   if (ok) { *c->h_status = 0; memset(c->h_gate, 0, (4 * kLevelTableMax + 2) * sizeof(int)); }
   if (!ok) { fail(nullptr, PF_ERR_DEVICE, "stream/event creation failed"); delete c; return nullptr; }
-  if (const char* sv = getenv("PANOFLOW_SWEEP")) { const int v = atoi(sv); c->sweep_version = (v == 1 || v == 3) ? v : 2; }
+  c->cfg = cfg;
   c->g5 = make_gauss(5, 0.25); c->g3_05 = make_gauss(3, 0.5); c->g3_1 = make_gauss(3, 1.0); c->g15 = make_gauss(15, 8.0);
   // Pre-sizing: every buffer a bidirectional solve / a stitch step on max_cols x max_rows needs is
   // allocated now, so that the first call does not pay ~40 hipMallocs.  0 x 0 = allocate lazily (the arena only grows).
@@ -598,10 +638,39 @@ pf_ctx* pf_create(int device, int max_cols, int max_rows) {
         {"nv_flow_l2r", n * 8}, {"nv_flow_r2l", n * 8}, {"h_img0", n * 4}, {"h_img1", n * 4}, {"h_flow0", n * 8}, {"h_flow1", n * 8}, {"h_blend", n * 4}, {"h_out", n * 4},
         {"ch_l", n * 4}, {"ch_r", n * 4}, {"ch_final", n * 4}, {"st_map", n}, {"st_ovl", n * 4}, {"st_ovr", n * 4}, {"st_blend", n * 4}, {"st_md", n * 4},
         {"st_merged", n * 4}, {"st_rowsum", n * 8}, {"st_blur_tmp", n * 4}};
-    for (const auto& e : io) if (ok2) ok2 = ensure(c, e.name, e.bytes) != nullptr;
+    for (const auto& e : io) if (ok2 && (!lane || strncmp(e.name, "nv_", 3) == 0)) ok2 = ensure(c, e.name, e.bytes) != nullptr;
     if (!ok2) { g_err = c->err; pf_destroy(c); return nullptr; }
   }
   return c;
+}
+}  // namespace
+
+extern "C" {
+
+pf_ctx* pf_create_cfg(const pf_config* user) {
+  if (!user || user->struct_size != (int)sizeof(pf_config)) { fail(nullptr, PF_ERR_ARG, "pf_create_cfg: struct_size does not match this library's pf_config"); return nullptr; }
+  pf_config cfg = *user;
+#ifdef PF_EXPERIMENTS
+  // lab build only: the diagnostics under tests/micro select variants per process through the environment
+  auto env_int = [](const char* name, int& v) { if (const char* e = getenv(name)) v = atoi(e); };
+  env_int("PANOFLOW_SWEEP", cfg.sweep_impl); env_int("PANOFLOW_PREP", cfg.record_path); env_int("PANOFLOW_STAGGER", cfg.stagger_levels);
+  env_int("PANOFLOW_PYR_CHAIN", cfg.pyramid_chaining); env_int("PANOFLOW_FINE_GRAD_BLOCKS", cfg.fine_gradient_blocks);
+  env_int("PANOFLOW_SPARSE", cfg.sparse_sweep);
+  if (getenv("PANOFLOW_NO_WINDOW")) cfg.sweep_window = 0;
+  if (const char* e = getenv("PANOFLOW_FUSE_UPS_PX")) cfg.fuse_small_level_px = atol(e);
+  if (cfg.sweep_impl != 1 && cfg.sweep_impl != 3) cfg.sweep_impl = 2;
+  if (cfg.record_path < 0 || cfg.record_path > 2) cfg.record_path = 0;
+#else
+  if (cfg.sweep_impl != 2 || cfg.record_path != 0) {
+    fail(nullptr, PF_ERR_ARG, "sweep_impl / record_path select cross-check implementations that only the -DPF_EXPERIMENTS build (libpanoflow_exp.so) contains");
+    return nullptr;
+  }
+#endif
+  if (cfg.fine_gradient_blocks < 1 || cfg.stagger_levels < -1 || cfg.fuse_small_level_px < -1 || cfg.sparse_sweep < -1 || cfg.sparse_sweep > 1) {
+    fail(nullptr, PF_ERR_ARG, "pf_create_cfg: knob out of range");
+    return nullptr;
+  }
+  return create_ctx(cfg, false);
 }
 
 void pf_destroy(pf_ctx* c) {
@@ -646,6 +715,15 @@ void* pf_dev_alloc(pf_ctx* c, size_t bytes) {
   return p;
 }
 void pf_dev_free(pf_ctx* c, void* p) { if (!use(c) && p) hipFree(p); }
+// page-locked host memory for the caller's images: copies to and from it run at the link's DMA rate (a pageable destination is
+// staged through the runtime's bounce buffers: 17.5 GB/s instead of ~55 GB/s for the 144 MB composite of a 9000x4000 step)
+void* pf_host_alloc(pf_ctx* c, size_t bytes) {
+  if (use(c)) return nullptr;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { fail(c, PF_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes); return nullptr; }
+  return p;
+}
+void pf_host_free(pf_ctx* c, void* p) { if (!use(c) && p) hipHostFree(p); }
 int pf_upload(pf_ctx* c, void* dst, const void* src, size_t bytes) {
   if (int e = use(c)) return e;
   CallGuard guard_(c);
@@ -659,6 +737,23 @@ int pf_download(pf_ctx* c, void* dst, const void* src, size_t bytes) {
   return 0;
 }
 int pf_sync(pf_ctx* c) { if (int e = use(c)) return e; return finish(c); }
+// 64-bit content checksum of `bytes` bytes at d_ptr (8-byte aligned), computed on the device: results that live in HBM -- on this
+// GPU or gathered from others -- are compared without a trip through the host.  ~25 us per 144 MB strip.
+int pf_checksum_dev(pf_ctx* c, const void* d_ptr, size_t bytes, uint64_t* out) {
+  if (int e = use(c)) return e;
+  CallGuard guard_(c);
+  if (!d_ptr || !out || (reinterpret_cast<uintptr_t>(d_ptr) & 7)) return fail(c, PF_ERR_ARG, "pf_checksum_dev: null or misaligned pointer");
+  unsigned long long* acc = (unsigned long long*)ensure(c, "checksum_acc", 256);
+  if (!acc) return PF_ERR_NOMEM;
+  HIPCHK(c, hipMemsetAsync(acc, 0, 8, c->s_main));
+  launch_checksum64(c->s_main, d_ptr, bytes, acc);
+  unsigned long long h = 0;
+  HIPCHK(c, hipMemcpyAsync(&h, acc, 8, hipMemcpyDeviceToHost, c->s_main));
+  HIPCHK(c, hipGetLastError());
+  if (int e = finish(c)) return e;
+  *out = h;
+  return 0;
+}
 
 // ---- device-resident entry points ----
 int pf_flow_bidir_dev(pf_ctx* c, const uint8_t* d_l, const uint8_t* d_r, int cols, int rows, int max_pct, float* d_l2r, float* d_r2l) {
@@ -670,7 +765,7 @@ int pf_flow_bidir_dev(pf_ctx* c, const uint8_t* d_l, const uint8_t* d_r, int col
   const int pad = cols / 20;                            // OpticalFlow.cpp:113
   if (int e = solve(c, d_l, d_r, cols, rows, pad, max_pct, 2, hints, outs)) return e;
   if (int e = finish(c)) return e;
-  return check_sweeps(c, cols, rows, pad, 2);
+  return check_sweeps(c);
 }
 
 int pf_blend_dev(pf_ctx* c, const uint8_t* d_l, const uint8_t* d_r, const float* d_l2r, const float* d_r2l, const float* d_blend, int cols,
@@ -700,7 +795,7 @@ int pf_novel_view_dev(pf_ctx* c, const uint8_t* d_l, const uint8_t* d_r, int col
   { PROF(c, c->s_main, "blend"); launch_blend(c->s_main, d_l, d_r, f0, f1, d_blend, cols, rows, d_out); }
   HIPCHK(c, hipGetLastError());
   if (int e = finish(c)) return e;
-  return check_sweeps(c, cols, rows, pad, 2);
+  return check_sweeps(c);
 }
 
 // ---- throughput mode ----
@@ -717,11 +812,12 @@ int pf_novel_view_batch_dev(pf_ctx* c, int n_pairs, const uint8_t* const* d_l, c
   if (in_flight > 16) in_flight = 16;
   if (in_flight > n_pairs) in_flight = n_pairs > 0 ? n_pairs : 1;
   while ((int)c->lanes.size() < in_flight - 1) {
-    pf_ctx* l = pf_create(c->device, cols, rows);
+    pf_config lc = c->cfg; lc.max_cols = cols; lc.max_rows = rows;
+    pf_ctx* l = create_ctx(lc, true);
     if (!l) return fail(c, PF_ERR_NOMEM, "cannot create lane %d: %s", (int)c->lanes.size() + 1, g_err.c_str());
-    l->sweep_version = c->sweep_version;
     c->lanes.push_back(l);
   }
+  for (pf_ctx* l : c->lanes) l->prof = c->prof;   // profiling covers every lane (collected into the lane's own totals)
   std::vector<int> rc(in_flight, 0);
   std::vector<std::string> msg(in_flight);
   auto run = [&](int k) {
@@ -738,6 +834,13 @@ int pf_novel_view_batch_dev(pf_ctx* c, int n_pairs, const uint8_t* const* d_l, c
   run(0);
   for (auto& t : th) t.join();
   for (int k = 0; k < in_flight; ++k) if (rc[k]) return fail(c, rc[k], "lane %d: %s", k, msg[k].c_str());
+  if (c->prof)   // per-kernel-family times of the lanes are reported with the owning context's
+    for (pf_ctx* l : c->lanes)
+      for (size_t i = 0; i < l->prof_names.size(); ++i) {
+        const int id = prof_id(c, l->prof_names[i].c_str());
+        c->prof_tot[id].ms += l->prof_tot[i].ms; c->prof_tot[id].n += l->prof_tot[i].n;
+        l->prof_tot[i] = ProfEntry();
+      }
   return 0;
 }
 
@@ -759,7 +862,7 @@ int pf_flow(pf_ctx* c, const uint8_t* i0, const uint8_t* i1, int cols, int rows,
   if (int e = solve(c, d0, d1, cols, rows, 0, max_pct, 1, hints, outs)) return e;
   if (int e = down2d(c, flow, fstep, df, size_t(cols) * 8, size_t(cols) * 8, rows)) return e;
   if (int e = finish(c)) return e;
-  return check_sweeps(c, cols, rows, 0, 1);
+  return check_sweeps(c);
 }
 
 int pf_novel_view(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int rows, size_t step, int max_pct, const float* blend, size_t bstep,
@@ -789,7 +892,7 @@ int pf_novel_view(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int r
   if (f_l2r) if (int e = down2d(c, f_l2r, fstep, d0, size_t(cols) * 8, size_t(cols) * 8, rows)) return e;
   if (f_r2l) if (int e = down2d(c, f_r2l, fstep, d1, size_t(cols) * 8, size_t(cols) * 8, rows)) return e;
   if (int e = finish(c)) return e;
-  return check_sweeps(c, cols, rows, pad, 2);
+  return check_sweeps(c);
 }
 
 int pf_flow_bidir(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int rows, size_t step, int max_pct, float* f_l2r, float* f_r2l,
@@ -929,13 +1032,17 @@ int pf_stitch_step(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int 
   hipStream_t sm = c->s_main;
   uint8_t* dnext = (uint8_t*)ensure(c, "ch_l_next", n * 4);
   if (!dnext) return PF_ERR_NOMEM;
-  if (c->prefetched && c->prefetch_src == l && c->prefetch_cols == cols && c->prefetch_rows == rows && c->prefetch_step == step) {
-    // this step's left image was uploaded while the previous step computed (pf_stitch_prefetch)
-    HIPCHK(c, hipMemcpyAsync(dl, dnext, n * 4, hipMemcpyDeviceToDevice, sm));
+  // both prefetch records are one-shot: latched and cleared here, whatever this step does with them
+  const pf_ctx::HostImage ready = c->ready, hint = c->hint;
+  c->ready = pf_ctx::HostImage(); c->hint = pf_ctx::HostImage();
+  if (ready.src == l && ready.cols == cols && ready.rows == rows && ready.step == step) {
+    // this step's left image was uploaded while the previous step computed: the two buffers trade places (no copy; the old
+    // "ch_l" is free -- the previous call drained every stream -- and receives the next prefetch)
+    std::swap(c->bufs["ch_l"], c->bufs["ch_l_next"]);
+    std::swap(dl, dnext);
   } else {
     if (int e = up2d(c, dl, size_t(cols) * 4, l, step, size_t(cols) * 4, rows)) return e;
   }
-  c->prefetched = false;
   if (r) { if (int e = up2d(c, dr, size_t(cols) * 4, r, step, size_t(cols) * 4, rows)) return e; }
   else {
     if (c->chain_cols != cols || c->chain_rows != rows) return fail(c, PF_ERR_ARG, "pf_stitch_step: no previous result of this size to chain on");
@@ -963,24 +1070,25 @@ int pf_stitch_step(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int 
   if (out) if (int e = down2d(c, out, ostep, dfin, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
   // everything of this step is enqueued: upload the NEXT step's left image now (announced with pf_stitch_prefetch); the
   // host-side staging of a pageable source runs while the GPU computes
-  if (c->prefetch_src && c->prefetch_src != l && c->prefetch_cols == cols && c->prefetch_rows == rows) {
-    HIPCHK(c, hipMemcpy2DAsync(dnext, size_t(cols) * 4, c->prefetch_src, c->prefetch_step, size_t(cols) * 4, rows, hipMemcpyHostToDevice, c->s_copy));
+  if (hint.src && hint.src != l && hint.cols == cols && hint.rows == rows) {
+    HIPCHK(c, hipMemcpy2DAsync(dnext, size_t(cols) * 4, hint.src, hint.step, size_t(cols) * 4, rows, hipMemcpyHostToDevice, c->s_copy));
     HIPCHK(c, hipStreamSynchronize(c->s_copy));
-    c->prefetched = true;
+    c->ready = hint;
   }
   HIPCHK(c, hipGetLastError());
   if (int e = finish(c)) return e;
   c->chain_cols = cols; c->chain_rows = rows;
-  return check_sweeps(c, cols, rows, pad, 2);
+  return check_sweeps(c);
 }
 
-// Announce the left image of the NEXT pf_stitch_step call: its upload then overlaps the current step's compute (the copy is
-// issued inside the current step after its kernels are enqueued).  The buffer must stay valid and unchanged until that
-// next call, which must pass the same pointer / size / step; anything else simply uploads as usual.  NULL cancels.
+// Announce the left image of the pf_stitch_step call AFTER the coming one: the coming step uploads it while its own kernels run
+// (the copy is issued after they are enqueued).  One-shot: the hint is consumed by the coming step; the buffer must stay valid
+// and unchanged until the step after it has returned, and that step must pass the same pointer / size / step -- anything else
+// simply uploads as usual and the prefetched copy is dropped.  NULL cancels.
 int pf_stitch_prefetch(pf_ctx* c, const uint8_t* next_l, int cols, int rows, size_t step) {
   if (!c) return fail(nullptr, PF_ERR_ARG, "null context");
   if (next_l && (cols <= 0 || rows <= 0 || step < size_t(cols) * 4)) return fail(c, PF_ERR_ARG, "bad argument");
-  c->prefetch_src = next_l; c->prefetch_cols = cols; c->prefetch_rows = rows; c->prefetch_step = step; c->prefetched = false;
+  c->hint.src = next_l; c->hint.cols = cols; c->hint.rows = rows; c->hint.step = step;
   return 0;
 }
 
@@ -1064,12 +1172,18 @@ int pf_stage_sweep(pf_ctx* c, const float* g0, const float* g1, const float* blu
   }
   float* rec = (float*)ensure(c, "sg_rec", sweep2_rec_bytes(w, h));
   if (!rec) return PF_ERR_NOMEM;
-  { PROF(c, sm, "sweep"); if (c->sweep_version == 1) launch_sweep(sm, sa); else if (c->sweep_version == 3) (void)launch_sweep_relax(sm, sa); else (void)launch_sweep2(sm, sa, rec); }
+#ifdef PF_EXPERIMENTS
+  sa.prep_mode = c->cfg.record_path;
+  if (c->cfg.sweep_impl == 1) { PROF(c, sm, "sweep"); launch_sweep(sm, sa); } else
+#endif
+  { PROF(c, sm, "sweep"); (void)launch_sweep_any(sm, sa, rec, c->cfg.sweep_impl == 3); }
   int hc[4] = {0, 0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(hc, ctrl, 16, hipMemcpyDeviceToHost, sm));
   if (int e = stage_down(c, flow, df, n * 8)) return e;
   if (hc[1]) return fail(c, PF_ERR_TIMEOUT, "sweep band timed out");
-  if (getenv("PANOFLOW_SWEEP_STATS")) fprintf(stderr, "[panoflow] sweep %dx%d: edge waits %d, spin iterations %d (needs a -DPF_SWEEP_STATS build)\n", w, h, hc[2], hc[3]);
+#ifdef PF_SWEEP_STATS
+  fprintf(stderr, "[panoflow] sweep %dx%d: edge waits %d, spin iterations %d\n", w, h, hc[2], hc[3]);
+#endif
   return 0;
 }
 int pf_stage_diffusion(pf_ctx* c, const float* a0, const float* a1, float* flow, int w, int h) {

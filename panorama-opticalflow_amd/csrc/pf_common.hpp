@@ -122,17 +122,19 @@ struct SweepArgs {
   // sweep kernel come from the dispatch packets' own timestamps), so that timing a sweep puts no marker packets on its stream
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   int* prepcnt = nullptr; // v2 sweep, prepass inside the launch: one counter per sweep workgroup (sweep2_num_wgs_max ints), ZEROED before the launch
+  int prep_mode = 0;      // lab build only (-DPF_EXPERIMENTS): 1 / 2 = the two rejected record paths (pf_config::record_path)
   int ax0 = 0, ay0 = 0, ax1 = 1 << 30, ay1 = 1 << 30;   // bounding box [ax0,ax1) x [ay0,ay1) of the gated pixels (default: everything); v2 sweep only
 };
-size_t sweep_boundary_elems(int W, int H);   // hand-off granules needed per sweep launch (covers both sweep kernels)
-void launch_sweep(hipStream_t st, const SweepArgs& a);          // v1: 64 rows per wave, kept as a cross-check (PANOFLOW_SWEEP=1)
+size_t sweep_boundary_elems(int W, int H);   // hand-off granules needed per sweep launch (covers every sweep kernel of this build)
+size_t sweep1_boundary_elems(int W, int H);                     // lab build only (-DPF_EXPERIMENTS)
+void launch_sweep(hipStream_t st, const SweepArgs& a);          // lab build only: v1, 64 rows per wave, the independent cross-check (pf_config::sweep_impl = 1)
 int sweep2_num_wgs(int H);
 int sweep2_num_wgs_max(int W, int H);          // workgroups a sweep launch on a W x H level can have (either band orientation)
 size_t sweep2_boundary_elems(int W, int H);   // granules one sweep launch may need (either band orientation)
 size_t sweep2_rec_bytes(int W, int H);
 bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec);  // v2: prepass + 8 lanes/pixel + helper waves; false = empty window, nothing launched
 size_t sweep_relax_boundary_elems(int W, int H);
-bool launch_sweep_relax(hipStream_t st, const SweepArgs& a);   // experiment (PANOFLOW_SWEEP=3): event-driven relaxation on LDS-resident tiles, kernels_relax.inl
+bool launch_sweep_relax(hipStream_t st, const SweepArgs& a);   // lab build only (pf_config::sweep_impl = 3): event-driven relaxation on LDS-resident tiles, kernels_relax.inl
 // coarsest-level search
 void launch_adjust_initial_flow(hipStream_t st, const float* i0, const float* i1, const float* a0, const float* a1, int w, int h, int hint,
                                 int max_pct, float* i1eq_tmp, float* flow);
@@ -147,6 +149,7 @@ void launch_tile_blur(hipStream_t st, float* blend, const float* mergedDis, int 
 void launch_gather(hipStream_t st, const uint8_t* L, const uint8_t* R, const uint8_t* merged, const uint8_t* map, int cols, int rows,
                    uint8_t* out);
 void launch_fill_u64(hipStream_t st, unsigned long long* p, size_t n, unsigned long long v);
+void launch_checksum64(hipStream_t st, const void* p, size_t bytes, unsigned long long* acc /* zeroed by the caller */);
 void launch_collect_status(hipStream_t st, const int* ctrl, int nwords, int* status_mapped, int bit);
 
 }  // namespace pf

@@ -139,10 +139,14 @@ int pf_dist_gather_async(pf_dist* d, const void* d_send, void* d_recv_all, size_
   DHIP(d, hipSetDevice(d->device));
   if (d->pending) { DHIP(d, hipEventSynchronize(d->done)); d->pending = false; }
   NCHK(d, r->GroupStart());
-  NCHK(d, r->Send(d_send, bytes, ncclUint8, 0, d->comm, d->stream));
+  ncclResult_t rc = r->Send(d_send, bytes, ncclUint8, 0, d->comm, d->stream);
   if (d->rank == 0)
-    for (int p = 0; p < d->world; ++p) NCHK(d, r->Recv(static_cast<char*>(d_recv_all) + size_t(p) * bytes, bytes, ncclUint8, p, d->comm, d->stream));
-  NCHK(d, r->GroupEnd());
+    for (int p = 0; p < d->world && rc == ncclSuccess; ++p) rc = r->Recv(static_cast<char*>(d_recv_all) + size_t(p) * bytes, bytes, ncclUint8, p, d->comm, d->stream);
+  const ncclResult_t re = r->GroupEnd();   // always: an error inside the group must not leave it open
+  if (rc != ncclSuccess || re != ncclSuccess) {
+    d->err = std::string("grouped ncclSend/ncclRecv failed: ") + r->GetErrorString(rc != ncclSuccess ? rc : re); g_derr = d->err;
+    return PF_ERR_DEVICE;
+  }
   DHIP(d, hipEventRecord(d->done, d->stream));
   d->pending = true;
   return 0;

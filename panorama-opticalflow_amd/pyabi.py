@@ -11,6 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libpanoflow.so")
+# the lab build (-DPF_EXPERIMENTS): product sources + the cross-check sweep implementations; loaded by tests and diagnostics only
+SO_PATH_EXP = os.path.join(_HERE, "libpanoflow_exp.so")
 
 HINT_UNKNOWN, HINT_RIGHT, HINT_DOWN, HINT_LEFT, HINT_UP = 0, 1, 2, 3, 4
 
@@ -26,15 +28,28 @@ def build(force=False):
     return SO_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
+class Config(C.Structure):
+    """pf_config (include/panoflow.h)"""
+    _fields_ = [("struct_size", C.c_int), ("device", C.c_int), ("max_cols", C.c_int), ("max_rows", C.c_int), ("stagger_levels", C.c_int),
+                ("fuse_small_level_px", C.c_long), ("fine_gradient_blocks", C.c_int), ("pyramid_chaining", C.c_int), ("sweep_window", C.c_int),
+                ("sparse_sweep", C.c_int), ("sweep_impl", C.c_int), ("record_path", C.c_int)]
+
+
+def lib(exp=False):
+    """exp=False: the product library.  exp=True: the lab build with the cross-check sweeps (tests / diagnostics only)."""
+    _lib = _libs.get(bool(exp))
     if _lib is None:
-        if not os.path.exists(SO_PATH):
-            raise PanoflowError("libpanoflow.so is not built (run __graft_entry__.build()); there is no fallback path")
-        _lib = C.CDLL(SO_PATH)
+        path = SO_PATH_EXP if exp else SO_PATH
+        if not os.path.exists(path):
+            raise PanoflowError("%s is not built (run __graft_entry__.build()); there is no fallback path" % os.path.basename(path))
+        _lib = C.CDLL(path)
+        _libs[bool(exp)] = _lib
+        _lib.pf_create_cfg.restype = C.c_void_p
+        _lib.pf_create_cfg.argtypes = [C.POINTER(Config)]
+        _lib.pf_config_init.argtypes = [C.POINTER(Config)]
         _lib.pf_create.restype = C.c_void_p
         _lib.pf_create.argtypes = [C.c_int, C.c_int, C.c_int]
         _lib.pf_destroy.argtypes = [C.c_void_p]
@@ -44,6 +59,9 @@ def lib():
         _lib.pf_dev_alloc.restype = C.c_void_p
         _lib.pf_dev_alloc.argtypes = [C.c_void_p, C.c_size_t]
         _lib.pf_dev_free.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.pf_host_alloc.restype = C.c_void_p
+        _lib.pf_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
+        _lib.pf_host_free.argtypes = [C.c_void_p, C.c_void_p]
         _lib.pf_algorithmic_bytes.restype = C.c_double
         _lib.pf_level_pixels.restype = C.c_longlong
         _lib.pf_dist_init.restype = C.c_void_p
@@ -61,9 +79,9 @@ def lib():
 
 
 EXPORTS = [
-    "pf_device_count", "pf_create", "pf_destroy", "pf_last_error", "pf_version", "pf_max_percentage_by_name",
+    "pf_device_count", "pf_create", "pf_config_init", "pf_create_cfg", "pf_destroy", "pf_last_error", "pf_version", "pf_max_percentage_by_name",
     "pf_flow", "pf_flow_bidir", "pf_blend", "pf_novel_view", "pf_stitch_prepare", "pf_stitch_raw_blend", "pf_stitch_gather", "pf_stitch_step", "pf_stitch_prefetch",
-    "pf_dev_alloc", "pf_dev_free", "pf_upload", "pf_download", "pf_sync",
+    "pf_dev_alloc", "pf_dev_free", "pf_host_alloc", "pf_host_free", "pf_upload", "pf_download", "pf_sync", "pf_checksum_dev",
     "pf_flow_bidir_dev", "pf_blend_dev", "pf_novel_view_dev", "pf_novel_view_batch_dev",
     "pf_stage_preprocess", "pf_stage_pyr_down", "pf_stage_gradients", "pf_stage_gauss", "pf_stage_median5", "pf_stage_sweep",
     "pf_stage_diffusion", "pf_stage_upsample_cubic", "pf_stage_final", "pf_stage_adjust_initial_flow", "pf_stage_level",
@@ -148,15 +166,30 @@ class Dist:
 
 
 class Context:
-    def __init__(self, device=0, max_cols=0, max_rows=0):
-        self.l = lib()
-        h = self.l.pf_create(device, max_cols, max_rows)
+    def __init__(self, device=0, max_cols=0, max_rows=0, exp=False, **knobs):
+        """knobs: fields of pf_config (stagger_levels, fuse_small_level_px, sweep_window, sparse_sweep, sweep_impl, record_path, ...);
+        exp=True loads the lab build, the only one that accepts sweep_impl / record_path other than the defaults."""
+        self.l = lib(exp)
+        if knobs:
+            cfg = Config()
+            self.l.pf_config_init(C.byref(cfg))
+            cfg.device, cfg.max_cols, cfg.max_rows = device, max_cols, max_rows
+            for k, v in knobs.items():
+                if not hasattr(cfg, k):
+                    raise TypeError("unknown pf_config field %r" % k)
+                setattr(cfg, k, v)
+            h = self.l.pf_create_cfg(C.byref(cfg))
+        else:
+            h = self.l.pf_create(device, max_cols, max_rows)
         if not h:
             raise PanoflowError("pf_create failed: " + self.l.pf_last_error(None).decode())
         self.h = C.c_void_p(h)  # keep it a c_void_p: a bare int would be passed as a 32-bit C int
 
     def close(self):
         if self.h:
+            for p in getattr(self, "_pinned", []):
+                self.l.pf_host_free(self.h, C.c_void_p(p))
+            self._pinned = []
             self.l.pf_destroy(self.h)
             self.h = None
 
@@ -215,9 +248,9 @@ class Context:
         return bl, md
 
     def stitch_gather(self, L, R, merged, mp):
-        a = _u8(L); rows, cols, _ = a.shape
+        a = _u8(L); b = _u8(R); g = _u8(merged); m = _u8(mp); rows, cols, _ = a.shape
         out = np.empty((rows, cols, 4), np.uint8)
-        self._chk(self.l.pf_stitch_gather(self.h, _p(a), _p(_u8(R)), _p(_u8(merged)), C.c_size_t(cols * 4), _p(_u8(mp)), C.c_size_t(cols), cols, rows,
+        self._chk(self.l.pf_stitch_gather(self.h, _p(a), _p(b), _p(g), C.c_size_t(cols * 4), _p(m), C.c_size_t(cols), cols, rows,
                                           _p(out), C.c_size_t(cols * 4)))
         return out
 
@@ -235,11 +268,12 @@ class Context:
         out: optional preallocated (rows, cols, 4) uint8 array for the composite (a caller that reuses its buffer, like
         the reference's Mat, does not pay a fresh 144 MB allocation + first-touch page faults per call)."""
         a = _u8(L); rows, cols, _ = a.shape
+        r = None if R is None else _u8(R)     # named, so that a converted copy outlives the call
         if out is not None:
             assert out.dtype == np.uint8 and out.shape == (rows, cols, 4) and out.flags["C_CONTIGUOUS"]
         elif want_out:
             out = np.empty((rows, cols, 4), np.uint8)
-        self._chk(self.l.pf_stitch_step(self.h, _p(a), None if R is None else _p(_u8(R)), cols, rows, C.c_size_t(cols * 4), max_pct,
+        self._chk(self.l.pf_stitch_step(self.h, _p(a), None if r is None else _p(r), cols, rows, C.c_size_t(cols * 4), max_pct,
                                         None if out is None else _p(out), C.c_size_t(cols * 4)))
         return out
 
@@ -253,9 +287,24 @@ class Context:
     def dev_free(self, p):
         self.l.pf_dev_free(self.h, C.c_void_p(p))
 
+    def host_array(self, shape, dtype=np.uint8):
+        """numpy array over page-locked host memory (pf_host_alloc); freed with the context (keep the context alive while it is used)"""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.l.pf_host_alloc(self.h, C.c_size_t(nbytes))
+        if not p:
+            raise PanoflowError(self.l.pf_last_error(self.h).decode())
+        self._pinned = getattr(self, "_pinned", []) + [p]
+        buf = (C.c_uint8 * nbytes).from_address(p)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
     def upload(self, dptr, arr):
         arr = np.ascontiguousarray(arr)
         self._chk(self.l.pf_upload(self.h, C.c_void_p(dptr), _p(arr), C.c_size_t(arr.nbytes)))
+
+    def checksum_dev(self, dptr, nbytes):
+        h = C.c_uint64(0)
+        self._chk(self.l.pf_checksum_dev(self.h, C.c_void_p(dptr), C.c_size_t(nbytes), C.byref(h)))
+        return h.value
 
     def download(self, arr, dptr):
         self._chk(self.l.pf_download(self.h, _p(arr), C.c_void_p(dptr), C.c_size_t(arr.nbytes)))

@@ -8,13 +8,15 @@
 //   pano_batch -pairs 8 -size 9000x4000 -flow_alg pixflow_search_20 [-gpus N] [-verify 1]
 //
 // Inputs are synthetic (textured pair with a smooth displacement, alpha holes at the edges) generated on the host per
-// pair and uploaded once; the clock covers compute + gather with inputs resident in HBM.
+// pair and uploaded once; the clock covers compute + gather with inputs resident in HBM.  -verify 1 (default) checks every
+// gathered strip against its producer's through device-side checksums: nothing is copied to or hashed on the host inside the clock.
 #include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <string>
 #include <thread>
 #include <vector>
@@ -69,23 +71,27 @@ void make_pair(int cols, int rows, int seed, std::vector<uint8_t>& L, std::vecto
     }
 }
 
-uint64_t fnv(const uint8_t* p, size_t n) { uint64_t h = 1469598103934665603ull; for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; } return h; }
-
 struct Shared {
   Args a; int ndev; int max_pct; unsigned char id[128];
-  std::vector<uint64_t> sum_local, sum_gathered;   // per pair: checksum at its producer / at rank 0 after the gather
+  std::vector<pf_ctx*> ctx;                        // one per device, all created (and checked) before any rank enters RCCL
+  std::vector<uint64_t> sum_local, sum_gathered;   // per pair: device-side checksum at its producer / at rank 0 after the gather
   std::vector<double> secs;                        // per device
-  std::atomic<int> failed{0};
 };
+
+// A rank that fails after the communicator exists cannot simply return: its peers would wait for it forever inside a grouped
+// send/recv or an all-reduce.  Nothing here is worth a partial result, so any such failure ends the whole process.
+[[noreturn]] void die(int dev, const char* what, const char* msg) {
+  fprintf(stderr, "[gpu %d] %s: %s\n", dev, what, msg ? msg : "?");
+  fflush(stderr);
+  _exit(1);
+}
 
 void worker(Shared* s, int dev) {
   const Args& a = s->a;
   const int ndev = s->ndev;
-  auto die = [&](const char* what, const char* msg) { fprintf(stderr, "[gpu %d] %s: %s\n", dev, what, msg); s->failed = 1; };
-  pf_ctx* ctx = pf_create(dev, a.cols, a.rows);
-  if (!ctx) return die("pf_create", pf_last_error(nullptr));
+  pf_ctx* ctx = s->ctx[dev];
   pf_dist* dist = pf_dist_init(dev, s->id, dev, ndev);
-  if (!dist) { die("pf_dist_init", pf_dist_last_error(nullptr)); pf_destroy(ctx); return; }
+  if (!dist) die(dev, "pf_dist_init", pf_dist_last_error(nullptr));
   const size_t n = size_t(a.cols) * a.rows, ib = n * 4;
   const std::vector<int> mine = pano_batch::pairs_for_device(a.pairs, dev, ndev);
   const int nrounds = pano_batch::rounds(a.pairs, ndev);
@@ -95,51 +101,53 @@ void worker(Shared* s, int dev) {
   void* dOut[2] = {pf_dev_alloc(ctx, ib), pf_dev_alloc(ctx, ib)};
   void* dRecv[2] = {nullptr, nullptr};
   if (dev == 0) { dRecv[0] = pf_dev_alloc(ctx, ib * ndev); dRecv[1] = pf_dev_alloc(ctx, ib * ndev); }
+  if (!dBlend || !dOut[0] || !dOut[1] || (dev == 0 && (!dRecv[0] || !dRecv[1]))) die(dev, "pf_dev_alloc", pf_last_error(ctx));
   {
     std::vector<uint8_t> L, R; std::vector<float> blend;
     for (size_t k = 0; k < mine.size(); ++k) {
       make_pair(a.cols, a.rows, 1234 + mine[k], L, R, blend);
       dL[k] = pf_dev_alloc(ctx, ib); dR[k] = pf_dev_alloc(ctx, ib);
-      if (!dL[k] || !dR[k] || pf_upload(ctx, dL[k], L.data(), ib) || pf_upload(ctx, dR[k], R.data(), ib)) { die("upload", pf_last_error(ctx)); return; }
-      if (k == 0 && pf_upload(ctx, dBlend, blend.data(), n * 4)) { die("upload", pf_last_error(ctx)); return; }
+      if (!dL[k] || !dR[k] || pf_upload(ctx, dL[k], L.data(), ib) || pf_upload(ctx, dR[k], R.data(), ib)) die(dev, "upload", pf_last_error(ctx));
+      if (k == 0 && pf_upload(ctx, dBlend, blend.data(), n * 4)) die(dev, "upload", pf_last_error(ctx));
     }
-    if (mine.empty()) { make_pair(a.cols, a.rows, 1, L, R, blend); pf_upload(ctx, dBlend, blend.data(), n * 4); }
+    if (mine.empty()) { make_pair(a.cols, a.rows, 1, L, R, blend); if (pf_upload(ctx, dBlend, blend.data(), n * 4)) die(dev, "upload", pf_last_error(ctx)); }
   }
-  std::vector<uint8_t> host(a.verify ? ib : 0);
+  // Verification (-verify 1) never touches the host inside the clock: every strip is checksummed ON THE DEVICE (pf_checksum_dev,
+  // ~25 us per 144 MB) at its producer and again in rank 0's receive area after the gather; 8 bytes per strip come back.
   auto consume = [&](int round) {   // rank 0: the blocks of `round` are in dRecv[round % 2]
     if (dev != 0 || !a.verify) return;
     for (int r = 0; r < ndev; ++r) {
       const int p = pano_batch::pair_of(round, r, a.pairs, ndev);
       if (p < 0) continue;
-      pf_download(ctx, host.data(), static_cast<char*>(dRecv[round % 2]) + size_t(r) * ib, ib);
-      s->sum_gathered[p] = fnv(host.data(), ib);
+      if (pf_checksum_dev(ctx, static_cast<char*>(dRecv[round % 2]) + size_t(r) * ib, ib, &s->sum_gathered[p])) die(dev, "checksum", pf_last_error(ctx));
     }
   };
-  if (pf_dist_barrier(dist)) { die("barrier", pf_dist_last_error(dist)); return; }
+  if (pf_dist_barrier(dist)) die(dev, "barrier", pf_dist_last_error(dist));
   const auto t0 = std::chrono::steady_clock::now();
   for (int j = 0; j < nrounds; ++j) {
     const int p = pano_batch::pair_of(j, dev, a.pairs, ndev);
     void* out = dOut[j % 2];
     if (p >= 0) {
       const size_t k = size_t(j);   // my k-th pair is handled in round k
-      if (pf_novel_view_dev(ctx, (const uint8_t*)dL[k], (const uint8_t*)dR[k], a.cols, a.rows, s->max_pct, (const float*)dBlend, (uint8_t*)out, nullptr, nullptr)) {
-        die("pf_novel_view_dev", pf_last_error(ctx)); return;
-      }
-      if (a.verify) { pf_download(ctx, host.data(), out, ib); s->sum_local[p] = fnv(host.data(), ib); }
+      if (pf_novel_view_dev(ctx, (const uint8_t*)dL[k], (const uint8_t*)dR[k], a.cols, a.rows, s->max_pct, (const float*)dBlend, (uint8_t*)out, nullptr, nullptr))
+        die(dev, "pf_novel_view_dev", pf_last_error(ctx));
+      if (a.verify && pf_checksum_dev(ctx, out, ib, &s->sum_local[p])) die(dev, "checksum", pf_last_error(ctx));
     }
     // all ranks take part in every round (a rank without a pair in the last round sends its stale buffer, which rank 0 ignores);
     // the call first waits for the previous gather, whose receive area the consumer below then owns
-    if (pf_dist_gather_async(dist, out, dRecv[j % 2], ib)) { die("gather", pf_dist_last_error(dist)); return; }
+    if (pf_dist_gather_async(dist, out, dRecv[j % 2], ib)) die(dev, "gather", pf_dist_last_error(dist));
     if (j > 0) consume(j - 1);
   }
-  if (pf_dist_wait(dist)) { die("wait", pf_dist_last_error(dist)); return; }
+  if (pf_dist_wait(dist)) die(dev, "wait", pf_dist_last_error(dist));
   if (nrounds > 0) consume(nrounds - 1);
   double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   s->secs[dev] = dt;
-  if (pf_dist_max(dist, &dt)) { die("max", pf_dist_last_error(dist)); return; }
+  if (pf_dist_max(dist, &dt)) die(dev, "max", pf_dist_last_error(dist));
   if (dev == 0) s->secs[0] = dt;   // the job's time: the slowest rank's
   pf_dist_destroy(dist);
-  pf_destroy(ctx);
+  for (void* p : dL) pf_dev_free(ctx, p);
+  for (void* p : dR) pf_dev_free(ctx, p);
+  pf_dev_free(ctx, dBlend); pf_dev_free(ctx, dOut[0]); pf_dev_free(ctx, dOut[1]); pf_dev_free(ctx, dRecv[0]); pf_dev_free(ctx, dRecv[1]);
 }
 
 }  // namespace
@@ -155,14 +163,24 @@ int main(int argc, char** argv) {
   if (s.ndev > have) { fprintf(stderr, "%d GPUs requested, %d present\n", s.ndev, have); return 1; }
   if (pf_dist_unique_id(s.id)) { fprintf(stderr, "%s\n", pf_dist_last_error(nullptr)); return 1; }
   s.sum_local.assign(s.a.pairs, 0); s.sum_gathered.assign(s.a.pairs, 0); s.secs.assign(s.ndev, 0.0);
+  // every context first: a GPU that cannot be used is reported before any rank enters ncclCommInitRank (where the others would hang)
+  s.ctx.assign(s.ndev, nullptr);
+  for (int d = 0; d < s.ndev; ++d) {
+    s.ctx[d] = pf_create(d, s.a.cols, s.a.rows);
+    if (!s.ctx[d]) {
+      fprintf(stderr, "[gpu %d] pf_create: %s\n", d, pf_last_error(nullptr));
+      for (int e = 0; e < d; ++e) pf_destroy(s.ctx[e]);
+      return 1;
+    }
+  }
   std::vector<std::thread> th;
   for (int d = 0; d < s.ndev; ++d) th.emplace_back(worker, &s, d);
   for (auto& t : th) t.join();
-  if (s.failed) return 1;
+  for (pf_ctx* c : s.ctx) pf_destroy(c);
   int bad = 0;
   if (s.a.verify) for (int p = 0; p < s.a.pairs; ++p) if (!s.sum_local[p] || s.sum_local[p] != s.sum_gathered[p]) { fprintf(stderr, "pair %d: gathered strip differs from its producer's\n", p); ++bad; }
   const double mpix = double(s.a.cols) * s.a.rows * s.a.pairs / 1e6;
-  printf("{\"tool\": \"pano_batch\", \"gpus\": %d, \"pairs\": %d, \"size\": \"%dx%d\", \"flow_alg\": \"%s\", \"seconds\": %.4f, \"Mpix/s\": %.2f, \"verified_pairs\": %d, \"gather\": \"rccl send/recv to rank 0, overlapped\"}\n",
-         s.ndev, s.a.pairs, s.a.cols, s.a.rows, s.a.alg.c_str(), s.secs[0], mpix / s.secs[0], s.a.verify ? s.a.pairs - bad : 0);
+  printf("{\"tool\": \"pano_batch\", \"gpus\": %d, \"pairs\": %d, \"size\": \"%dx%d\", \"flow_alg\": \"%s\", \"seconds\": %.4f, \"Mpix/s\": %.2f, \"verified_pairs\": %d, \"verification\": \"%s\", \"gather\": \"rccl send/recv to rank 0, overlapped\"}\n",
+         s.ndev, s.a.pairs, s.a.cols, s.a.rows, s.a.alg.c_str(), s.secs[0], mpix / s.secs[0], s.a.verify ? s.a.pairs - bad : 0, s.a.verify ? "device-side checksums (pf_checksum_dev), no host copies inside the clock" : "off");
   return bad ? 1 : 0;
 }

@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Golden fixture for BASELINE config 5's per-GPU workload: ONE DENSE 9000x4000 overlap pair (seed 1234, pixflow_low,
+the pair bench.py times on every GPU), solved by the CPU oracle in the build container.
+
+The oracle needs minutes per direction at this size, so the GPU tier cannot run it; this script runs it ONCE here
+and stores what tests/test_gpu_fullsize.py::test_dense_canvas_pair_vs_oracle_fixture needs:
+
+  * SHA-256 of the synthetic inputs (L, R, blend) -- the test regenerates them and refuses to compare on a mismatch,
+  * SHA-256 of both flow fields and of the blended strip (NovelViewGeneratorAsymmetricFlow::prepare +
+    combineNovelViews, CPU/OpticalFlow.cpp:30-145) -- the HIP path must reproduce all three BIT FOR BIT,
+  * a stride-16 subsample of the three outputs (to say WHERE a mismatch is, should there ever be one).
+
+Run:  python tests/golden/make_dense_golden.py [cols rows [alg]]   (writes tests/golden/dense_<cols>x<rows>.npz)
+"""
+import hashlib
+import importlib.util
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import orc  # noqa: E402
+
+STRIDE = 16
+SEED = 1234
+
+
+def load_synth():
+    spec = importlib.util.spec_from_file_location("pano_amd_synth", os.path.join(ROOT, "panorama-opticalflow_amd", "synth.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    cols, rows = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (9000, 4000)
+    max_pct = {"pixflow_low": 0, "pixflow_search_20": 20}[sys.argv[3] if len(sys.argv) > 3 else "pixflow_low"]
+    orc.build()
+    synth = load_synth()
+    t0 = time.time()
+    L, R, blend = synth.make_pair_np(cols, rows, SEED)
+    print("inputs generated in %.0f s" % (time.time() - t0), flush=True)
+    res = [None, None]
+
+    def run(d):
+        t1 = time.time()
+        res[d] = orc.flow_one_dir(L, R, max_pct, d)
+        print("direction %d: %.0f s" % (d, time.time() - t1), flush=True)
+
+    th = [threading.Thread(target=run, args=(d,)) for d in (0, 1)]
+    [t.start() for t in th]; [t.join() for t in th]
+    out = orc.combine_novel_views(L, R, res[0], res[1], blend)
+    fix = {"cols": cols, "rows": rows, "seed": SEED, "max_pct": max_pct, "stride": STRIDE,
+           "sha_inputs": np.array([sha(L), sha(R), sha(blend)]),
+           "sha_outputs": np.array([sha(res[0]), sha(res[1]), sha(out)]),
+           "flow_l2r_sub": res[0][::STRIDE, ::STRIDE].copy(), "flow_r2l_sub": res[1][::STRIDE, ::STRIDE].copy(),
+           "out_sub": out[::STRIDE, ::STRIDE].copy()}
+    path = os.path.join(HERE, "dense_%dx%d.npz" % (cols, rows))
+    np.savez_compressed(path, **fix)
+    print("wrote %s (%.1f MB) in %.0f s; max |flow| = %.2f px" % (path, os.path.getsize(path) / 1e6, time.time() - t0,
+                                                                  float(max(np.abs(res[0]).max(), np.abs(res[1]).max()))))
+
+
+if __name__ == "__main__":
+    main()

@@ -20,24 +20,12 @@ def strip(synth):
     return synth.make_pair_np(2000, 4000, 1234)
 
 
-def _with_env(name, value, fn):
-    old = os.environ.get(name)
-    os.environ[name] = value
-    try:
-        return fn()
-    finally:
-        if old is None:
-            del os.environ[name]
-        else:
-            os.environ[name] = old
-
-
 def test_strip_v2_sweep_equals_v1_sweep_bit_for_bit(pf, strip):
     L, R, _ = strip
     c2 = pf.Context(0)
     f0, f1 = c2.flow_bidir(L, R, 0)
     c2.close()
-    c1 = _with_env("PANOFLOW_SWEEP", "1", lambda: pf.Context(0))     # the context picks its sweep kernel at creation
+    c1 = pf.Context(0, exp=True, sweep_impl=1)     # the independent v1 kernel lives in the lab build (libpanoflow_exp.so) only
     g0, g1 = c1.flow_bidir(L, R, 0)
     c1.close()
     assert np.isfinite(f0).all() and np.abs(f0).max() > 1.0          # a real flow field, not zeros
@@ -50,10 +38,12 @@ def test_strip_switches_are_result_neutral_and_runs_are_deterministic(pf, strip)
     out, f0, f1 = c.novel_view(L, R, 0, blend)
     out_b, f0_b, f1_b = c.novel_view(L, R, 0, blend)
     assert np.array_equal(out, out_b) and np.array_equal(f0, f0_b) and np.array_equal(f1, f1_b)
-    for name, value in (("PANOFLOW_NO_WINDOW", "1"), ("PANOFLOW_SPARSE", "1"), ("PANOFLOW_SPARSE", "0")):
-        o2, a0, a1 = _with_env(name, value, lambda: c.novel_view(L, R, 0, blend))
-        assert np.array_equal(f0.view(np.uint32), a0.view(np.uint32)) and np.array_equal(f1.view(np.uint32), a1.view(np.uint32)), name
-        assert np.array_equal(out, o2), name
+    for knobs in ({"sweep_window": 0}, {"sparse_sweep": 1}, {"sparse_sweep": 0}, {"stagger_levels": 0, "pyramid_chaining": 0, "fine_gradient_blocks": 256}):
+        ck = pf.Context(0, **knobs)
+        o2, a0, a1 = ck.novel_view(L, R, 0, blend)
+        ck.close()
+        assert np.array_equal(f0.view(np.uint32), a0.view(np.uint32)) and np.array_equal(f1.view(np.uint32), a1.view(np.uint32)), knobs
+        assert np.array_equal(out, o2), knobs
     # fused entry point == composition of the separate ones
     h0, h1 = c.flow_bidir(L, R, 0)
     assert np.array_equal(f0, h0) and np.array_equal(f1, h1)
@@ -65,18 +55,18 @@ def test_canvas_stitch_step_window_and_sparse_switches(pf, synth):
     cols, rows = 9000, 4000
     top, imgs = synth.make_stitch_set(cols, rows, 1234, 2, "cuda")
     top = top.cpu().numpy(); imgs = [im.cpu().numpy() for im in imgs]
-    c = pf.Context(0)
-
-    def chain():
+    def chain(**knobs):
+        c = pf.Context(0, **knobs)
         c.stitch_step(imgs[0], top, 20, want_out=False)
-        return c.stitch_step(imgs[1], None, 20, want_out=True)
+        out = c.stitch_step(imgs[1], None, 20, want_out=True)
+        c.close()
+        return out
 
     ref = chain()
     assert (ref[..., 3] > 0).mean() > 0.3
     assert np.array_equal(ref, chain())
-    for name, value in (("PANOFLOW_NO_WINDOW", "1"), ("PANOFLOW_SPARSE", "0"), ("PANOFLOW_SPARSE", "1")):
-        assert np.array_equal(ref, _with_env(name, value, chain)), name
-    c.close()
+    for knobs in ({"sweep_window": 0}, {"sparse_sweep": 0}, {"sparse_sweep": 1}):
+        assert np.array_equal(ref, chain(**knobs)), knobs
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -121,6 +111,42 @@ def test_strip_pixflow_low_and_search_20_vs_oracle(pf, orc, synth, strip):
             assert np.array_equal(gotw[pct][d].view(np.uint32), ref[("wide", pct, d)].view(np.uint32)), "wide pair, pixflow %d dir %d" % (pct, d)
     # the wide-search path (PixFlow.hpp:226-270,296-303) really took part: it changes the result
     assert not np.array_equal(gotw[0][0], gotw[20][0])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 5's per-GPU workload -- one DENSE 9000x4000 pair, the pair bench.py times on every GPU -- against the
+# oracle's result computed in the build container (tests/golden/make_dense_golden.py -> dense_9000x4000.npz), plus the
+# independent v1 sweep kernel at that size.
+# ---------------------------------------------------------------------------------------------------------------
+def test_dense_canvas_pair_vs_oracle_fixture(pf, synth):
+    import torch
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dense_9000x4000.npz"))
+    cols, rows, pct, stride = int(g["cols"]), int(g["rows"]), int(g["max_pct"]), int(g["stride"])
+
+    def gen(device):
+        L, R, blend, _ = synth.make_pair(cols, rows, int(g["seed"]), device)
+        L, R, blend = L.cpu().numpy(), R.cpu().numpy(), blend.cpu().numpy()
+        return L, R, blend, [_sha(L), _sha(R), _sha(blend)]
+
+    # same float64 formulas on the GPU (seconds) unless a value lands within an ulp of a rounding boundary: SHA-checked
+    L, R, blend, shas = gen("cuda")
+    if shas != list(g["sha_inputs"]):
+        L, R, blend, shas = gen("cpu")
+    assert shas == list(g["sha_inputs"]), "synthetic pair differs from the one the fixture was computed on"
+    torch.cuda.empty_cache()
+    c = pf.Context(0)
+    out, f0, f1 = c.novel_view(L, R, pct, blend)
+    c.close()
+    s_f0, s_f1, s_out = list(g["sha_outputs"])
+    where = lambda a, sub: "first mismatch in the stride-%d subsample at %s" % (stride, np.argwhere(a[::stride, ::stride] != sub)[:1].tolist())
+    assert _sha(f0) == s_f0, "flow L->R is not bit-identical to the oracle's; " + where(f0, g["flow_l2r_sub"])
+    assert _sha(f1) == s_f1, "flow R->L is not bit-identical to the oracle's; " + where(f1, g["flow_r2l_sub"])
+    assert _sha(out) == s_out, "blended strip is not byte-identical to the oracle's; " + where(out, g["out_sub"])
+    # the independent v1 kernel (lab build) on the same pair: bit for bit
+    c1 = pf.Context(0, exp=True, sweep_impl=1)
+    h0, h1 = c1.flow_bidir(L, R, pct)
+    c1.close()
+    assert np.array_equal(f0.view(np.uint32), h0.view(np.uint32)) and np.array_equal(f1.view(np.uint32), h1.view(np.uint32))
 
 
 # ---------------------------------------------------------------------------------------------------------------

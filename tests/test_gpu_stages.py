@@ -148,11 +148,7 @@ def test_sweep_v1_kernel_cross_check(pf, orc):
     flow = (r.standard_normal((h, w, 2)) * 2.0).astype(np.float32)
     blurred = orc.gaussian_blur(flow, 15, 8.0)
     a = np.ones((h, w), np.float32); a[50:60, 30:90] = 0.2
-    os.environ["PANOFLOW_SWEEP"] = "1"
-    try:
-        c1 = pf.Context(0)
-    finally:
-        del os.environ["PANOFLOW_SWEEP"]
+    c1 = pf.Context(0, exp=True, sweep_impl=1)     # the v1 kernel only exists in the lab build (libpanoflow_exp.so)
     c2 = pf.Context(0)
     for fwd in (1, 0):
         ref = orc.sweep(g0[..., 0], g0[..., 1], g1[..., 0], g1[..., 1], blurred, a, a, flow, fwd)
@@ -271,38 +267,44 @@ def test_level_fuzz_alpha_patterns(ctx, orc):
 
 
 @pytest.mark.parametrize("mode", ["1", "2", "relax", "fuse"])
-def test_sweep_record_experiment_paths_are_bit_identical(mode):
-    """Rejected-on-measurement alternatives kept behind a switch must stay exact.  Mode relax = PANOFLOW_SWEEP=3, the event-driven
-    relaxation sweep on LDS-resident tiles (kernels_relax.inl: same fixed point reached in any evaluation order; slower than the
-    wavefront because the longest dependency chain, not the anti-diagonal count, still sets its time:
-    profiles/r02_relaxation_sweep.txt).  PANOFLOW_PREP=1 (loader waves compute the records) and =2 (prepass blocks inside the sweep launch, G16/R1 hand-off) are
-    the two record-path experiments.  Mode fuse = the throughput mode's launch fusion (upsample inside the next level's Gaussian,
-    second median inside the diffusion kernel) forced on for every level.  The switches are read once per process."""
-    import os, subprocess, sys
-    code = r'''
-import sys, os, numpy as np
-sys.path.insert(0, "tests"); sys.path.insert(0, "oracle")
-from conftest import load_pkg_module
-import orc
-pf = load_pkg_module("pyabi")
-c = pf.Context(0)
-for (w, h, fwd) in [(150, 131, 1), (64, 257, 0), (300, 90, 1)]:
-    r = np.random.default_rng(7 + w + fwd)
-    img0 = r.random((h, w)).astype(np.float32); img1 = np.roll(img0, 2, axis=1) + 0.05 * r.random((h, w)).astype(np.float32)
-    g0 = np.stack(orc.gradients(img0), -1); g1 = np.stack(orc.gradients(img1), -1)
-    flow = (r.standard_normal((h, w, 2)) * 1.5).astype(np.float32)
-    bl = orc.gaussian_blur(flow, 15, 8.0)
-    a0 = np.ones((h, w), np.float32); a1 = np.ones((h, w), np.float32); a0[h // 3: h // 3 + 9, w // 4: w // 2] = 0.5; a1[:, :3] = 0.0
-    ref = orc.sweep(g0[..., 0], g0[..., 1], g1[..., 0], g1[..., 1], bl, a0, a1, flow, fwd)
-    got = c.stage_sweep(g0, g1, bl, a0, a1, flow, fwd)
-    assert np.array_equal(got, ref), (w, h, fwd)
-L, R, blend = load_pkg_module("synth").make_pair_np(320, 256, 4321)
-f0, f1 = c.flow_bidir(L, R, 20)
-r0, r1 = orc.flow_bidir(L, R, 20)
-assert np.array_equal(f0, r0) and np.array_equal(f1, r1)
-print("ok")
-'''
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, **({"PANOFLOW_SWEEP": "3"} if mode == "relax" else {"PANOFLOW_FUSE_UPS_PX": "100000000"} if mode == "fuse" else {"PANOFLOW_PREP": mode}))
-    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+def test_sweep_record_experiment_paths_are_bit_identical(pf, orc, synth, mode):
+    """Rejected-on-measurement alternatives must stay exact.  They live in the lab build (libpanoflow_exp.so, -DPF_EXPERIMENTS), not
+    in the product library.  Mode relax = pf_config::sweep_impl 3, the event-driven relaxation sweep on LDS-resident tiles
+    (kernels_relax.inl: same fixed point reached in any evaluation order; slower than the wavefront because the longest dependency
+    chain, not the anti-diagonal count, still sets its time: profiles/r02_relaxation_sweep.txt).  record_path 1 (loader waves compute
+    the records) and 2 (prepass blocks inside the sweep launch, G16/R1 hand-off) are the two record-path experiments.  Mode fuse = the
+    throughput mode's launch fusion (upsample inside the next level's Gaussian, second median inside the diffusion kernel) forced on
+    for every level -- product code, product library."""
+    if mode == "relax":
+        c = pf.Context(0, exp=True, sweep_impl=3)
+    elif mode == "fuse":
+        c = pf.Context(0, fuse_small_level_px=100000000)
+    else:
+        c = pf.Context(0, exp=True, record_path=int(mode))
+    for (w, h, fwd) in [(150, 131, 1), (64, 257, 0), (300, 90, 1)]:
+        r = np.random.default_rng(7 + w + fwd)
+        img0 = r.random((h, w)).astype(np.float32); img1 = np.roll(img0, 2, axis=1) + 0.05 * r.random((h, w)).astype(np.float32)
+        g0 = np.stack(orc.gradients(img0), -1); g1 = np.stack(orc.gradients(img1), -1)
+        flow = (r.standard_normal((h, w, 2)) * 1.5).astype(np.float32)
+        bl = orc.gaussian_blur(flow, 15, 8.0)
+        a0 = np.ones((h, w), np.float32); a1 = np.ones((h, w), np.float32); a0[h // 3: h // 3 + 9, w // 4: w // 2] = 0.5; a1[:, :3] = 0.0
+        ref = orc.sweep(g0[..., 0], g0[..., 1], g1[..., 0], g1[..., 1], bl, a0, a1, flow, fwd)
+        got = c.stage_sweep(g0, g1, bl, a0, a1, flow, fwd)
+        assert np.array_equal(got, ref), (w, h, fwd)
+    L, R, blend = synth.make_pair_np(320, 256, 4321)
+    f0, f1 = c.flow_bidir(L, R, 20)
+    r0, r1 = orc.flow_bidir(L, R, 20)
+    assert np.array_equal(f0, r0) and np.array_equal(f1, r1)
+    c.close()
+
+
+def test_product_library_ships_one_sweep(pf):
+    """libpanoflow.so contains the wavefront sweep only: the cross-check implementations are refused, and it reads no PANOFLOW_*
+    environment switch (none of the names is in the binary)."""
+    with pytest.raises(pf.PanoflowError, match="PF_EXPERIMENTS"):
+        pf.Context(0, sweep_impl=1)
+    with pytest.raises(pf.PanoflowError, match="PF_EXPERIMENTS"):
+        pf.Context(0, record_path=2)
+    blob = open(pf.SO_PATH, "rb").read()
+    assert b"PANOFLOW_" not in blob and b"k_sweep_relax" not in blob
+    assert b"k_sweep_relax" in open(pf.SO_PATH_EXP, "rb").read()

@@ -1,0 +1,26 @@
+"""CPU tier: the device restatements of the blend's two libm calls (csrc/libm_exact.hpp: tanhf, fp64 exp;
+CPU/OpticalFlow.cpp:69-76) equal THIS host's libm bit for bit -- tanhf on all 2^32 float bit patterns, exp on 2^31
+doubles over the whole argument range.  The same source compiled by hipcc runs in k_blend (IEEE +, *, /, fma give the
+same bits there), which is what makes the blended panorama byte-identical to the CPU path."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def _has_fma():
+    try:
+        return " fma " in open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+
+
+@pytest.mark.skipif(not _has_fma(), reason="host CPU without FMA3: its libm runs the non-FMA exp variant, which rounds differently in rare cases")
+def test_libm_restatements_equal_host_libm_bit_for_bit(tmp_path):
+    exe = str(tmp_path / "libm_exact_test")
+    src = os.path.join(ROOT, "tests", "cpp", "libm_exact_test.cpp")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-pthread", "-o", exe, src], check=True)
+    out = subprocess.run([exe, "full"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and " 0 mismatches" in out.stdout, out.stdout + out.stderr
