@@ -2,14 +2,17 @@
 """Benchmark of the hot path: Mpix/s of bidirectional PixFlow + novel-view blend, inputs resident in HBM
 when the clock starts.
 
-  --gpus 1 (default): BASELINE.json configs[1] -- ONE 2000x4000 overlap strip, pixflow_low.  `value` is quoted on it.
-      The same JSON line carries, as extra keys, the other single-GPU configs timed in-process:
-      `canvas_pair_9000x4000` (north_star's target size through pf_novel_view_dev), `config4_chain` (the full 5+top
-      stitch chain at 9000x4000, pixflow_search_20, host images -> host composite through pf_stitch_step),
-      `roofline.latency_bound` (dependency-chain bound of the exact sweeps) and `cpu_baseline` (1 and 2 threads).
-  --gpus N>1: BASELINE.json configs[4] -- N independent 9000x4000 pairs, one per GPU (seeds 1234..), weak scaling;
-      the blended strips are gathered to rank 0 over RCCL, overlapped with the next pair.
-      (--cols/--rows override the workload in either mode.)
+ONE per-GPU workload for every --gpus N, so that the driver's N = 1, 2, 4, 8 values divide into a scaling curve:
+  north_star / BASELINE.json configs[4] -- one DENSE 9000x4000 overlap pair per GPU (seed 1234 + rank), pixflow_low, flows L->R and
+  R->L + novel-view blend through pf_novel_view_dev; weak scaling, no collective on the data path.  With N > 1 (or
+  PANOFLOW_FORCE_DIST=1 on one GPU) the blended strips are additionally gathered to rank 0 over RCCL inside libpanoflow.so
+  (pf_dist_*), overlapped with the next pair.  `value` = N x 36 Mpix x steps / max-over-ranks time.
+At N = 1 the same JSON line carries, as extra keys timed in-process (never `value`):
+  `strip_2000x4000`  BASELINE configs[1] (one 2000x4000 strip, what rounds 1-2 quoted `value` on),
+  `config4_chain`    BASELINE configs[3] (5+top stitch chain at 9000x4000, pixflow_search_20, host images -> host composite),
+  `throughput_mode`  several independent strips side by side on the GPU (pf_novel_view_batch_dev),
+  `roofline.latency_bound` (dependency-chain bound of the exact sweeps), `cpu_baseline` + `parity_vs_cpu`.
+(--cols/--rows override the workload.)
 
 One process per GPU (torch.distributed / RCCL for the barrier, the max-over-ranks time and the final gather);
 prints ONE JSON line on rank 0.
@@ -97,11 +100,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cols", type=int, default=0, help="default: 2000 at --gpus 1 (configs[1]), 9000 at --gpus N>1 (configs[4])")
-    ap.add_argument("--rows", type=int, default=0, help="default: 4000")
+    ap.add_argument("--cols", type=int, default=9000, help="default 9000 (BASELINE configs[4] / north_star: one 9000x4000 pair per GPU, for EVERY --gpus N)")
+    ap.add_argument("--rows", type=int, default=4000)
     ap.add_argument("--alg", default="pixflow_low")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the 9000x4000 pair / config-4 chain / lone-band step-time legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the 2000x4000 strip / config-4 chain / throughput / lone-band step-time legs")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--concurrent", type=int, default=1, help="independent pairs in flight per GPU (one context + host thread each); 1 = the BASELINE config")
     args = ap.parse_args()
@@ -118,14 +121,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    force_dist = os.environ.get("PANOFLOW_FORCE_DIST") == "1"   # exercise the RCCL path on a single GPU
+    force_dist = os.environ.get("PANOFLOW_FORCE_DIST") == "1"   # exercise the RCCL path on a single GPU (same workload, same `value`)
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     pf = _load("pyabi"); synth = _load("synth"); shard = _load("shard")
-    cols = args.cols or (2000 if world == 1 else 9000)
-    rows = args.rows or 4000
+    cols, rows = args.cols, args.rows
     max_pct = pf.max_percentage_by_name(args.alg)
     ctx = pf.Context(local_rank, cols, rows)            # pre-sized: the first step pays no allocation
 
@@ -138,7 +140,7 @@ def main():
     assert my_pairs == [rank]
     torch.cuda.synchronize()
 
-    # optional throughput mode: more independent pairs in flight on the same GPU (a sweep only occupies ~35 of 256 CUs)
+    # optional: more independent pairs in flight on the same GPU (a sweep only occupies a fraction of the 256 CUs)
     extra = []
     for j in range(1, max(1, args.concurrent)):
         Lj, Rj, bj, _ = synth.make_pair(cols, rows, 1234 + rank + 1000 * j, dev)
@@ -225,6 +227,7 @@ def main():
     prof = ctx.profile()
     # per-family breakdown from ONE extra, untimed step with every family instrumented
     ctx.profile_reset(); ctx.profile_enable(1); step(); ctx.profile_enable(0)
+    fence()
     prof_all = ctx.profile()
     ctx.profile_reset()
     if rank == 0:
@@ -233,43 +236,42 @@ def main():
         value = npairs * mpix * args.steps / dt
         P, nlev, sweep_steps = pf.level_pixels(cols, rows)
         b_alg = pf.algorithmic_bytes(cols, rows)
-        which = "BASELINE configs[1]" if (world == 1 and (cols, rows) == (2000, 4000)) else ("BASELINE configs[4] (one 9000x4000 pair per GPU)" if (cols, rows) == (9000, 4000) else "custom size")
+        which = "BASELINE configs[4] / north_star" if (cols, rows) == (9000, 4000) else ("BASELINE configs[1]" if (cols, rows) == (2000, 4000) else "custom size")
         res = {
             "metric": "Mpix/s bidirectional optical flow (overlap strip) at 1/2/4/8 GPU", "value": round(value, 3), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %dx%d overlap pair per GPU, %s, flow L->R + R->L + novel-view blend, %d pair(s) in flight per GPU" % (which, cols, rows, args.alg, max(1, args.concurrent)),
+            "config": {"workload": "%s: one dense %dx%d overlap pair per GPU (the same for every --gpus N), %s, flow L->R + R->L + novel-view blend, %d pair(s) in flight per GPU"
+                                   % (which, cols, rows, args.alg, max(1, args.concurrent)),
                        "levels": nlev, "level_pixels": P, "sweep_steps_per_direction": sweep_steps, "swept_steps_per_direction_in_gated_window": swept,
-                       "final_gather": ((gather_note or "rccl send/recv to rank 0 inside libpanoflow.so (pf_dist_*), overlapped with the next pair") + "; rank-0 slot verified: %s" % gathered_ok) if og else "none"},
+                       "final_gather": ((gather_note or "rccl send/recv to rank 0 inside libpanoflow.so (pf_dist_*), overlapped with the next pair") + "; rank-0 slot verified: %s" % gathered_ok) if og else "none (single rank)"},
             "ms_per_step_median": round(med_ms, 3), "value_at_median": round(npairs * mpix / (med_ms * 1e-3), 3),
         }
         # roofline of the dominant kernel (the exact wavefront sweep): algorithmic bytes per launch =
         # 48 B per level-pixel (alpha/grad0 16 + blurred 8 + flow r/w 16 + grad1 gather 8)
         # x the level's pixels; 2 sweeps x 2 directions x all levels = 4*48*P bytes per step.
-        # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
-        # figure comes from the committed rocprofv3 --pmc pass of this same command (profiles/, see its note); it only
-        # applies to the default workload.
+        # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is
+        # READ FROM A COMMITTED FILE -- the rocprofv3 --pmc passes of this same command (profiles/, see its note) -- and labelled so.
         traffic, traffic_src = None, None
-        for name in ("r02_pmc_bench.json", "r01_pmc_bench.json"):
-            pmc_path = os.path.join(ROOT, "profiles", name)
-            if (cols, rows, args.alg) == (2000, 4000, "pixflow_low") and os.path.exists(pmc_path):
-                try:
-                    pl = json.load(open(pmc_path))["sweep_per_launch"]
-                    traffic = round(0.5 * (pl["traffic_bytes_lo"] + pl["traffic_bytes_hi"]))
-                    traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per sweep launch; read side bracketed [raw,2x raw], midpoint reported; not re-measured in this run)" % name
-                    break
-                except Exception:
-                    pass
+        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
+        if (cols, rows, args.alg) == (9000, 4000, "pixflow_low") and os.path.exists(pmc_path):
+            try:
+                pl = json.load(open(pmc_path))["sweep_per_launch"]
+                traffic = round(0.5 * (pl["traffic_bytes_lo"] + pl["traffic_bytes_hi"]))
+                traffic_src = "from_file: profiles/r03_pmc_bench.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per sweep launch; read side bracketed [raw, 2x raw], midpoint reported; NOT measured by this run)"
+            except Exception:
+                pass
         if "sweep" in prof and prof["sweep"][1] > 0:
             ms, n = prof["sweep"]
             bytes_total = 48.0 * P * 4 * args.steps
             ach = bytes_total / (ms * 1e-3) / 1e9
             res["roofline"] = {"bound": "hbm", "kernel": "k_sweep_prep+k_sweep2", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6),
                                "traffic": traffic, "traffic_source": traffic_src, "launches": n, "avg_launch_us": round(1000 * ms / n, 2),
+                               "algorithmic_bytes_per_launch": round(bytes_total / n),
                                "note": "exact Gauss-Seidel sweep is dependency-latency bound (see latency_bound), not HBM bound"}
             sweep_ms_per_dir = ms / args.steps / 2.0          # the two directions run concurrently on two streams
         else:
-            res["roofline"] = {"bound": "hbm", "kernel": "k_sweep", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None}
+            res["roofline"] = {"bound": "hbm", "kernel": "k_sweep_prep+k_sweep2", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None}
             sweep_ms_per_dir = None
         ach_path = b_alg * args.steps / dt / 1e9
         res["roofline_path"] = {"bound": "hbm", "achieved": round(ach_path, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach_path / 8000.0, 6),
@@ -278,36 +280,49 @@ def main():
 
         if world == 1 and not args.no_extras and args.concurrent <= 1:
             # ---- the honest bound of the sweeps: a dependency chain of `swept` steps per direction x the time of one step
-            # of a lone band (measured live) ----
+            # of a lone band (measured live); hw_floor_us = the same chain priced with the guide's instruction latencies
+            # (profiles/r03_sweep_step_isa.txt) ----
             t_step = measure_t_step(pf, ctx, np)
             if sweep_ms_per_dir:
                 bound_ms = swept * t_step * 1e-3
-                res["roofline"]["latency_bound"] = {"swept_steps": swept, "t_step_us": round(t_step, 4), "bound_ms": round(bound_ms, 3),
-                                                    "measured_sweep_ms_per_direction": round(sweep_ms_per_dir, 3), "frac_of_bound": round(bound_ms / sweep_ms_per_dir, 4),
-                                                    "note": "bound = swept_steps x t_step of ONE lone band (8 rows x 4096, HIP events); the two directions run concurrently"}
-            # ---- north_star's target size: one 9000x4000 pair through the same entry point ----
+                lb = {"swept_steps": swept, "t_step_us": round(t_step, 4), "bound_ms": round(bound_ms, 3),
+                      "measured_sweep_ms_per_direction": round(sweep_ms_per_dir, 3), "frac_of_bound": round(bound_ms / sweep_ms_per_dir, 4),
+                      "note": "bound = swept_steps x t_step of ONE lone band (8 rows x 4096, HIP events); the two directions run concurrently"}
+                isa = os.path.join(ROOT, "profiles", "r03_sweep_step_isa.json")
+                if os.path.exists(isa):
+                    try:
+                        hw = json.load(open(isa))
+                        lb["hw_floor_us"] = hw["hw_floor_us"]
+                        lb["hw_floor_ms"] = round(swept * hw["hw_floor_us"] * 1e-3, 3)
+                        lb["frac_of_hw_floor"] = round(swept * hw["hw_floor_us"] * 1e-3 / sweep_ms_per_dir, 4)
+                        lb["hw_floor_source"] = "from_file: profiles/r03_sweep_step_isa.txt (loop-carried dependency chain of one step of compute_band<1,...>, priced with MI355X_MICROARCH.md latencies)"
+                    except Exception:
+                        pass
+                res["roofline"]["latency_bound"] = lb
             del extra[:]
-            cc, cr = 9000, 4000
-            cx = pf.Context(local_rank, cc, cr)
-            Lc, Rc, bc, _ = synth.make_pair(cc, cr, 1234, dev)
-            oc = torch.empty((cr, cc, 4), dtype=torch.uint8, device=dev)
+            # ---- BASELINE configs[1]: ONE 2000x4000 strip (what rounds 1-2 quoted `value` on) ----
+            sc, sr = 2000, 4000
+            Ls, Rs, bs, _ = synth.make_pair(sc, sr, 1234, dev)
+            os_ = torch.empty((sr, sc, 4), dtype=torch.uint8, device=dev)
+            cs = pf.Context(local_rank, sc, sr)
             torch.cuda.synchronize()
             ts = []
-            for i in range(4):
+            for i in range(8):
                 t1 = time.perf_counter()
-                cx.novel_view_dev(Lc.data_ptr(), Rc.data_ptr(), cc, cr, max_pct, bc.data_ptr(), oc.data_ptr())
+                cs.novel_view_dev(Ls.data_ptr(), Rs.data_ptr(), sc, sr, max_pct, bs.data_ptr(), os_.data_ptr())
                 ts.append(time.perf_counter() - t1)
             tm = statistics.median(ts[1:])
-            res["canvas_pair_9000x4000"] = {"value": round(cc * cr / 1e6 / tm, 3), "unit": "Mpix/s", "ms_per_pair": round(1000 * tm, 3), "alg": args.alg,
-                                            "swept_steps_per_direction": cx.last_swept_steps(), "steps": 3, "warmup": 1,
-                                            "roofline_path_frac": round(pf.algorithmic_bytes(cc, cr) / tm / 8e12, 6)}
-            del Lc, Rc, bc, oc
+            res["strip_2000x4000"] = {"value": round(sc * sr / 1e6 / tm, 3), "unit": "Mpix/s", "ms_per_pair": round(1000 * tm, 3), "alg": args.alg,
+                                      "workload": "BASELINE configs[1]: one 2000x4000 strip", "swept_steps_per_direction": cs.last_swept_steps(), "steps": 7, "warmup": 1,
+                                      "roofline_path_frac": round(pf.algorithmic_bytes(sc, sr) / tm / 8e12, 6)}
+            cs.close()
             # ---- BASELINE configs[3]: the full 5+top chain, 9000x4000, pixflow_search_20, host images -> host composite ----
+            cc, cr = 9000, 4000
             top, imgs = synth.make_stitch_set(cc, cr, 1234, 5, dev)
             top = top.cpu().numpy(); imgs = [im.cpu().numpy() for im in imgs]
             torch.cuda.empty_cache()
-
-            final = np.zeros((cr, cc, 4), np.uint8)       # the caller's result buffer, reused across runs (like the reference's Mat)
+            cx = ctx if (cols, rows) == (cc, cr) else pf.Context(local_rank, cc, cr)
+            final = cx.host_array((cr, cc, 4))       # the caller's result buffer (page-locked, pf_host_alloc), reused across runs like the reference's Mat
 
             def chain():
                 t1 = time.perf_counter()
@@ -320,34 +335,70 @@ def main():
             chain()
             tc = sorted(chain()[0] for _ in range(3))[1]
             res["config4_chain"] = {"seconds": round(tc, 4), "unit": "s", "workload": "5+top stitch chain, 9000x4000, pixflow_search_20, pf_stitch_step x5 (host images in, host composite out)",
-                                    "Mpix/s_canvas": round(5 * cc * cr / 1e6 / tc, 2), "runs": 3, "warmup": 1}
-            cx.close()
+                                    "Mpix/s_canvas": round(5 * cc * cr / 1e6 / tc, 2), "runs": 3, "warmup": 1, "statistic": "median"}
+            del final
+            if cx is not ctx:
+                cx.close()
             # ---- throughput mode (never `value`): 12 independent strips, 6 in flight on this GPU, through the C ABI's batch entry ----
             nb, infl = 12, 6
-            pairs_b = [synth.make_pair(cols, rows, 5000 + i, dev) for i in range(nb)]
-            outs_b = [torch.empty_like(out) for _ in range(nb)]
+            pairs_b = [synth.make_pair(sc, sr, 5000 + i, dev) for i in range(nb)]
+            outs_b = [torch.empty_like(os_) for _ in range(nb)]
             torch.cuda.synchronize()
-            ct = pf.Context(local_rank, cols, rows)          # its own context: the lanes it creates go away with it
-            call_b = lambda: ct.novel_view_batch_dev([p[0].data_ptr() for p in pairs_b], [p[1].data_ptr() for p in pairs_b], cols, rows, max_pct,
+            ct = pf.Context(local_rank, sc, sr)          # its own context: the lanes it creates go away with it
+            call_b = lambda: ct.novel_view_batch_dev([p[0].data_ptr() for p in pairs_b], [p[1].data_ptr() for p in pairs_b], sc, sr, max_pct,
                                                       [p[2].data_ptr() for p in pairs_b], [o.data_ptr() for o in outs_b], None, None, in_flight=infl)
             call_b()
-            t1 = time.perf_counter(); call_b(); tb = time.perf_counter() - t1
-            res["throughput_mode"] = {"value": round(nb * mpix / tb, 3), "unit": "Mpix/s", "pairs": nb, "in_flight": infl, "entry": "pf_novel_view_batch_dev",
-                                      "note": "several independent pairs side by side on one GPU; an extra figure, not the BASELINE single-strip config"}
-            del pairs_b, outs_b
+            tbs = []
+            for _ in range(3):
+                t1 = time.perf_counter(); call_b(); tbs.append(time.perf_counter() - t1)
+            tb = statistics.median(tbs)
+            res["throughput_mode"] = {"value": round(nb * sc * sr / 1e6 / tb, 3), "unit": "Mpix/s", "pairs": nb, "in_flight": infl, "entry": "pf_novel_view_batch_dev",
+                                      "workload": "12 independent 2000x4000 strips", "runs": 3, "warmup": 1, "statistic": "median",
+                                      "note": "several independent pairs side by side on one GPU; an extra figure, not the per-GPU workload `value` is quoted on"}
+            del pairs_b, outs_b, Ls, Rs, bs, os_
             ct.close()
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
-            Lh, Rh, bh = L.cpu().numpy(), R.cpu().numpy(), blend.cpu().numpy()
+            # A 9000x4000 pair costs the oracle ~2 x 100 s; the bounded sample is a 2000-column sub-strip of the SAME pair (the
+            # whole path on it: 2 flow directions + blend), timed on 1 and on 2 host threads, and compared with the GPU path
+            # run on exactly that sub-strip.  The full pair is held to the oracle through the committed fixture's SHA-256.
+            x0 = max(0, (cols - 2000) // 2); x1 = min(cols, x0 + 2000)
+            Lh, Rh, bh = L[:, x0:x1].contiguous().cpu().numpy(), R[:, x0:x1].contiguous().cpu().numpy(), blend[:, x0:x1].contiguous().cpu().numpy()
             t1, t2, r0, r1, rout = cpu_baseline(Lh, Rh, bh, max_pct)
-            g0, g1, gout = f0.cpu().numpy(), f1.cpu().numpy(), (og.bufs[(og.k - 1) % 2] if og else out).cpu().numpy()
-            off = np.abs(gout.astype(np.int32) - rout.astype(np.int32))
-            res["cpu_baseline"] = {"value": round(mpix / t2, 4), "unit": "Mpix/s", "cores": 2, "kind": "port",
-                                   "sample": "the same %dx%d pair, whole path once: 2 flow directions on 2 threads + blend (%.1f s)" % (cols, rows, t2),
-                                   "one_thread": {"value": round(mpix / t1, 4), "unit": "Mpix/s", "cores": 1, "seconds": round(t1, 2)},
+            cg = pf.Context(local_rank)
+            gout, g0, g1 = cg.novel_view(Lh, Rh, max_pct, bh)
+            cg.close()
+            smp = (x1 - x0) * rows / 1e6
+            res["cpu_baseline"] = {"value": round(smp / t2, 4), "unit": "Mpix/s", "cores": 2, "kind": "port",
+                                   "sample": "columns [%d, %d) of the same %dx%d pair (a %dx%d sub-strip), whole path once: 2 flow directions on 2 threads + blend (%.1f s)" % (x0, x1, cols, rows, x1 - x0, rows, t2),
+                                   "one_thread": {"value": round(smp / t1, 4), "unit": "Mpix/s", "cores": 1, "seconds": round(t1, 2)},
                                    "host_threads_available": os.cpu_count(),
                                    "note": "leg (iii) of SURVEY 8(d) (one pair per core) only applies to config 5 and is not run"}
-            res["parity_vs_cpu"] = {"max_abs_dflow_px": float(max(np.abs(g0 - r0).max(), np.abs(g1 - r1).max())),
-                                    "blend_pixels_off": int((off > 0).sum()), "blend_max_lsb": int(off.max())}
+            res["parity_vs_cpu"] = {"sample_max_abs_dflow_px": float(max(np.abs(g0 - r0).max(), np.abs(g1 - r1).max())),
+                                    "sample_blend_bytes_off": int((gout != rout).sum())}
+            fx = os.path.join(ROOT, "tests", "golden", "dense_%dx%d.npz" % (cols, rows))
+            if os.path.exists(fx) and args.alg == "pixflow_low":
+                import hashlib
+                g = np.load(fx)
+                sha = lambda t: hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()
+                note = "the timed pair itself (generated on this GPU) is the fixture's"
+                last_out = og.bufs[(og.k - 1) % 2] if og else out
+                if [sha(L), sha(R), sha(blend)] != list(g["sha_inputs"]):
+                    # sin/cos of the synthetic texture round differently on the GPU in a few pixels: regenerate the fixture's pair on
+                    # the host, and run ONE more (untimed) pass of the same entry point on it
+                    Lc, Rc, bc, _ = synth.make_pair(cols, rows, 1234 + rank, "cpu")
+                    L.copy_(Lc); R.copy_(Rc); blend.copy_(bc)
+                    torch.cuda.synchronize()
+                    ctx.novel_view_dev(L.data_ptr(), R.data_ptr(), cols, rows, max_pct, blend.data_ptr(), out.data_ptr(), f0.data_ptr(), f1.data_ptr())
+                    last_out = out
+                    note = "the fixture's pair regenerated on the host (the GPU-generated texture differs from it in a few pixels), one extra untimed pass"
+                if [sha(L), sha(R), sha(blend)] == list(g["sha_inputs"]):
+                    res["parity_vs_cpu"]["full_pair_vs_oracle_fixture"] = {
+                        "flow_l2r_bit_identical": sha(f0) == str(g["sha_outputs"][0]), "flow_r2l_bit_identical": sha(f1) == str(g["sha_outputs"][1]),
+                        "blend_byte_identical": sha(last_out) == str(g["sha_outputs"][2]), "inputs": note,
+                        "fixture": "tests/golden/dense_%dx%d.npz (SHA-256 of the oracle's outputs for this very pair, computed in the build container)" % (cols, rows)}
+                else:
+                    res["parity_vs_cpu"]["full_pair_vs_oracle_fixture"] = "synthetic pair differs from the fixture's even when generated on the host: not compared"
         line = json.dumps(res)
     if pfd:
         pfd.close()

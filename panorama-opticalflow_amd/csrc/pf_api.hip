@@ -556,12 +556,15 @@ int use(pf_ctx* c) {
   return 0;
 }
 
+// packed rows on both sides (the usual case): one linear copy -- the DMA engines at the link rate when the host side is pinned
 int up2d(pf_ctx* c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, int rows) {
-  HIPCHK(c, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, hipMemcpyHostToDevice, c->s_main));
+  if (dpitch == width_bytes && spitch == width_bytes) HIPCHK(c, hipMemcpyAsync(dst, src, width_bytes * size_t(rows), hipMemcpyHostToDevice, c->s_main));
+  else HIPCHK(c, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, hipMemcpyHostToDevice, c->s_main));
   return 0;
 }
 int down2d(pf_ctx* c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, int rows) {
-  HIPCHK(c, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, hipMemcpyDeviceToHost, c->s_main));
+  if (dpitch == width_bytes && spitch == width_bytes) HIPCHK(c, hipMemcpyAsync(dst, src, width_bytes * size_t(rows), hipMemcpyDeviceToHost, c->s_main));
+  else HIPCHK(c, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, hipMemcpyDeviceToHost, c->s_main));
   return 0;
 }
 
@@ -614,6 +617,11 @@ pf_ctx* create_ctx(const pf_config& cfg, bool lane) {
   c->device = device;
   bool ok = hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking) == hipSuccess;
   for (int d = 0; d < 2 && ok; ++d) ok = hipStreamCreateWithFlags(&c->s_dir[d], hipStreamNonBlocking) == hipSuccess;
+  // The runtime hands hardware queues to streams round-robin in creation order.  A context's five streams are created together so
+  // that they land on five DIFFERENT queues: created on first use (after other contexts' streams), the blend-ramp stream ended
+  // up sharing a queue with one of the flow directions and a 9000x4000 stitch step took 7 ms longer.  Lanes of the throughput
+  // mode never stitch: three streams each, so that six lanes fit GPU_MAX_HW_QUEUES = 24.
+  if (!lane) ok = ok && hipStreamCreateWithFlags(&c->s_aux, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_alpha, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_aux_go, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_fine, hipEventDisableTiming) == hipSuccess &&
@@ -1071,7 +1079,8 @@ int pf_stitch_step(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int 
   // everything of this step is enqueued: upload the NEXT step's left image now (announced with pf_stitch_prefetch); the
   // host-side staging of a pageable source runs while the GPU computes
   if (hint.src && hint.src != l && hint.cols == cols && hint.rows == rows) {
-    HIPCHK(c, hipMemcpy2DAsync(dnext, size_t(cols) * 4, hint.src, hint.step, size_t(cols) * 4, rows, hipMemcpyHostToDevice, c->s_copy));
+    if (hint.step == size_t(cols) * 4) HIPCHK(c, hipMemcpyAsync(dnext, hint.src, n * 4, hipMemcpyHostToDevice, c->s_copy));
+    else HIPCHK(c, hipMemcpy2DAsync(dnext, size_t(cols) * 4, hint.src, hint.step, size_t(cols) * 4, rows, hipMemcpyHostToDevice, c->s_copy));
     HIPCHK(c, hipStreamSynchronize(c->s_copy));
     c->ready = hint;
   }

@@ -30,7 +30,7 @@ sw = [v for k, v in fam.items() if 'k_sweep' in k]
 launches = sum(v["dispatches"] for k, v in fam.items() if 'k_sweep2' in k)      # one launch = prep + main
 fb = sum(v["FETCH_SIZE_KB"] for v in sw) * 1024 / max(launches, 1)
 wb = sum(v["WRITE_SIZE_KB"] for v in sw) * 1024 / max(launches, 1)
-out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only) on \`python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile\` (2000x4000 strip; the run executes 2 pairs: the timed step + the untimed per-family profiling step). Values are KB summed over all dispatches of a kernel family. gfx950: FETCH_SIZE counts 1/2 of wide (16 B/lane) coalesced reads, so the true read side lies in [raw, 2*raw] (MI355X_MICROARCH.md, HBM section).",
+out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only) on \`python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile\` (one dense 9000x4000 pair per step; the run executes 2 pairs: the timed step + the untimed per-family profiling step). Values are KB summed over all dispatches of a kernel family. gfx950: FETCH_SIZE counts 1/2 of wide (16 B/lane) coalesced reads, so the true read side lies in [raw, 2*raw] (MI355X_MICROARCH.md, HBM section).",
        "pairs_in_run": pairs, "families": fam,
        "sweep_per_launch": {"launches": launches, "fetch_bytes_raw": fb, "write_bytes": wb, "traffic_bytes_lo": fb + wb, "traffic_bytes_hi": 2 * fb + wb},
        "per_pair": {"fetch_bytes_raw": sum(v["FETCH_SIZE_KB"] for v in fam.values()) * 1024 / pairs, "write_bytes": sum(v["WRITE_SIZE_KB"] for v in fam.values()) * 1024 / pairs}}

@@ -57,13 +57,11 @@ def test_cli_three_step_chain(tmp_path, orc, synth, compression, fused):
     assert "Part1 Finished!RUNTIME (sec) = " in out.stdout and "TotalRunTime (sec) = " in out.stdout
     rd = lambda name: np.array(Image.open(tmp_path / name))[..., [2, 1, 0, 3]]
     ref = _oracle_chain(orc, top, imgs, 20)
-    # step 1 sees identical inputs: flows are bit-exact, only libm ulps in the blend remain (<= 1 LSB, rare)
-    d1 = np.abs(rd("ProcessResult1.png").astype(np.int32) - ref[0].astype(np.int32))
-    assert d1.max() <= 1 and (d1 > 0).mean() < 2e-3
-    # later steps start from images that differ in those few LSBs; the solver's strict '<' decisions amplify them
-    # (inherent to the algorithm), so the chain is held to the PSNR bar of BASELINE.md section 4
-    assert _psnr(rd("ProcessResult2.png"), ref[1]) >= 50.0
-    assert _psnr(rd("FinalResult.png"), ref[2]) >= 45.0
+    # every step of the chain is byte-identical to the oracle chain: the flows were bit-exact all along, and the blend now
+    # evaluates tanhf / exp with the host libm's roundings (csrc/libm_exact.hpp), so no LSB is left for the next step to amplify
+    for name, r in zip(("ProcessResult1.png", "ProcessResult2.png", "FinalResult.png"), ref):
+        got = rd(name)
+        assert np.array_equal(got, r), "%s: %d bytes differ, PSNR %.1f dB" % (name, int((got != r).sum()), _psnr(got, r))
 
 
 @pytest.mark.gpu
@@ -83,5 +81,4 @@ def test_cli_four_input_mode(tmp_path, orc, synth):
     L = np.clip(cropped[0] + cropped[2], 0, 255).astype(np.uint8); R = np.clip(cropped[1] + cropped[3], 0, 255).astype(np.uint8)
     ref = _oracle_chain(orc, R, [L], 0)[0]
     got = np.array(Image.open(tmp_path / "FinalResult.png"))[..., [2, 1, 0, 3]]
-    d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
-    assert d.max() <= 1 and (d > 0).mean() < 2e-3
+    assert np.array_equal(got, ref), "%d bytes differ" % int((got != ref).sum())

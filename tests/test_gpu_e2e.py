@@ -35,10 +35,8 @@ def test_flow_bidir_and_blend_512(ctx, orc, pf, pair512, alg):
     print("max|dflow| LR %g RL %g" % (dLR, dRL))
     assert dLR <= 1e-2 and dRL <= 1e-2
     assert np.array_equal(fLR, rLR) and np.array_equal(fRL, rRL)
-    psnr = _psnr(out, rout)
-    off = np.abs(out.astype(np.int32) - rout.astype(np.int32))
-    print("blend PSNR %.2f dB, frac>1LSB %g, frac!=0 %g" % (psnr, (off > 1).mean(), (off > 0).mean()))
-    assert psnr >= 50.0 and (off > 1).mean() < 1e-4
+    # blended strip: byte-identical (tanhf / exp with the host libm's roundings on the device, csrc/libm_exact.hpp)
+    assert np.array_equal(out, rout), "%d blended bytes differ (PSNR %.2f dB)" % (int((out != rout).sum()), _psnr(out, rout))
 
 
 def test_blend_only(ctx, orc, pair512):
@@ -47,8 +45,7 @@ def test_blend_only(ctx, orc, pair512):
     fLR = (r.standard_normal((512, 512, 2)) * 3).astype(np.float32); fRL = (r.standard_normal((512, 512, 2)) * 3).astype(np.float32)
     ref = orc.combine_novel_views(L, R, fLR, fRL, blend)
     got = ctx.blend(L, R, fLR, fRL, blend)
-    off = np.abs(got.astype(np.int32) - ref.astype(np.int32))
-    assert off.max() <= 1 and (off > 0).mean() < 1e-3
+    assert np.array_equal(got, ref), "%d blended bytes differ" % int((got != ref).sum())
     # blend == 0 / 1 with zero flow reproduces L / R up to the reference's float->uchar truncation
     # (weights sum to 1-ulp), alpha 255 where both inputs are valid and (0,0,0,0) elsewhere
     z = np.zeros((512, 512, 2), np.float32)
@@ -56,7 +53,7 @@ def test_blend_only(ctx, orc, pair512):
         bl = np.full((512, 512), b, np.float32)
         o = ctx.blend(L, R, z, z, bl)
         ro = orc.combine_novel_views(L, R, z, z, bl)
-        assert np.abs(o.astype(np.int32) - ro.astype(np.int32)).max() <= 1 and (o != ro).mean() < 1e-2  # libm tanhf/exp ulps
+        assert np.array_equal(o, ro)
         m = (L[..., 3] > 0) & (R[..., 3] > 0)
         d = src[m][:, :3].astype(np.int32) - o[m][:, :3].astype(np.int32)
         assert d.min() >= 0 and d.max() <= 1 and (o[m][:, 3] == 255).all() and (o[~m] == 0).all()
@@ -124,8 +121,7 @@ def test_cpp_dropin_headers_one_stitch_step(orc, synth, pf, tmp_path):
     assert np.array_equal(rd("flowLR.f32", np.float32, (rows, cols, 2)), fLR)
     assert np.array_equal(rd("flowRL.f32", np.float32, (rows, cols, 2)), fRL)
     gm = rd("merged.bgra", np.uint8, (rows, cols, 4)); gf = rd("final.bgra", np.uint8, (rows, cols, 4))
-    assert np.abs(gm.astype(np.int32) - merged.astype(np.int32)).max() <= 1 and (gm != merged).mean() < 1e-3
-    assert np.abs(gf.astype(np.int32) - final.astype(np.int32)).max() <= 1 and (gf != final).mean() < 1e-3
+    assert np.array_equal(gm, merged) and np.array_equal(gf, final)
     # unknown algorithm name -> VrCamException -> exit code 1 (PixFlow.hpp:499)
     assert subprocess.call([exe, str(cols), str(rows), str(tmp_path / "L.bgra"), str(tmp_path / "R.bgra"), "nope", str(tmp_path / "x")]) == 1
 
