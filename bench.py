@@ -316,6 +316,7 @@ def main():
                                       "workload": "BASELINE configs[1]: one 2000x4000 strip", "swept_steps_per_direction": cs.last_swept_steps(), "steps": 7, "warmup": 1,
                                       "roofline_path_frac": round(pf.algorithmic_bytes(sc, sr) / tm / 8e12, 6)}
             cs.close()
+            del Ls, Rs, bs, os_
             # ---- BASELINE configs[3]: the full 5+top chain, 9000x4000, pixflow_search_20, host images -> host composite ----
             cc, cr = 9000, 4000
             top, imgs = synth.make_stitch_set(cc, cr, 1234, 5, dev)
@@ -339,25 +340,6 @@ def main():
             del final
             if cx is not ctx:
                 cx.close()
-            # ---- throughput mode (never `value`): 12 independent strips, 6 in flight on this GPU, through the C ABI's batch entry ----
-            nb, infl = 12, 6
-            pairs_b = [synth.make_pair(sc, sr, 5000 + i, dev) for i in range(nb)]
-            outs_b = [torch.empty_like(os_) for _ in range(nb)]
-            torch.cuda.synchronize()
-            ct = pf.Context(local_rank, sc, sr)          # its own context: the lanes it creates go away with it
-            call_b = lambda: ct.novel_view_batch_dev([p[0].data_ptr() for p in pairs_b], [p[1].data_ptr() for p in pairs_b], sc, sr, max_pct,
-                                                      [p[2].data_ptr() for p in pairs_b], [o.data_ptr() for o in outs_b], None, None, in_flight=infl)
-            call_b()
-            tbs = []
-            for _ in range(3):
-                t1 = time.perf_counter(); call_b(); tbs.append(time.perf_counter() - t1)
-            tb = statistics.median(tbs)
-            res["throughput_mode"] = {"value": round(nb * sc * sr / 1e6 / tb, 3), "unit": "Mpix/s", "pairs": nb, "in_flight": infl, "entry": "pf_novel_view_batch_dev",
-                                      "workload": "12 independent 2000x4000 strips", "runs": 3, "warmup": 1, "statistic": "median",
-                                      "note": "several independent pairs side by side on one GPU; an extra figure, not the per-GPU workload `value` is quoted on"}
-            del pairs_b, outs_b, Ls, Rs, bs, os_
-            ct.close()
-            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             # A 9000x4000 pair costs the oracle ~2 x 100 s; the bounded sample is a 2000-column sub-strip of the SAME pair (the
             # whole path on it: 2 flow directions + blend), timed on 1 and on 2 host threads, and compared with the GPU path
@@ -399,6 +381,31 @@ def main():
                         "fixture": "tests/golden/dense_%dx%d.npz (SHA-256 of the oracle's outputs for this very pair, computed in the build container)" % (cols, rows)}
                 else:
                     res["parity_vs_cpu"]["full_pair_vs_oracle_fixture"] = "synthetic pair differs from the fixture's even when generated on the host: not compared"
+        if world == 1 and not args.no_extras and args.concurrent <= 1:
+            # the main context's five streams give way first: a lane drives three streams and the runtime maps streams to
+            # GPU_MAX_HW_QUEUES hardware queues round-robin -- more live streams than queues and two busy ones share a queue
+            ctx.close()
+            sc, sr = 2000, 4000
+            os_ = torch.empty((sr, sc, 4), dtype=torch.uint8, device=dev)
+            # ---- throughput mode (never `value`): 12 independent strips, 6 in flight on this GPU, through the C ABI's batch entry ----
+            nb, infl = 12, 6
+            pairs_b = [synth.make_pair(sc, sr, 5000 + i, dev) for i in range(nb)]
+            outs_b = [torch.empty_like(os_) for _ in range(nb)]
+            torch.cuda.synchronize()
+            ct = pf.Context(local_rank, sc, sr)          # its own context: the lanes it creates go away with it
+            call_b = lambda: ct.novel_view_batch_dev([p[0].data_ptr() for p in pairs_b], [p[1].data_ptr() for p in pairs_b], sc, sr, max_pct,
+                                                      [p[2].data_ptr() for p in pairs_b], [o.data_ptr() for o in outs_b], None, None, in_flight=infl)
+            call_b()
+            tbs = []
+            for _ in range(3):
+                t1 = time.perf_counter(); call_b(); tbs.append(time.perf_counter() - t1)
+            tb = statistics.median(tbs)
+            res["throughput_mode"] = {"value": round(nb * sc * sr / 1e6 / tb, 3), "unit": "Mpix/s", "pairs": nb, "in_flight": infl, "entry": "pf_novel_view_batch_dev",
+                                      "workload": "12 independent 2000x4000 strips", "runs": 3, "warmup": 1, "statistic": "median",
+                                      "note": "several independent pairs side by side on one GPU; an extra figure, not the per-GPU workload `value` is quoted on"}
+            del pairs_b, outs_b, os_
+            ct.close()
+            torch.cuda.empty_cache()
         line = json.dumps(res)
     if pfd:
         pfd.close()

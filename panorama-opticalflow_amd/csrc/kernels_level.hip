@@ -532,6 +532,8 @@ void launch_gauss15_mix(hipStream_t st, float* flow, float* tmp, const float* a0
   hipLaunchKernelGGL((k_gauss15_fused<true, false, false>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float2*>(flow), reinterpret_cast<float2*>(out), w, h, g15, a0, a1, ntx, ntiles, UpsSrc{});
 }
 
+// Direct form: every thread loads the 6 x 5 neighbourhood of its output pair straight from memory (the 15x re-reads are served by
+// L1 / L2).  Lowest latency per launch: used for the levels where a launch is latency-bound (below kMedTiledMinPx pixels).
 __global__ __launch_bounds__(256) void k_median5(const float2* __restrict__ src, float2* __restrict__ dst, int w, int h) {
   const int xp = (blockIdx.x * blockDim.x + threadIdx.x) * 2, y = blockIdx.y;   // outputs xp and xp + 1
   if (xp >= w) return;
@@ -564,9 +566,84 @@ __global__ __launch_bounds__(256) void k_median5(const float2* __restrict__ src,
   dst[size_t(y) * w + xp] = make_float2(m[0][0], m[0][1]);
   if (xp + 1 < w) dst[size_t(y) * w + xp + 1] = make_float2(m[1][0], m[1][1]);
 }
+// A block of 1024 threads owns a 128 x 16 output tile.  The tile + its 2-pixel halo (replicate border) is staged in LDS once -- 1.29
+// global loads per output instead of 15 through L1 -- and every thread then selects 2 horizontally adjacent outputs of one row
+// from LDS (16-byte reads: the six columns of an output pair are three float4).  Same selection network (d_mid6of20 / d_median11).
+// Measured per launch beside the other direction's kernels (tests/micro/kern_by_grid.sh): 4950x2000 123 vs 139 us, 4455x1800 112 vs
+// 124, equal at ~2.3 Mpix, slower below (a block's single HBM round trip + barrier in front of the network): levels >= kMedTiledMinPx.
+constexpr int kMedX = 128, kMedY = 16, kMedSX = kMedX + 4, kMedSY = kMedY + 4, kMedT = 64 * kMedY;
+__global__ __launch_bounds__(kMedT) void k_median5_tiled(const float2* __restrict__ src, float2* __restrict__ dst, int w, int h) {
+  __shared__ __attribute__((aligned(16))) float2 tile[kMedSY][kMedSX];
+  const int x0 = blockIdx.x * kMedX, y0 = blockIdx.y * kMedY;
+  {   // all of a thread's loads are issued before the first LDS store: one HBM round trip per block
+    constexpr int kN = (kMedSY * kMedSX + kMedT - 1) / kMedT;
+    float2 v[kN];
+#pragma unroll
+    for (int u = 0; u < kN; ++u) {
+      const int i = threadIdx.x + u * kMedT, ty = i / kMedSX, tx = i - ty * kMedSX;
+      v[u] = i < kMedSY * kMedSX ? src[size_t(d_replicate(y0 + ty - 2, h)) * w + d_replicate(x0 + tx - 2, w)] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < kN; ++u) {
+      const int i = threadIdx.x + u * kMedT;
+      if (i < kMedSY * kMedSX) (&tile[0][0])[i] = v[u];
+    }
+  }
+  __syncthreads();
+  const int lx = (threadIdx.x & 63) * 2, xp = x0 + lx;   // outputs xp and xp + 1
+  const int ly = threadIdx.x >> 6, y = y0 + ly;
+  if (xp >= w || y >= h) return;
+  float2 col[6][5];   // columns xp-2 .. xp+3, rows y-2 .. y+2
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const float4* rp = reinterpret_cast<const float4*>(&tile[ly + j][lx]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const float4 v = rp[i]; col[2 * i][j] = make_float2(v.x, v.y); col[2 * i + 1][j] = make_float2(v.z, v.w); }
+  }
+  float m[2][2];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {
+    float s[20];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) s[i * 5 + j] = ch ? col[i + 1][j].y : col[i + 1][j].x;
+    d_mid6of20(s);
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      float t[11];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) t[k] = s[k + 1];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) t[6 + j] = ch ? col[o ? 5 : 0][j].y : col[o ? 5 : 0][j].x;
+      m[o][ch] = d_median11(t);
+    }
+  }
+  if (xp + 1 < w && ((w & 1) == 0)) *reinterpret_cast<float4*>(&dst[size_t(y) * w + xp]) = make_float4(m[0][0], m[0][1], m[1][0], m[1][1]);
+  else {
+    dst[size_t(y) * w + xp] = make_float2(m[0][0], m[0][1]);
+    if (xp + 1 < w) dst[size_t(y) * w + xp + 1] = make_float2(m[1][0], m[1][1]);
+  }
+}
+constexpr long kMedTiledMinPx = 3000000;
 void launch_median5(hipStream_t st, const float* src, float* dst, int w, int h) {
-  dim3 grid(((w + 1) / 2 + 255) / 256, h);
-  hipLaunchKernelGGL(k_median5, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h);
+  if ((long)w * h >= kMedTiledMinPx) {
+    dim3 grid((w + kMedX - 1) / kMedX, (h + kMedY - 1) / kMedY);
+    hipLaunchKernelGGL(k_median5_tiled, grid, dim3(kMedT), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h);
+  } else {
+    dim3 grid(((w + 1) / 2 + 255) / 256, h);
+    hipLaunchKernelGGL(k_median5, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h);
+  }
+}
+// tests: force one of the two forms whatever the size
+void launch_median5_form(hipStream_t st, const float* src, float* dst, int w, int h, bool tiled) {
+  if (tiled) {
+    dim3 grid((w + kMedX - 1) / kMedX, (h + kMedY - 1) / kMedY);
+    hipLaunchKernelGGL(k_median5_tiled, grid, dim3(kMedT), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h);
+  } else {
+    dim3 grid(((w + 1) / 2 + 255) / 256, h);
+    hipLaunchKernelGGL(k_median5, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h);
+  }
 }
 
 // medianBlur(5) + lowAlphaFlowDiffusion in one launch: `flow` is the backward sweep's output, `out` a different plane

@@ -227,7 +227,8 @@ void launch_countblend(hipStream_t st, const uint8_t* map, int cols, int rows, f
 // image.  The sliding sums are order-dependent along a row/column, so one lane walks each row (row
 // pass) and each column (column pass) -- exactly the O(1)/pixel schedule one wants anyway.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_box_rows(const float* __restrict__ src, double* __restrict__ rs, int cols, int rows, int k) {
+// any kernel width, one lane per row straight from memory (only used beyond kBoxKMax)
+__global__ __launch_bounds__(64) void k_box_rows_wide(const float* __restrict__ src, double* __restrict__ rs, int cols, int rows, int k) {
   const int y = blockIdx.x * blockDim.x + threadIdx.x;
   if (y >= rows) return;
   const int a = k / 2;
@@ -240,6 +241,62 @@ __global__ __launch_bounds__(64) void k_box_rows(const float* __restrict__ src, 
     rs[size_t(y) * cols + x] = s;
   }
 }
+// Row pass.  A block owns 64 rows and walks them in chunks of 64 columns: the chunk (+ the k-1 taps beside it, reflected) is staged
+// in LDS with coalesced loads, lane y then advances ITS row's sliding sum through the chunk in the reference's order -- the
+// dependent chain is one fp64 add per pixel, everything else comes from LDS -- and the 64 x 64 sums leave through LDS as coalesced
+// 512-byte rows.  (Before: every lane read its own row straight from HBM, 64 cache lines per load: ~150 GB/s.)
+constexpr int kBoxR = 64, kBoxC = 64, kBoxKMax = 32;   // 58 KB of LDS (24.8 in + 33.3 out)
+__global__ __launch_bounds__(256) void k_box_rows(const float* __restrict__ src, double* __restrict__ rs, int cols, int rows, int k) {
+  __shared__ float tin[kBoxR][kBoxC + kBoxKMax + 1];   // odd row stride: the 64 lanes (rows) of the walking wave hit different banks
+  __shared__ double tout[kBoxR][kBoxC + 1];
+  const int y0 = blockIdx.x * kBoxR, tid = threadIdx.x;
+  const int a = k / 2;
+  const int wIn = kBoxC + k;   // columns c0 - a - 1 .. c0 + 63 - a - 1 + k: the subtracted tap of the chunk's first pixel .. the added tap of its last
+  double s = 0;
+  for (int c0 = 0; c0 < cols; c0 += kBoxC) {
+    // stage: all four waves, consecutive threads = consecutive columns of one row, 8 independent loads in flight per thread
+    const int total = kBoxR * wIn;
+    for (int base = 0; base < total; base += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * 256 + tid;
+        const int r = idx / wIn, i = idx - r * wIn;
+        const int y = y0 + r < rows ? y0 + r : rows - 1;
+        v[u] = idx < total ? src[size_t(y) * cols + d_reflect101(c0 - a - 1 + i, cols)] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * 256 + tid;
+        const int r = idx / wIn, i = idx - r * wIn;
+        if (idx < total) tin[r][i] = v[u];
+      }
+    }
+    __syncthreads();
+    const int n = cols - c0 < kBoxC ? cols - c0 : kBoxC;
+    if (tid < kBoxR) {   // one wave walks the 64 rows: lane = row, the reference's order along x
+      const float* t = tin[tid];
+      int x = 0;
+      if (c0 == 0) {   // RowSum: the first k taps summed left to right, then the sliding update
+        for (int i = 0; i < k; ++i) s += (double)t[1 + i];
+        tout[tid][0] = s;
+        x = 1;
+      }
+      for (; x < n; ++x) {
+        s += (double)t[x + k] - (double)t[x];
+        tout[tid][x] = s;
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < kBoxR * kBoxC; idx += 256) {
+      const int r = idx / kBoxC, x = idx - r * kBoxC;
+      if (x < n && y0 + r < rows) rs[size_t(y0 + r) * cols + c0 + x] = tout[r][x];
+    }
+    // the next chunk's staging writes tin only (read by the walking wave before the barrier above); tout is rewritten after the next barrier
+  }
+}
+// Column pass: lanes are adjacent columns (coalesced already); the two taps of the next 8 rows are loaded before the 8 dependent
+// updates, so that a wave has 16 loads in flight instead of one round trip per row.
 __global__ __launch_bounds__(64) void k_box_cols(const double* __restrict__ rs, float* __restrict__ dst, int cols, int rows, int k) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= cols) return;
@@ -247,56 +304,141 @@ __global__ __launch_bounds__(64) void k_box_cols(const double* __restrict__ rs, 
   const double scale = 1. / ((double)k * k);
   double sum = 0;
   for (int j = 0; j < k - 1; ++j) sum += rs[size_t(d_reflect101(-a + j, rows)) * cols + x];
-  for (int y = 0; y < rows; ++y) {
-    const double s0 = sum + rs[size_t(d_reflect101(y - a + k - 1, rows)) * cols + x];
-    dst[size_t(y) * cols + x] = (float)(s0 * scale);
-    sum = s0 - rs[size_t(d_reflect101(y - a, rows)) * cols + x];
+  constexpr int U = 8;
+  for (int y0 = 0; y0 < rows; y0 += U) {
+    double add[U], sub[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int y = y0 + u < rows ? y0 + u : rows - 1;
+      add[u] = rs[size_t(d_reflect101(y - a + k - 1, rows)) * cols + x];
+      sub[u] = rs[size_t(d_reflect101(y - a, rows)) * cols + x];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (y0 + u < rows) {
+        const double s0 = sum + add[u];
+        dst[size_t(y0 + u) * cols + x] = (float)(s0 * scale);
+        sum = s0 - sub[u];
+      }
+    }
   }
 }
 void launch_box_blur(hipStream_t st, const float* src, float* dst, double* rowsum_tmp, int cols, int rows, int k) {
-  hipLaunchKernelGGL(k_box_rows, dim3((rows + 63) / 64), dim3(64), 0, st, src, rowsum_tmp, cols, rows, k);
+  if (k <= kBoxKMax) hipLaunchKernelGGL(k_box_rows, dim3((rows + kBoxR - 1) / kBoxR), dim3(256), 0, st, src, rowsum_tmp, cols, rows, k);
+  else hipLaunchKernelGGL(k_box_rows_wide, dim3((rows + 63) / 64), dim3(64), 0, st, src, rowsum_tmp, cols, rows, k);   // canvases beyond 13000 rows
   hipLaunchKernelGGL(k_box_cols, dim3((cols + 63) / 64), dim3(64), 0, st, rowsum_tmp, dst, cols, rows, k);
 }
 
 // Conditional per-tile box blur, in place, raster order (StitchTool.cpp:134-141).  A tile reads the
 // CURRENT image in a (step+k-1)^2 window, so it depends on raster-earlier tiles within d =
 // ceil(max(a, k-1-a)/step) tiles and must precede raster-later ones in that range.  Tiles with equal
-// t = tx + (d+1)*ty are mutually independent: one launch per t (a wavefront over tiles) is exact.
-__global__ __launch_bounds__(64) void k_tile_blur(float* __restrict__ img, const float* __restrict__ mergedDis, int cols, int rows, int step, int k,
-                                                  int t, int dskew, int ntx, int nty) {
-  // tile on this diagonal: ty = blockIdx.x + ty0, tx = t - dskew*ty
-  const int ty_min = (t - (ntx - 1) + dskew - 1) / dskew > 0 ? (t - (ntx - 1) + dskew - 1) / dskew : 0;
-  const int ty = ty_min + blockIdx.x;
-  if (ty >= nty) return;
-  const int tx = t - dskew * ty;
-  if (tx < 0 || tx >= ntx) return;
-  const int x0 = tx * step, y0 = ty * step;
-  if (!(mergedDis[size_t(y0) * cols + x0] > step)) return;
-  extern __shared__ double sm[];  // row sums: (step+k-1) x step
-  const int a = k / 2, nr = step + k - 1;
-  for (int j = threadIdx.x; j < nr; j += blockDim.x) {
-    const float* r = img + size_t(d_reflect101(y0 - a + j, rows)) * cols;
-    double s = 0;
-    for (int i = 0; i < k; ++i) s += (double)r[d_reflect101(x0 - a + i, cols)];
-    sm[j * step] = s;
-    for (int x = 1; x < step; ++x) {
-      s += (double)r[d_reflect101(x0 - a + x - 1 + k, cols)] - (double)r[d_reflect101(x0 - a + x - 1, cols)];
-      sm[j * step + x] = s;
+// t = tx + (d+1)*ty are mutually independent: a wavefront over tiles, diagonal by diagonal, is exact.
+//
+// ONE persistent launch (round 2: one launch per diagonal, ~850 of them per 9000x4000 canvas, ~9 us each).  Only tiles well
+// inside the overlap are blurred (MergedDis > step), typically a few percent; a first pass counts the active tiles of every
+// diagonal, and the blocks then walk the diagonals together, skipping the empty ones WITHOUT synchronising and meeting at a
+// grid barrier (agent-scope release / acquire, guide G16; every spin is bounded by wall-clock time) after each non-empty one.
+// A tile is done by one 256-thread block: its window is staged in LDS with coalesced independent loads, then RowSum /
+// ColumnSum exactly as blur() computes them (sliding fp64 sums, one lane per row, then one lane per column).
+struct TileBlurWork { int bar; int err; int cnt[1]; };   // cnt[tmax + 1]; the whole struct is zeroed before every launch
+__device__ __forceinline__ bool d_grid_barrier(int* bar, int* err, int target, long long deadline) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own stores first (G16)
+  __syncthreads();
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int good = 1;
+    for (unsigned spins = 0; __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
+      __builtin_amdgcn_s_sleep(8);
+      if ((spins & 255) == 255 && ((long long)wall_clock64() > deadline || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); good = 0; break;
+      }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    ok = good;
   }
   __syncthreads();
+  return ok != 0;
+}
+__global__ __launch_bounds__(256) void k_tile_blur(float* __restrict__ img, const float* __restrict__ mergedDis, int cols, int rows, int step, int k,
+                                                   int dskew, int ntx, int nty, TileBlurWork* __restrict__ wk, long long budget_ticks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  const int a = k / 2, nr = step + k - 1;
+  double* sm = reinterpret_cast<double*>(smraw);                 // row sums: nr x step
+  float* win = reinterpret_cast<float*>(sm + size_t(nr) * step);  // the tile's input window: nr x nr
+  const int tid = threadIdx.x, nblk = gridDim.x;
+  const long long deadline = (long long)wall_clock64() + budget_ticks;
+  const int tmax = (ntx - 1) + dskew * (nty - 1);
+  auto active = [&](int tx, int ty) { return mergedDis[size_t(ty) * step * cols + size_t(tx) * step] > step; };
+  // pass 0: active tiles per diagonal
+  for (int i = blockIdx.x * 256 + tid; i < ntx * nty; i += nblk * 256) {
+    const int ty = i / ntx, tx = i - ty * ntx;
+    if (active(tx, ty)) __hip_atomic_fetch_add(&wk->cnt[tx + dskew * ty], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  int phase = 1;
+  if (!d_grid_barrier(&wk->bar, &wk->err, phase * nblk, deadline)) return;
   const double scale = 1. / ((double)k * k);
-  for (int x = threadIdx.x; x < step; x += blockDim.x) {
-    double sum = 0;
-    for (int j = 0; j < k - 1; ++j) sum += sm[j * step + x];
-    for (int y = 0; y < step; ++y) {
-      const double s0 = sum + sm[(y + k - 1) * step + x];
-      img[size_t(y0 + y) * cols + x0 + x] = (float)(s0 * scale);
-      sum = s0 - sm[y * step + x];
+  for (int t = 0; t <= tmax; ++t) {
+    if (__hip_atomic_load(&wk->cnt[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) continue;   // the same answer in every block: no barrier needed
+    const int lo = t - (ntx - 1);
+    const int ty_min = lo > 0 ? (lo + dskew - 1) / dskew : 0;
+    const int ty_max = t / dskew < nty - 1 ? t / dskew : nty - 1;
+    for (int ty = ty_min + blockIdx.x; ty <= ty_max; ty += nblk) {
+      const int tx = t - dskew * ty;
+      if (tx < 0 || tx >= ntx || !active(tx, ty)) continue;   // block-uniform
+      const int x0 = tx * step, y0 = ty * step;
+      __syncthreads();   // the previous tile's LDS is no longer read
+      for (int base = 0; base < nr * nr; base += 256 * 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = base + u * 256 + tid, j = idx / nr, i = idx - j * nr;
+          v[u] = idx < nr * nr ? img[size_t(d_reflect101(y0 - a + j, rows)) * cols + d_reflect101(x0 - a + i, cols)] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int idx = base + u * 256 + tid; if (idx < nr * nr) win[idx] = v[u]; }
+      }
+      __syncthreads();
+      for (int j = tid; j < nr; j += 256) {
+        const float* r = win + j * nr;
+        double s = 0;
+        for (int i = 0; i < k; ++i) s += (double)r[i];
+        sm[j * step] = s;
+        for (int x = 1; x < step; ++x) {
+          s += (double)r[x - 1 + k] - (double)r[x - 1];
+          sm[j * step + x] = s;
+        }
+      }
+      __syncthreads();
+      for (int x = tid; x < step; x += 256) {
+        double sum = 0;
+        for (int j = 0; j < k - 1; ++j) sum += sm[j * step + x];
+        for (int y = 0; y < step; ++y) {
+          const double s0 = sum + sm[(y + k - 1) * step + x];
+          img[size_t(y0 + y) * cols + x0 + x] = (float)(s0 * scale);
+          sum = s0 - sm[y * step + x];
+        }
+      }
     }
+    ++phase;
+    if (!d_grid_barrier(&wk->bar, &wk->err, phase * nblk, deadline)) return;
   }
 }
-void launch_tile_blur(hipStream_t st, float* blend, const float* mergedDis, int cols, int rows, int step, int k) {
+size_t tile_blur_work_bytes(int cols, int rows, int step, int k) {
+  if (step < 1 || k < 1) return 0;
+  int nty = 0, ntx = 0;
+  for (int y = 0; y + step < rows; y += step) ++nty;
+  for (int x = 0; x + step < cols; x += step) ++ntx;
+  if (nty <= 0 || ntx <= 0) return 0;
+  const int a = k / 2, reach = a > (k - 1 - a) ? a : (k - 1 - a);
+  const int dskew = (reach + step - 1) / step + 1;
+  return sizeof(TileBlurWork) + sizeof(int) * size_t((ntx - 1) + dskew * (nty - 1) + 1);
+}
+size_t tile_blur_lds_bytes(int step, int k) { const size_t nr = size_t(step) + k - 1; return nr * step * sizeof(double) + nr * nr * sizeof(float); }
+// work: tile_blur_work_bytes() of device memory (zeroed here); work[1] != 0 afterwards = a grid barrier timed out (never expected)
+void launch_tile_blur(hipStream_t st, float* blend, const float* mergedDis, int cols, int rows, int step, int k, void* work) {
   if (step < 1 || k < 1) return;
   // tiles: y = 0, step, ... while y+step < rows  (StitchTool.cpp:134-135)
   int nty = 0, ntx = 0;
@@ -305,16 +447,20 @@ void launch_tile_blur(hipStream_t st, float* blend, const float* mergedDis, int 
   if (nty <= 0 || ntx <= 0) return;
   const int a = k / 2, reach = a > (k - 1 - a) ? a : (k - 1 - a);
   const int d = (reach + step - 1) / step, dskew = d + 1;
-  const size_t shmem = size_t(step + k - 1) * step * sizeof(double);
-  // canvases beyond ~13000 rows need more than the default 64 KB of dynamic LDS (gfx950 has 160 KB per CU)
+  const size_t shmem = tile_blur_lds_bytes(step, k);
+  // large canvases need more than the default 64 KB of dynamic LDS (gfx950 has 160 KB per CU)
   if (shmem > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_blur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  const int tmax = (ntx - 1) + dskew * (nty - 1);
-  for (int t = 0; t <= tmax; ++t) {
-    const int ty_min = (t - (ntx - 1) + dskew - 1) / dskew > 0 ? (t - (ntx - 1) + dskew - 1) / dskew : 0;
-    const int ty_max = t / dskew < nty - 1 ? t / dskew : nty - 1;
-    if (ty_max < ty_min) continue;
-    hipLaunchKernelGGL(k_tile_blur, dim3(ty_max - ty_min + 1), dim3(64), shmem, st, blend, mergedDis, cols, rows, step, k, t, dskew, ntx, nty);
-  }
+  hipMemsetAsync(work, 0, tile_blur_work_bytes(cols, rows, step, k), st);
+  // every block must be resident (grid barrier): one block per CU at most, and no more than the longest diagonal has tiles
+  static const int ncu = [] { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 64; return p.multiProcessorCount; }();
+  // Few blocks: a diagonal rarely holds more than a dozen active tiles, a barrier among 32 blocks is cheaper than among 128, and
+  // in pf_stitch_step this launch runs BESIDE the two flow solves, whose latency-bound sweeps should not share their CUs and
+  // the L2 channel of the barrier word with a crowd of pollers.
+  int blocks = nty < 32 ? nty : 32;
+  if (blocks > ncu / 2) blocks = ncu / 2;
+  if (blocks < 1) blocks = 1;
+  const long long budget = 200000000ll * 5;   // 10 s of 100 MHz ticks: the launch may queue behind other work of the process
+  hipLaunchKernelGGL(k_tile_blur, dim3(blocks), dim3(256), shmem, st, blend, mergedDis, cols, rows, step, k, dskew, ntx, nty, static_cast<TileBlurWork*>(work), budget);
 }
 
 // ------------------------------------------------------------------------------------------------

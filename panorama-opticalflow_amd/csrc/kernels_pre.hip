@@ -238,6 +238,16 @@ void launch_checksum64(hipStream_t st, const void* p, size_t bytes, unsigned lon
                      static_cast<const uint8_t*>(p) + nwords * 8, int(bytes - nwords * 8), acc);
 }
 
+__global__ __launch_bounds__(256) void k_count_diff_u32(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, size_t n, int* __restrict__ count) {
+  int d = 0;
+  for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256) d += a[i] != b[i];
+  if (d) atomicAdd(count, d);
+}
+void launch_count_diff_u32(hipStream_t st, const uint32_t* a, const uint32_t* b, size_t n, int* count) {
+  size_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(k_count_diff_u32, dim3((unsigned)blocks), dim3(256), 0, st, a, b, n, count);
+}
+
 __global__ void k_collect_status(const int* __restrict__ ctrl, int nwords, int* __restrict__ status, int bit) {
   int bad = 0;
   for (int i = threadIdx.x; i < nwords; i += blockDim.x) if ((i & 1) && ctrl[i]) bad = 1;

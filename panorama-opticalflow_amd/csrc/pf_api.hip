@@ -520,7 +520,7 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
 // written by k_collect_status at the end of each direction's stream: no copy, no further sync)
 int check_sweeps(pf_ctx* c) {
   const int st = __atomic_load_n(c->h_status, __ATOMIC_ACQUIRE);
-  if (st) { *c->h_status = 0; return fail(c, PF_ERR_TIMEOUT, "sweep band timed out (direction mask %d)", st); }
+  if (st) { *c->h_status = 0; return fail(c, PF_ERR_TIMEOUT, "an in-kernel wait timed out (bits 0/1: sweep band of direction 0/1, bit 2: blend-ramp grid barrier; mask %d)", st); }
   return 0;
 }
 
@@ -934,9 +934,12 @@ static int blend_smooth_dev(pf_ctx* c, float* d_blend, const float* d_md, int co
   const int step = cols <= rows ? cols / 200 : rows / 200, k1 = rows / 130, k2 = rows / 400;
   if (!sm) sm = c->s_main;
   if (step > 0 && k1 > 0) {
-    // the tile kernel keeps (step+k1-1) x step row sums in LDS: 160 KB per CU bound the canvas at ~17900 rows
-    if (size_t(step + k1 - 1) * step * sizeof(double) > 160 * 1024) return fail(c, PF_ERR_ARG, "canvas %dx%d too large for the blend-ramp tile smoothing (LDS)", cols, rows);
-    PROF(c, sm, "tile_blur"); launch_tile_blur(sm, d_blend, d_md, cols, rows, step, k1);
+    // the tile kernel keeps a (step+k1-1)^2 window and (step+k1-1) x step row sums in LDS: 160 KB per CU bound the canvas at ~15000 rows
+    if (tile_blur_lds_bytes(step, k1) > 160 * 1024) return fail(c, PF_ERR_ARG, "canvas %dx%d too large for the blend-ramp tile smoothing (LDS)", cols, rows);
+    void* work = ensure(c, "st_tile_work", tile_blur_work_bytes(cols, rows, step, k1) + 256);
+    if (!work) return PF_ERR_NOMEM;
+    { PROF(c, sm, "tile_blur"); launch_tile_blur(sm, d_blend, d_md, cols, rows, step, k1, work); }
+    launch_collect_status(sm, static_cast<const int*>(work), 2, c->d_status, 4);   // word 1 = a grid barrier of the tile smoothing gave up
   }
   if (k2 > 0) {
     double* rs = (double*)ensure(c, "st_rowsum", size_t(cols) * rows * 8);
@@ -973,7 +976,8 @@ int pf_stitch_prepare(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, i
   if (blend_out) if (int e = down2d(c, blend_out, bstep, db, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
   if (merged_dis) if (int e = down2d(c, merged_dis, size_t(cols) * 4, dmd, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
   HIPCHK(c, hipGetLastError());
-  return finish(c);
+  if (int e = finish(c)) return e;
+  return check_sweeps(c);
 }
 
 // GenerateBlend's per-pixel part alone (StitchTool.cpp:113-125 with countblend :148-191): the ramp BEFORE the tile / global
@@ -1154,8 +1158,18 @@ int pf_stage_median5(pf_ctx* c, const float* flow, int w, int h, float* out) {
   STAGE_BEGIN(c);
   float* s = (float*)stage_up(c, "sg_a", flow, size_t(w) * h * 8); float* d = (float*)ensure(c, "sg_b", size_t(w) * h * 8);
   if (!s || !d) return PF_ERR_NOMEM;
-  launch_median5(sm, s, d, w, h);
-  return stage_down(c, out, d, size_t(w) * h * 8);
+  // the stage entry runs BOTH forms of the kernel (direct and LDS-tiled; the solver picks by level size) and requires identical bits
+  float* d2 = (float*)ensure(c, "sg_c", size_t(w) * h * 8); int* neq = (int*)ensure(c, "sg_d", 256);
+  if (!d2 || !neq) return PF_ERR_NOMEM;
+  launch_median5_form(sm, s, d, w, h, false);
+  launch_median5_form(sm, s, d2, w, h, true);
+  HIPCHK(c, hipMemsetAsync(neq, 0, 4, sm));
+  launch_count_diff_u32(sm, reinterpret_cast<const uint32_t*>(d), reinterpret_cast<const uint32_t*>(d2), size_t(w) * h * 2, neq);
+  int hneq = 0;
+  HIPCHK(c, hipMemcpyAsync(&hneq, neq, 4, hipMemcpyDeviceToHost, sm));
+  if (int e = stage_down(c, out, d, size_t(w) * h * 8)) return e;
+  if (hneq) return fail(c, PF_ERR_DEVICE, "median5: the direct and the LDS-tiled kernel disagree in %d words", hneq);
+  return 0;
 }
 int pf_stage_sweep(pf_ctx* c, const float* g0, const float* g1, const float* blurred, const float* a0, const float* a1, float* flow, int w, int h, int forward) {
   STAGE_BEGIN(c);
@@ -1271,7 +1285,8 @@ int pf_stage_blend_smooth(pf_ctx* c, float* blend, const float* md, int cols, in
   float* db = (float*)stage_up(c, "st_blend", blend, n * 4); float* dmd = (float*)stage_up(c, "st_md", md, n * 4);
   if (!db || !dmd) return PF_ERR_NOMEM;
   if (int e = blend_smooth_dev(c, db, dmd, cols, rows)) return e;
-  return stage_down(c, blend, db, n * 4);
+  if (int e = stage_down(c, blend, db, n * 4)) return e;
+  return check_sweeps(c);
 }
 
 // ---- profiling ----

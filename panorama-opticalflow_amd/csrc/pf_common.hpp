@@ -103,7 +103,8 @@ void launch_median_gauss15_mix(hipStream_t st, const float* flow, const float* a
 void launch_gauss15_upsample(hipStream_t st, const float* coarse, int sw, int sh, float mul, float* up, float* dst, int w, int h, const Gauss& g15);
 void launch_gauss15_mix(hipStream_t st, float* flow, float* tmp, const float* a0, const float* a1, int w, int h, const Gauss& g15,
                         float* out);
-void launch_median5(hipStream_t st, const float* src, float* dst, int w, int h);
+void launch_median5(hipStream_t st, const float* src, float* dst, int w, int h);   // direct form below 3 Mpix, LDS-tiled form above
+void launch_median5_form(hipStream_t st, const float* src, float* dst, int w, int h, bool tiled);   // a given form at any size (tests)
 void launch_upsample_cubic(hipStream_t st, const float* src, int sw, int sh, float* dst, int dw, int dh, float mul);
 void launch_final_flow(hipStream_t st, const float* flow0, int sw, int sh, int pad_cols, int rows, int pad, float mul, const Gauss& g3,
                        float* out);
@@ -145,11 +146,14 @@ void launch_blend(hipStream_t st, const uint8_t* L, const uint8_t* R, const floa
 void launch_match_images(hipStream_t st, const uint8_t* L, const uint8_t* R, int cols, int rows, uint8_t* map, uint8_t* ovL, uint8_t* ovR);
 void launch_countblend(hipStream_t st, const uint8_t* map, int cols, int rows, float* blend, float* mergedDis);
 void launch_box_blur(hipStream_t st, const float* src, float* dst, double* rowsum_tmp, int cols, int rows, int k);
-void launch_tile_blur(hipStream_t st, float* blend, const float* mergedDis, int cols, int rows, int step, int k);
+size_t tile_blur_work_bytes(int cols, int rows, int step, int k);   // device scratch of launch_tile_blur (diagonal counts + barrier word)
+size_t tile_blur_lds_bytes(int step, int k);
+void launch_tile_blur(hipStream_t st, float* blend, const float* mergedDis, int cols, int rows, int step, int k, void* work);
 void launch_gather(hipStream_t st, const uint8_t* L, const uint8_t* R, const uint8_t* merged, const uint8_t* map, int cols, int rows,
                    uint8_t* out);
 void launch_fill_u64(hipStream_t st, unsigned long long* p, size_t n, unsigned long long v);
 void launch_checksum64(hipStream_t st, const void* p, size_t bytes, unsigned long long* acc /* zeroed by the caller */);
+void launch_count_diff_u32(hipStream_t st, const uint32_t* a, const uint32_t* b, size_t n, int* count /* zeroed by the caller */);
 void launch_collect_status(hipStream_t st, const int* ctrl, int nwords, int* status_mapped, int bit);
 
 }  // namespace pf

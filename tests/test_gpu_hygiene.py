@@ -131,7 +131,7 @@ def test_stitch_prefetch_is_one_shot_and_result_neutral(pf, synth):
 def test_device_checksum(pf):
     import torch
     c = pf.Context(0)
-    a = torch.randint(0, 256, (1 << 20) + 13, dtype=torch.uint8, device="cuda")
+    a = torch.randint(0, 256, ((1 << 20) + 13,), dtype=torch.uint8, device="cuda")
     b = a.clone()
     torch.cuda.synchronize()
     n = a.numel()
