@@ -60,6 +60,8 @@ typedef struct pf_config {
   int pyramid_chaining;     /* 1: small pyramid levels are built two or three per launch, 0: one launch per level (1) */
   int sweep_window;         /* 1: a sweep covers the bounding box of the gated pixels only, 0: the whole level (1) */
   int sparse_sweep;         /* -1: pick the sweep variant that skips ungated anti-diagonals from the gate density, 0 / 1: force (-1) */
+  int batch_pairs;          /* throughput mode (pf_novel_view_batch_dev): pairs that go through ONE set of launches (1..8; in_flight =
+                               lanes x batch_pairs).  -1: in_flight itself up to 8 (one lane), half of it (two lanes) beyond */
   /* Cross-check implementations -- only in libpanoflow_exp.so (the -DPF_EXPERIMENTS build used by the test-suite);
    * libpanoflow.so rejects anything but the defaults with PF_ERR_ARG. */
   int sweep_impl;           /* 2: wavefront sweep (k_sweep_prep + k_sweep2); 1: the independent 64-rows-per-wave kernel; 3: LDS-tile relaxation */
@@ -102,6 +104,14 @@ int pf_novel_view(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, int
 int pf_stitch_prepare(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, int cols, int rows, size_t step_bytes,
                       uint8_t* map_out, size_t map_step_bytes, uint8_t* overlapped_l, uint8_t* overlapped_r,
                       float* blend_out, size_t blend_step_bytes, float* merged_dis /* packed, nullable */);
+
+/* The two halves of prepare() as the reference exposes them: Stitchtools::MatchImages (CPU/StitchTool.cpp:38-50) with the overlap
+ * masking of :17-33, and Stitchtools::GenerateBlend (:98-146) computed from a GIVEN map -- the reference reads its public `Map`
+ * member there, so a caller that edits Map between the two calls gets the ramp of the edited map.  Outputs may be NULL. */
+int pf_stitch_match(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, int cols, int rows, size_t step_bytes, uint8_t* map_out,
+                    size_t map_step_bytes, uint8_t* overlapped_l, uint8_t* overlapped_r);
+int pf_stitch_generate_blend(pf_ctx* ctx, const uint8_t* map, size_t map_step_bytes, int cols, int rows, float* blend_out,
+                             size_t blend_step_bytes, float* merged_dis /* packed, nullable */);
 
 /* GenerateBlend's per-pixel loop alone, CPU/StitchTool.cpp:113-125: 0 / 1 / 0.5 by map code and, in the overlap,
  * Stitchtools::countblend(x, y) (:148-191) = minLdis / (minRdis + minLdis) -- the ramp BEFORE the smoothing of
@@ -153,10 +163,11 @@ int pf_blend_dev(pf_ctx* ctx, const uint8_t* d_l, const uint8_t* d_r, const floa
 int pf_novel_view_dev(pf_ctx* ctx, const uint8_t* d_l, const uint8_t* d_r, int cols, int rows, int max_percentage,
                       const float* d_blend, uint8_t* d_out, float* d_flow_l2r, float* d_flow_r2l);
 
-/* Throughput mode: n_pairs independent pairs of one size, `in_flight` (1..16) of them side by side on this GPU (the exact
- * sweeps of one pair are a dependency chain that occupies ~1/4 of the CUs).  Arrays of n_pairs device pointers; d_flow_*
- * may be NULL (or hold NULL entries).  Same results as n_pairs calls of pf_novel_view_dev.  Needs GPU_MAX_HW_QUEUES >=
- * 4 * in_flight in the environment before the first HIP call, or the lanes' streams share hardware queues. */
+/* Throughput mode: n_pairs independent pairs of one size, `in_flight` (1..16) of them on this GPU at a time (the exact sweeps of one
+ * pair are a dependency chain that occupies ~1/4 of the CUs): batches of pairs that share every kernel launch, on one or more
+ * lanes of streams (pf_config::batch_pairs).  Arrays of n_pairs device pointers; d_flow_* may be NULL (or hold NULL entries).
+ * Same results as n_pairs calls of pf_novel_view_dev.  Needs GPU_MAX_HW_QUEUES >= 3 * lanes + 2 in the environment before the
+ * first HIP call, or the lanes' streams share hardware queues. */
 int pf_novel_view_batch_dev(pf_ctx* ctx, int n_pairs, const uint8_t* const* d_l, const uint8_t* const* d_r, int cols, int rows,
                             int max_percentage, const float* const* d_blend, uint8_t* const* d_out, float* const* d_flow_l2r,
                             float* const* d_flow_r2l, int in_flight);

@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void k_gradients(const float* __restrict__ img
 // All pyramid levels of both images in ONE launch (the per-level launches of the small levels are pure launch latency):
 // a thread's flat index inside the pyramid plane -> level by binary search in the offset table -> (x, y).
 __global__ __launch_bounds__(256) void k_gradients_all(const float* __restrict__ img0, const float* __restrict__ img1, float2* __restrict__ g0,
-                                                       float2* __restrict__ g1, LevelTable t, unsigned first, unsigned total, Gauss g) {
+                                                       float2* __restrict__ g1, LevelTable t, unsigned first, unsigned total, Gauss g, size_t bstride) {
+  { const size_t bo = size_t(blockIdx.z) * bstride; PF_BOFF(img0, bo); PF_BOFF(img1, bo); PF_BOFF(g0, bo); PF_BOFF(g1, bo); }
   // elements [first, total) of the pyramid plane; grid-stride, so that a launch can be made with few blocks on purpose
   for (unsigned i = first + blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     int lo = 0, hi = t.n - 1;
@@ -64,12 +65,12 @@ void launch_gradients(hipStream_t st, const float* img, int w, int h, float* gxy
 // max_blocks > 0 caps the blocks per image: a launch that runs BESIDE latency-critical kernels (the finest levels' gradients
 // next to the coarse levels' sweeps) is made narrow so that it takes a few wave slots per CU instead of all of them.
 void launch_gradients_all(hipStream_t st, const float* pyr0, const float* pyr1, float* grad0, float* grad1, const LevelTable& t, size_t first,
-                          size_t total, const Gauss& g3, int max_blocks) {
+                          size_t total, const Gauss& g3, int max_blocks, Batch bt) {
   if (total <= first) return;
   size_t blocks = (total - first + 255) / 256;
   if (max_blocks > 0 && blocks > size_t(max_blocks)) blocks = size_t(max_blocks);
-  hipLaunchKernelGGL(k_gradients_all, dim3((unsigned)blocks, 2), dim3(256), 0, st, pyr0, pyr1, reinterpret_cast<float2*>(grad0),
-                     reinterpret_cast<float2*>(grad1), t, (unsigned)first, (unsigned)total, g3);
+  hipLaunchKernelGGL(k_gradients_all, dim3((unsigned)blocks, 2, bt.n), dim3(256), 0, st, pyr0, pyr1, reinterpret_cast<float2*>(grad0),
+                     reinterpret_cast<float2*>(grad1), t, (unsigned)first, (unsigned)total, g3, bt.stride);
 }
 
 // update gate of the sweeps (PixFlow.hpp:317,330): alpha0 > 0.9 && alpha1 > 0.9
@@ -133,7 +134,8 @@ void launch_gate_bbox(hipStream_t st, const uint8_t* gate, const LevelTable& t, 
 #endif
 constexpr unsigned kGatePer = PF_GATE_PER;   // level-pixels per block
 __global__ __launch_bounds__(256) void k_gate_bbox_all(const float* __restrict__ a0, const float* __restrict__ a1, uint8_t* __restrict__ gate, LevelTable t,
-                                                       unsigned total, int* __restrict__ work, int* __restrict__ host, int epoch) {
+                                                       unsigned total, int* __restrict__ work, int* __restrict__ host, int epoch, size_t bstride, size_t hstride) {
+  { const size_t bo = size_t(blockIdx.z) * bstride; PF_BOFF(a0, bo); PF_BOFF(a1, bo); PF_BOFF(gate, bo); PF_BOFF(work, bo); PF_BOFF(host, size_t(blockIdx.z) * hstride); }
   __shared__ int sbox[4];
   __shared__ int scnt, slast;
   constexpr unsigned kPer = kGatePer;
@@ -222,8 +224,10 @@ __global__ __launch_bounds__(256) void k_gate_bbox_all(const float* __restrict__
     __hip_atomic_store(&host[kDone], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
-void launch_gate_bbox_all(hipStream_t st, const float* a0, const float* a1, uint8_t* gate, const LevelTable& t, size_t total, int* work, int* host_mapped, int epoch) {
-  hipLaunchKernelGGL(k_gate_bbox_all, dim3((unsigned)((total + kGatePer - 1) / kGatePer)), dim3(256), 0, st, a0, a1, gate, t, (unsigned)total, work, host_mapped, epoch);
+void launch_gate_bbox_all(hipStream_t st, const float* a0, const float* a1, uint8_t* gate, const LevelTable& t, size_t total, int* work, int* host_mapped, int epoch,
+                          Batch bt, size_t host_stride) {
+  hipLaunchKernelGGL(k_gate_bbox_all, dim3((unsigned)((total + kGatePer - 1) / kGatePer), 1, bt.n), dim3(256), 0, st, a0, a1, gate, t, (unsigned)total, work, host_mapped,
+                     epoch, bt.stride, host_stride);
 }
 
 __global__ __launch_bounds__(256) void k_count_gate(const uint8_t* __restrict__ gate, int n, unsigned* __restrict__ count) {
@@ -382,7 +386,11 @@ constexpr int kG15Pre = (kG15SW * kG15SH + 255) / 256;                     // 15
 struct UpsSrc { const float2* src; int sw, sh; double scale_x, scale_y; float mul; float2* up_out; };
 template <bool MIX, bool UPS, bool MED>
 __global__ __launch_bounds__(256, 3) void k_gauss15_fused(const float2* __restrict__ src, float2* __restrict__ dst, int w, int h, Gauss g,
-                                                        const float* __restrict__ a0, const float* __restrict__ a1, int ntx, int ntiles, UpsSrc ups) {
+                                                        const float* __restrict__ a0, const float* __restrict__ a1, int ntx, int ntiles, UpsSrc ups, size_t bstride) {
+  {   // blockIdx.z = pair of a batched launch (every pointer is pair 0's)
+    const size_t bo = size_t(blockIdx.z) * bstride;
+    PF_BOFF(src, bo); PF_BOFF(dst, bo); PF_BOFF(a0, bo); PF_BOFF(a1, bo); PF_BOFF(ups.src, bo); PF_BOFF(ups.up_out, bo);
+  }
   constexpr int SW = kG15SW, SH = kG15SH;
   constexpr int SS = SW + 1, RS = kG15TX + 1;                        // LDS row strides in float2: 79, 65 (odd); 53 KB in all: three blocks per CU
   __shared__ float2 srct[SH * SS];
@@ -493,25 +501,27 @@ __global__ __launch_bounds__(256, 3) void k_gauss15_fused(const float2* __restri
     if (tile < ntiles) __syncthreads();   // every read of this tile's LDS is done before the next one is stored
   }
 }
-static inline void gauss15_grid(int w, int h, int& ntx, int& ntiles, unsigned& blocks) {
+static inline void gauss15_grid(int w, int h, int& ntx, int& ntiles, unsigned& blocks, int nbatch = 1) {
   ntx = (w + kG15TX - 1) / kG15TX;
   ntiles = ntx * ((h + kG15TY - 1) / kG15TY);
   static const int cap = [] { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 768; return 3 * p.multiProcessorCount; }();
-  blocks = (unsigned)(ntiles < cap ? ntiles : cap);
+  int per = cap / (nbatch > 0 ? nbatch : 1);   // the persistent blocks of all pairs of a batch share the chip
+  if (per < 1) per = 1;
+  blocks = (unsigned)(ntiles < per ? ntiles : per);
 }
-void launch_gauss15(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const Gauss& g15) {
+void launch_gauss15(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const Gauss& g15, Batch bt) {
   (void)tmp;
   int ntx, ntiles; unsigned blocks;
-  gauss15_grid(w, h, ntx, ntiles, blocks);
-  hipLaunchKernelGGL((k_gauss15_fused<false, false, false>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h, g15, nullptr, nullptr, ntx, ntiles, UpsSrc{});
+  gauss15_grid(w, h, ntx, ntiles, blocks, bt.n);
+  hipLaunchKernelGGL((k_gauss15_fused<false, false, false>), dim3(blocks, 1, bt.n), dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h, g15, nullptr, nullptr, ntx, ntiles, UpsSrc{}, bt.stride);
 }
 
 // upsample (coarse sw x sh -> w x h, times mul) + Gauss15 of the upsampled plane in one launch: `up` receives the upsampled flow
-void launch_gauss15_upsample(hipStream_t st, const float* coarse, int sw, int sh, float mul, float* up, float* dst, int w, int h, const Gauss& g15) {
+void launch_gauss15_upsample(hipStream_t st, const float* coarse, int sw, int sh, float mul, float* up, float* dst, int w, int h, const Gauss& g15, Batch bt) {
   int ntx, ntiles; unsigned blocks;
-  gauss15_grid(w, h, ntx, ntiles, blocks);
+  gauss15_grid(w, h, ntx, ntiles, blocks, bt.n);
   const UpsSrc u{reinterpret_cast<const float2*>(coarse), sw, sh, 1. / ((double)w / sw), 1. / ((double)h / sh), mul, reinterpret_cast<float2*>(up)};
-  hipLaunchKernelGGL((k_gauss15_fused<false, true, false>), dim3(blocks), dim3(256), 0, st, nullptr, reinterpret_cast<float2*>(dst), w, h, g15, nullptr, nullptr, ntx, ntiles, u);
+  hipLaunchKernelGGL((k_gauss15_fused<false, true, false>), dim3(blocks, 1, bt.n), dim3(256), 0, st, nullptr, reinterpret_cast<float2*>(dst), w, h, g15, nullptr, nullptr, ntx, ntiles, u, bt.stride);
 }
 
 // K8 lowAlphaFlowDiffusion (PixFlow.hpp:388-405): column pass fused with the alpha mix.
@@ -525,18 +535,19 @@ __global__ __launch_bounds__(256) void k_gauss15_col_mix(const float2* __restric
   const float diffusionCoef = 1.0f - a0[i] * a1[i];
   out[i] = make_float2(diffusionCoef * b.x + (1.0f - diffusionCoef) * f.x, diffusionCoef * b.y + (1.0f - diffusionCoef) * f.y);
 }
-void launch_gauss15_mix(hipStream_t st, float* flow, float* tmp, const float* a0, const float* a1, int w, int h, const Gauss& g15, float* out) {
+void launch_gauss15_mix(hipStream_t st, float* flow, float* tmp, const float* a0, const float* a1, int w, int h, const Gauss& g15, float* out, Batch bt) {
   (void)tmp;
   int ntx, ntiles; unsigned blocks;
-  gauss15_grid(w, h, ntx, ntiles, blocks);
-  hipLaunchKernelGGL((k_gauss15_fused<true, false, false>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float2*>(flow), reinterpret_cast<float2*>(out), w, h, g15, a0, a1, ntx, ntiles, UpsSrc{});
+  gauss15_grid(w, h, ntx, ntiles, blocks, bt.n);
+  hipLaunchKernelGGL((k_gauss15_fused<true, false, false>), dim3(blocks, 1, bt.n), dim3(256), 0, st, reinterpret_cast<const float2*>(flow), reinterpret_cast<float2*>(out), w, h, g15, a0, a1, ntx, ntiles, UpsSrc{}, bt.stride);
 }
 
 // Direct form: every thread loads the 6 x 5 neighbourhood of its output pair straight from memory (the 15x re-reads are served by
 // L1 / L2).  Lowest latency per launch: used for the levels where a launch is latency-bound (below kMedTiledMinPx pixels).
-__global__ __launch_bounds__(256) void k_median5(const float2* __restrict__ src, float2* __restrict__ dst, int w, int h) {
+__global__ __launch_bounds__(256) void k_median5(const float2* __restrict__ src, float2* __restrict__ dst, int w, int h, size_t bstride) {
   const int xp = (blockIdx.x * blockDim.x + threadIdx.x) * 2, y = blockIdx.y;   // outputs xp and xp + 1
   if (xp >= w) return;
+  { const size_t bo = size_t(blockIdx.z) * bstride; PF_BOFF(src, bo); PF_BOFF(dst, bo); }
   float2 col[6][5];   // columns xp-2 .. xp+3 (replicate border), rows y-2 .. y+2
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
@@ -572,7 +583,8 @@ __global__ __launch_bounds__(256) void k_median5(const float2* __restrict__ src,
 // Measured per launch beside the other direction's kernels (tests/micro/kern_by_grid.sh): 4950x2000 123 vs 139 us, 4455x1800 112 vs
 // 124, equal at ~2.3 Mpix, slower below (a block's single HBM round trip + barrier in front of the network): levels >= kMedTiledMinPx.
 constexpr int kMedX = 128, kMedY = 16, kMedSX = kMedX + 4, kMedSY = kMedY + 4, kMedT = 64 * kMedY;
-__global__ __launch_bounds__(kMedT) void k_median5_tiled(const float2* __restrict__ src, float2* __restrict__ dst, int w, int h) {
+__global__ __launch_bounds__(kMedT) void k_median5_tiled(const float2* __restrict__ src, float2* __restrict__ dst, int w, int h, size_t bstride) {
+  { const size_t bo = size_t(blockIdx.z) * bstride; PF_BOFF(src, bo); PF_BOFF(dst, bo); }
   __shared__ __attribute__((aligned(16))) float2 tile[kMedSY][kMedSX];
   const int x0 = blockIdx.x * kMedX, y0 = blockIdx.y * kMedY;
   {   // all of a thread's loads are issued before the first LDS store: one HBM round trip per block
@@ -626,31 +638,22 @@ __global__ __launch_bounds__(kMedT) void k_median5_tiled(const float2* __restric
   }
 }
 constexpr long kMedTiledMinPx = 3000000;
-void launch_median5(hipStream_t st, const float* src, float* dst, int w, int h) {
-  if ((long)w * h >= kMedTiledMinPx) {
-    dim3 grid((w + kMedX - 1) / kMedX, (h + kMedY - 1) / kMedY);
-    hipLaunchKernelGGL(k_median5_tiled, grid, dim3(kMedT), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h);
-  } else {
-    dim3 grid(((w + 1) / 2 + 255) / 256, h);
-    hipLaunchKernelGGL(k_median5, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h);
-  }
-}
-// tests: force one of the two forms whatever the size
-void launch_median5_form(hipStream_t st, const float* src, float* dst, int w, int h, bool tiled) {
+void launch_median5_form(hipStream_t st, const float* src, float* dst, int w, int h, bool tiled, Batch bt) {
   if (tiled) {
-    dim3 grid((w + kMedX - 1) / kMedX, (h + kMedY - 1) / kMedY);
-    hipLaunchKernelGGL(k_median5_tiled, grid, dim3(kMedT), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h);
+    dim3 grid((w + kMedX - 1) / kMedX, (h + kMedY - 1) / kMedY, bt.n);
+    hipLaunchKernelGGL(k_median5_tiled, grid, dim3(kMedT), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h, bt.stride);
   } else {
-    dim3 grid(((w + 1) / 2 + 255) / 256, h);
-    hipLaunchKernelGGL(k_median5, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h);
+    dim3 grid(((w + 1) / 2 + 255) / 256, h, bt.n);
+    hipLaunchKernelGGL(k_median5, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), w, h, bt.stride);
   }
 }
+void launch_median5(hipStream_t st, const float* src, float* dst, int w, int h, Batch bt) { launch_median5_form(st, src, dst, w, h, (long)w * h >= kMedTiledMinPx, bt); }
 
 // medianBlur(5) + lowAlphaFlowDiffusion in one launch: `flow` is the backward sweep's output, `out` a different plane
-void launch_median_gauss15_mix(hipStream_t st, const float* flow, const float* a0, const float* a1, int w, int h, const Gauss& g15, float* out) {
+void launch_median_gauss15_mix(hipStream_t st, const float* flow, const float* a0, const float* a1, int w, int h, const Gauss& g15, float* out, Batch bt) {
   int ntx, ntiles; unsigned blocks;
-  gauss15_grid(w, h, ntx, ntiles, blocks);
-  hipLaunchKernelGGL((k_gauss15_fused<true, false, true>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float2*>(flow), reinterpret_cast<float2*>(out), w, h, g15, a0, a1, ntx, ntiles, UpsSrc{});
+  gauss15_grid(w, h, ntx, ntiles, blocks, bt.n);
+  hipLaunchKernelGGL((k_gauss15_fused<true, false, true>), dim3(blocks, 1, bt.n), dim3(256), 0, st, reinterpret_cast<const float2*>(flow), reinterpret_cast<float2*>(out), w, h, g15, a0, a1, ntx, ntiles, UpsSrc{}, bt.stride);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -658,9 +661,10 @@ void launch_median_gauss15_mix(hipStream_t st, const float* flow, const float* a
 // [OpenCV imgwarp.cpp] HResizeCubic (taps clamped to the row) then VResizeCubic (rows clipped).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_upsample_cubic(const float2* __restrict__ src, int sw, int sh, float2* __restrict__ dst, int dw, int dh,
-                                                        double scale_x, double scale_y, float mul) {
+                                                        double scale_x, double scale_y, float mul, size_t bstride) {
   const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
   if (dx >= dw) return;
+  { const size_t bo = size_t(blockIdx.z) * bstride; PF_BOFF(src, bo); PF_BOFF(dst, bo); }
   dst[size_t(dy) * dw + dx] = d_upsample_cubic_px(src, sw, sh, dx, dy, scale_x, scale_y, mul);
 }
 // Tiled form: a block owns a 64 x 16 output tile.  The horizontal pass (HResizeCubic) of every source row the tile's vertical
@@ -668,7 +672,8 @@ __global__ __launch_bounds__(256) void k_upsample_cubic(const float2* __restrict
 // vertical pass (VResizeCubic) reads four LDS rows: ~5 global loads per output instead of 16, same expressions.
 constexpr int kUpX = 64, kUpY = 16, kUpRows = 24;
 __global__ __launch_bounds__(256) void k_upsample_cubic_tiled(const float2* __restrict__ src, int sw, int sh, float2* __restrict__ dst, int dw, int dh,
-                                                              double scale_x, double scale_y, float mul) {
+                                                              double scale_x, double scale_y, float mul, size_t bstride) {
+  { const size_t bo = size_t(blockIdx.z) * bstride; PF_BOFF(src, bo); PF_BOFF(dst, bo); }
   __shared__ float2 hp[kUpRows][kUpX];
   const int x0 = blockIdx.x * kUpX, y0 = blockIdx.y * kUpY;
   const int tx = threadIdx.x & (kUpX - 1), ty4 = threadIdx.x >> 6;
@@ -703,16 +708,16 @@ __global__ __launch_bounds__(256) void k_upsample_cubic_tiled(const float2* __re
     dst[size_t(dy) * dw + x0 + tx] = make_float2(ox * mul + 0.0f, oy2 * mul + 0.0f);
   }
 }
-void launch_upsample_cubic(hipStream_t st, const float* src, int sw, int sh, float* dst, int dw, int dh, float mul) {
+void launch_upsample_cubic(hipStream_t st, const float* src, int sw, int sh, float* dst, int dw, int dh, float mul, Batch bt) {
   const double sx = 1. / ((double)dw / sw), sy = 1. / ((double)dh / sh);
   if (kUpY * sy + 5.0 <= kUpRows) {   // source rows a 16-row output tile can touch: floor(15 * sy) + 4 (+1 for rounding)
-    dim3 grid((dw + kUpX - 1) / kUpX, (dh + kUpY - 1) / kUpY);
-    hipLaunchKernelGGL(k_upsample_cubic_tiled, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), sw, sh, reinterpret_cast<float2*>(dst), dw, dh, sx, sy, mul);
+    dim3 grid((dw + kUpX - 1) / kUpX, (dh + kUpY - 1) / kUpY, bt.n);
+    hipLaunchKernelGGL(k_upsample_cubic_tiled, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), sw, sh, reinterpret_cast<float2*>(dst), dw, dh, sx, sy, mul, bt.stride);
     return;
   }
-  dim3 grid((dw + 255) / 256, dh);
+  dim3 grid((dw + 255) / 256, dh, bt.n);
   hipLaunchKernelGGL(k_upsample_cubic, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(src), sw, sh, reinterpret_cast<float2*>(dst), dw, dh, sx,
-                     sy, mul);
+                     sy, mul, bt.stride);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -725,7 +730,9 @@ void launch_upsample_cubic(hipStream_t st, const float* src, int sw, int sh, flo
 // same expressions as before) reads LDS -- 1.2 bilinear samples per output instead of 9.
 constexpr int kFFX = 64, kFFY = 16;
 __global__ __launch_bounds__(256) void k_final_flow(const float* __restrict__ flow0, int sw, int sh, int pad_cols, int rows, int pad, double scale_x,
-                                                    double scale_y, float mul, Gauss g, float2* __restrict__ out) {
+                                                    double scale_y, float mul, Gauss g, ExtPtrs outs, size_t bstride) {
+  PF_BOFF(flow0, size_t(blockIdx.z) * bstride);
+  float2* __restrict__ out = static_cast<float2*>(const_cast<void*>(outs.p[blockIdx.z]));   // caller-owned (or internal) output plane of this pair
   __shared__ float2 up[kFFY + 2][kFFX + 2];
   const int cols = pad_cols - 2 * pad;
   const int x0 = blockIdx.x * kFFX, y0 = blockIdx.y * kFFY;
@@ -756,11 +763,13 @@ __global__ __launch_bounds__(256) void k_final_flow(const float* __restrict__ fl
     out[size_t(y) * cols + x] = make_float2(ox, oy2);
   }
 }
-void launch_final_flow(hipStream_t st, const float* flow0, int sw, int sh, int pad_cols, int rows, int pad, float mul, const Gauss& g3, float* out) {
+void launch_final_flow(hipStream_t st, const float* flow0, int sw, int sh, int pad_cols, int rows, int pad, float mul, const Gauss& g3, float* out, Batch bt,
+                       const ExtPtrs* outs) {
   const double sx = 1. / ((double)pad_cols / sw), sy = 1. / ((double)rows / sh);
   const int cols = pad_cols - 2 * pad;
-  dim3 grid((cols + kFFX - 1) / kFFX, (rows + kFFY - 1) / kFFY);
-  hipLaunchKernelGGL(k_final_flow, grid, dim3(256), 0, st, flow0, sw, sh, pad_cols, rows, pad, sx, sy, mul, g3, reinterpret_cast<float2*>(out));
+  dim3 grid((cols + kFFX - 1) / kFFX, (rows + kFFY - 1) / kFFY, bt.n);
+  ExtPtrs e{}; if (outs) e = *outs; else e.p[0] = out;
+  hipLaunchKernelGGL(k_final_flow, grid, dim3(256), 0, st, flow0, sw, sh, pad_cols, rows, pad, sx, sy, mul, g3, e, bt.stride);
 }
 
 }  // namespace pf

@@ -11,7 +11,8 @@ namespace pf {
 // products are staged through LDS by the whole block so the serial part only reads LDS).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_intensity_ratio(const float* __restrict__ i0, const float* __restrict__ i1, const float* __restrict__ a0,
-                                                         const float* __restrict__ a1, int n, float* __restrict__ ratio) {
+                                                         const float* __restrict__ a1, int n, float* __restrict__ ratio, size_t bstride) {
+  { const size_t bo = size_t(blockIdx.z) * bstride; PF_BOFF(i0, bo); PF_BOFF(i1, bo); PF_BOFF(a0, bo); PF_BOFF(a1, bo); PF_BOFF(ratio, bo); }
   __shared__ float pl[1024], pr[1024];
   float sumL = 0.f, sumR = 0.f;
   for (int base = 0; base < n; base += 1024) {
@@ -60,9 +61,10 @@ __device__ __forceinline__ float d_patch_error(const float* __restrict__ i0, con
 // adjustInitialFlow (PixFlow.hpp:226-270)
 __global__ __launch_bounds__(64) void k_adjust_initial_flow(const float* __restrict__ i0, const float* __restrict__ i1, const float* __restrict__ a0,
                                                             const float* __restrict__ a1, int w, int h, int bx, int by, int bw, int bh, int dist,
-                                                            const float* __restrict__ ratio_p, float2* __restrict__ flow) {
+                                                            const float* __restrict__ ratio_p, float2* __restrict__ flow, size_t bstride) {
   const int i0x = blockIdx.x * blockDim.x + threadIdx.x, i0y = blockIdx.y;
   if (i0x >= w) return;
+  { const size_t bo = size_t(blockIdx.z) * bstride; PF_BOFF(i0, bo); PF_BOFF(i1, bo); PF_BOFF(a0, bo); PF_BOFF(a1, bo); PF_BOFF(ratio_p, bo); PF_BOFF(flow, bo); }
   if (!(a0[size_t(i0y) * w + i0x] > kUpdateAlphaThreshold)) return;
   const float ratio = *ratio_p;
   const float kFraction = 0.8f;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(64) void k_adjust_initial_flow(const float* __restr
 
 // `flow` must be zero-filled by the caller (PixFlow.hpp:298).  i1eq_tmp: >= 1 float of scratch (the ratio).
 void launch_adjust_initial_flow(hipStream_t st, const float* i0, const float* i1, const float* a0, const float* a1, int w, int h, int hint,
-                                int max_pct, float* ratio_tmp, float* flow) {
+                                int max_pct, float* ratio_tmp, float* flow, Batch bt) {
   const int dist = (kPyrMinImageSize * max_pct + 50) / 100;  // computeSearchDistance, PixFlow.hpp:153-155
   const int kRatio = 8, ortho = (dist + kRatio / 2) / kRatio, thickness = 2 * ortho + 1;
   int bx, by, bw, bh;  // computeSearchBox, PixFlow.hpp:207-224
@@ -92,10 +94,10 @@ void launch_adjust_initial_flow(hipStream_t st, const float* i0, const float* i1
     case 4: bx = -ortho; by = -dist; bw = thickness; bh = dist + 1; break;   // UP
     default: return;
   }
-  hipLaunchKernelGGL(k_intensity_ratio, dim3(1), dim3(256), 0, st, i0, i1, a0, a1, w * h, ratio_tmp);
-  dim3 grid((w + 63) / 64, h);
+  hipLaunchKernelGGL(k_intensity_ratio, dim3(1, 1, bt.n), dim3(256), 0, st, i0, i1, a0, a1, w * h, ratio_tmp, bt.stride);
+  dim3 grid((w + 63) / 64, h, bt.n);
   hipLaunchKernelGGL(k_adjust_initial_flow, grid, dim3(64), 0, st, i0, i1, a0, a1, w, h, bx, by, bw, bh, dist, ratio_tmp,
-                     reinterpret_cast<float2*>(flow));
+                     reinterpret_cast<float2*>(flow), bt.stride);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -113,9 +115,9 @@ __device__ __forceinline__ uchar4 d_novel_view_point(const uchar4* __restrict__ 
 }
 __device__ __forceinline__ float d_lerp(float x0, float x1, float alpha) { return x0 * (1.0f - alpha) + x1 * alpha; }  // util.hpp:93-101
 
-__global__ __launch_bounds__(256) void k_blend(const uchar4* __restrict__ L, const uchar4* __restrict__ R, const float2* __restrict__ flowLR,
-                                               const float2* __restrict__ flowRL, const float* __restrict__ blend, int cols, int rows,
-                                               uchar4* __restrict__ out) {
+__device__ __forceinline__ void d_blend_px(const uchar4* __restrict__ L, const uchar4* __restrict__ R, const float2* __restrict__ flowLR,
+                                           const float2* __restrict__ flowRL, const float* __restrict__ blend, int cols, int rows,
+                                           uchar4* __restrict__ out) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= cols) return;
   const size_t i = size_t(y) * cols + x;
@@ -146,6 +148,21 @@ __global__ __launch_bounds__(256) void k_blend(const uchar4* __restrict__ L, con
     o.w = 255;
   }
   out[i] = o;
+}
+__global__ __launch_bounds__(256) void k_blend(const uchar4* __restrict__ L, const uchar4* __restrict__ R, const float2* __restrict__ flowLR,
+                                               const float2* __restrict__ flowRL, const float* __restrict__ blend, int cols, int rows,
+                                               uchar4* __restrict__ out) {
+  d_blend_px(L, R, flowLR, flowRL, blend, cols, rows, out);
+}
+__global__ __launch_bounds__(256) void k_blend_batch(BlendPtrs p, int cols, int rows) {
+  const int z = blockIdx.z;
+  d_blend_px(reinterpret_cast<const uchar4*>(p.L[z]), reinterpret_cast<const uchar4*>(p.R[z]), reinterpret_cast<const float2*>(p.fLR[z]),
+             reinterpret_cast<const float2*>(p.fRL[z]), p.blend[z], cols, rows, reinterpret_cast<uchar4*>(p.out[z]));
+}
+// n pairs in one launch (blockIdx.z = pair): every buffer is caller-owned or per-pair, so the pointers come as tables
+void launch_blend_batch(hipStream_t st, const BlendPtrs& p, int n, int cols, int rows) {
+  dim3 grid((cols + 255) / 256, rows, n);
+  hipLaunchKernelGGL(k_blend_batch, grid, dim3(256), 0, st, p, cols, rows);
 }
 void launch_blend(hipStream_t st, const uint8_t* L, const uint8_t* R, const float* flowLR, const float* flowRL, const float* blend, int cols,
                   int rows, uint8_t* out) {

@@ -11,10 +11,12 @@ __device__ __forceinline__ int sat_short(int v) { return v < -32768 ? -32768 : (
 
 // [OpenCV imgwarp.cpp] INTER_CUBIC 8UC4: HResizeCubic<uchar,int,short> + VResizeCubic/FixedPtCast<int,uchar,22>.
 // The padded image [last `pad` cols | image | first `pad` cols] is virtual: taps are re-mapped.
-__global__ __launch_bounds__(256) void k_downscale_gray(const uint8_t* __restrict__ bgra, int cols, int rows, int pad, float* __restrict__ gray,
-                                                        float* __restrict__ alpha, int dw, int dh, double scale_x, double scale_y) {
+__global__ __launch_bounds__(256) void k_downscale_gray(ExtPtrs imgs, int cols, int rows, int pad, float* __restrict__ gray,
+                                                        float* __restrict__ alpha, int dw, int dh, double scale_x, double scale_y, size_t bstride) {
   const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
   if (dx >= dw) return;
+  const uint8_t* __restrict__ bgra = static_cast<const uint8_t*>(imgs.p[blockIdx.z]);   // caller-owned: one pointer per pair
+  { const size_t bo = size_t(blockIdx.z) * bstride; PF_BOFF(gray, bo); PF_BOFF(alpha, bo); }
   const int ce = cols + 2 * pad;
   int sx, sy; float fx, fy;
   d_src_coord(dx, scale_x, sx, fx);
@@ -54,19 +56,22 @@ __global__ __launch_bounds__(256) void k_downscale_gray(const uint8_t* __restric
   alpha[size_t(dy) * dw + dx] = float(px[3]) * inv255 + 0.0f;
 }
 
-void launch_downscale_gray(hipStream_t st, const uint8_t* bgra, int cols, int rows, int pad, float* gray, float* alpha, int dw, int dh) {
+void launch_downscale_gray(hipStream_t st, const uint8_t* bgra, int cols, int rows, int pad, float* gray, float* alpha, int dw, int dh, Batch bt,
+                           const ExtPtrs* imgs) {
   const int ce = cols + 2 * pad;
   const double sx = 1. / ((double)dw / ce), sy = 1. / ((double)dh / rows);
-  dim3 grid((dw + 255) / 256, dh);
-  hipLaunchKernelGGL(k_downscale_gray, grid, dim3(256), 0, st, bgra, cols, rows, pad, gray, alpha, dw, dh, sx, sy);
+  dim3 grid((dw + 255) / 256, dh, bt.n);
+  ExtPtrs e{}; if (imgs) e = *imgs; else e.p[0] = bgra;
+  hipLaunchKernelGGL(k_downscale_gray, grid, dim3(256), 0, st, e, cols, rows, pad, gray, alpha, dw, dh, sx, sy, bt.stride);
 }
 
 // [OpenCV filter.cpp] separable symmetric Gaussian, ksize 3 or 5, BORDER_REFLECT_101:
 // row pass SymmRowSmallFilter (centre*k0 + (l+r)*k1 + ...), column pass SymmColumnFilter.
 template <int R, int CN>
-__global__ __launch_bounds__(256) void k_gauss_small(const float* __restrict__ src, float* __restrict__ dst, int w, int h, Gauss g) {
+__global__ __launch_bounds__(256) void k_gauss_small(const float* __restrict__ src, float* __restrict__ dst, int w, int h, Gauss g, size_t bstride) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= w) return;
+  { const size_t bo = size_t(blockIdx.z) * bstride; PF_BOFF(src, bo); PF_BOFF(dst, bo); }
   int xi[2 * R + 1];
 #pragma unroll
   for (int i = -R; i <= R; ++i) xi[i + R] = d_reflect101(x + i, w);
@@ -89,12 +94,12 @@ __global__ __launch_bounds__(256) void k_gauss_small(const float* __restrict__ s
   }
 }
 
-void launch_gauss_small(hipStream_t st, const float* src, float* dst, int w, int h, int cn, const Gauss& g) {
-  dim3 grid((w + 255) / 256, h);
-  if (g.ksize == 3 && cn == 1) hipLaunchKernelGGL((k_gauss_small<1, 1>), grid, dim3(256), 0, st, src, dst, w, h, g);
-  else if (g.ksize == 3 && cn == 2) hipLaunchKernelGGL((k_gauss_small<1, 2>), grid, dim3(256), 0, st, src, dst, w, h, g);
-  else if (g.ksize == 5 && cn == 1) hipLaunchKernelGGL((k_gauss_small<2, 1>), grid, dim3(256), 0, st, src, dst, w, h, g);
-  else hipLaunchKernelGGL((k_gauss_small<2, 2>), grid, dim3(256), 0, st, src, dst, w, h, g);
+void launch_gauss_small(hipStream_t st, const float* src, float* dst, int w, int h, int cn, const Gauss& g, Batch bt) {
+  dim3 grid((w + 255) / 256, h, bt.n);
+  if (g.ksize == 3 && cn == 1) hipLaunchKernelGGL((k_gauss_small<1, 1>), grid, dim3(256), 0, st, src, dst, w, h, g, bt.stride);
+  else if (g.ksize == 3 && cn == 2) hipLaunchKernelGGL((k_gauss_small<1, 2>), grid, dim3(256), 0, st, src, dst, w, h, g, bt.stride);
+  else if (g.ksize == 5 && cn == 1) hipLaunchKernelGGL((k_gauss_small<2, 1>), grid, dim3(256), 0, st, src, dst, w, h, g, bt.stride);
+  else hipLaunchKernelGGL((k_gauss_small<2, 2>), grid, dim3(256), 0, st, src, dst, w, h, g, bt.stride);
 }
 
 template <int CN>
@@ -116,20 +121,23 @@ void launch_resize_linear(hipStream_t st, const float* src, int sw, int sh, floa
 }
 
 struct Ptr4 { const float* s[4]; float* d[4]; };
-__global__ __launch_bounds__(256) void k_pyr_down4(Ptr4 p, int sw, int sh, int dw, int dh, double scale_x, double scale_y) {
-  const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y, pl = blockIdx.z;
+__global__ __launch_bounds__(256) void k_pyr_down4(Ptr4 p, int sw, int sh, int dw, int dh, double scale_x, double scale_y, int nplanes, size_t bstride) {
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y, pl = blockIdx.z % nplanes;
   if (dx >= dw) return;
+  const size_t bo = size_t(blockIdx.z / nplanes) * bstride;   // z = plane + nplanes * pair
+  const float* src = p.s[pl]; float* dst = p.d[pl];
+  PF_BOFF(src, bo); PF_BOFF(dst, bo);
   float v[1];
-  d_resize_linear_px<1>(p.s[pl], sw, sh, dw, dh, scale_x, scale_y, dx, dy, v);
-  p.d[pl][size_t(dy) * dw + dx] = v[0];
+  d_resize_linear_px<1>(src, sw, sh, dw, dh, scale_x, scale_y, dx, dy, v);
+  dst[size_t(dy) * dw + dx] = v[0];
 }
 
 void launch_pyr_down4(hipStream_t st, const float* s0, const float* s1, const float* s2, const float* s3, int sw, int sh, float* d0,
-                      float* d1, float* d2, float* d3, int dw, int dh) {
+                      float* d1, float* d2, float* d3, int dw, int dh, Batch bt) {
   Ptr4 p{{s0, s1, s2, s3}, {d0, d1, d2, d3}};
   const double sx = 1. / ((double)dw / sw), sy = 1. / ((double)dh / sh);
-  dim3 grid((dw + 255) / 256, dh, 4);
-  hipLaunchKernelGGL(k_pyr_down4, grid, dim3(256), 0, st, p, sw, sh, dw, dh, sx, sy);
+  dim3 grid((dw + 255) / 256, dh, 4 * bt.n);
+  hipLaunchKernelGGL(k_pyr_down4, grid, dim3(256), 0, st, p, sw, sh, dw, dh, sx, sy, 4, bt.stride);
 }
 
 // two planes per launch: the alpha pyramids and the grey pyramids are built on different streams (pf_api.hip: solve)
@@ -137,7 +145,7 @@ void launch_pyr_down2(hipStream_t st, const float* s0, const float* s1, int sw, 
   Ptr4 p{{s0, s1, s0, s1}, {d0, d1, d0, d1}};
   const double sx = 1. / ((double)dw / sw), sy = 1. / ((double)dh / sh);
   dim3 grid((dw + 255) / 256, dh, 2);
-  hipLaunchKernelGGL(k_pyr_down4, grid, dim3(256), 0, st, p, sw, sh, dw, dh, sx, sy);
+  hipLaunchKernelGGL(k_pyr_down4, grid, dim3(256), 0, st, p, sw, sh, dw, dh, sx, sy, 2, size_t(0));
 }
 
 // Several pyramid levels per launch.  The levels form a dependency chain (level l+1 is a bilinear resize of level l), and for the
@@ -171,9 +179,10 @@ __device__ __forceinline__ float d_pyr_virtual(const float* __restrict__ base, c
   }
 }
 struct Ptr4P { float* p[4]; };
-__global__ __launch_bounds__(256) void k_pyr_chain(Ptr4P planes, PyrChain c, int rows1, int rows2) {
-  // blockIdx.y walks the rows of level 1, then of level 2, then of level 3 of the chain; blockIdx.z = plane
-  float* base = planes.p[blockIdx.z];
+__global__ __launch_bounds__(256) void k_pyr_chain(Ptr4P planes, PyrChain c, int rows1, int rows2, size_t bstride) {
+  // blockIdx.y walks the rows of level 1, then of level 2, then of level 3 of the chain; blockIdx.z = plane + 4 * pair
+  float* base = planes.p[blockIdx.z & 3];
+  PF_BOFF(base, size_t(blockIdx.z >> 2) * bstride);
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   int y = blockIdx.y, lvl = 1;
   if (y >= rows1) { y -= rows1; lvl = 2; if (y >= rows2) { y -= rows2; lvl = 3; } }
@@ -185,7 +194,7 @@ __global__ __launch_bounds__(256) void k_pyr_chain(Ptr4P planes, PyrChain c, int
   base[c.off[lvl] + size_t(y) * c.w[lvl] + x] = v;
 }
 // planes p0..p3 hold every level at offset off[l]; writes levels first+1 .. first+k (k = 1..3) from level `first`
-void launch_pyr_chain4(hipStream_t st, float* p0, float* p1, float* p2, float* p3, const int* ws, const int* hs, const size_t* off, int first, int k) {
+void launch_pyr_chain4(hipStream_t st, float* p0, float* p1, float* p2, float* p3, const int* ws, const int* hs, const size_t* off, int first, int k, Batch bt) {
   PyrChain c; c.n = k;
   for (int i = 0; i <= 3; ++i) {
     const int l = first + (i <= k ? i : k);
@@ -194,19 +203,26 @@ void launch_pyr_chain4(hipStream_t st, float* p0, float* p1, float* p2, float* p
   }
   Ptr4P pl{{p0, p1, p2, p3}};
   const int rows1 = c.h[1], rows2 = k >= 2 ? c.h[2] : 0, rows3 = k >= 3 ? c.h[3] : 0;
-  dim3 grid((c.w[1] + 255) / 256, rows1 + rows2 + rows3, 4);
-  hipLaunchKernelGGL(k_pyr_chain, grid, dim3(256), 0, st, pl, c, rows1, rows2);
+  dim3 grid((c.w[1] + 255) / 256, rows1 + rows2 + rows3, 4 * bt.n);
+  hipLaunchKernelGGL(k_pyr_chain, grid, dim3(256), 0, st, pl, c, rows1, rows2, bt.stride);
 }
 
-__global__ void k_fill_u64(unsigned long long* p, size_t n, unsigned long long v) {
+template <class T>
+__global__ void k_fill(T* p, size_t n, T v, size_t bstride) {
+  PF_BOFF(p, size_t(blockIdx.z) * bstride);
   size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t stride = size_t(gridDim.x) * blockDim.x;
   for (; i < n; i += stride) p[i] = v;
 }
-void launch_fill_u64(hipStream_t st, unsigned long long* p, size_t n, unsigned long long v) {
+void launch_fill_u64(hipStream_t st, unsigned long long* p, size_t n, unsigned long long v, Batch bt) {
   if (n == 0) return;
   const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-  hipLaunchKernelGGL(k_fill_u64, dim3(blocks), dim3(256), 0, st, p, n, v);
+  hipLaunchKernelGGL((k_fill<unsigned long long>), dim3(blocks, 1, bt.n), dim3(256), 0, st, p, n, v, bt.stride);
+}
+void launch_fill_u32(hipStream_t st, unsigned* p, size_t n, unsigned v, Batch bt) {
+  if (n == 0) return;
+  const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  hipLaunchKernelGGL((k_fill<unsigned>), dim3(blocks, 1, bt.n), dim3(256), 0, st, p, n, v, bt.stride);
 }
 
 // Did any sweep launch of a solve give up (ctrl[4*l+1], ctrl[4*l+3])?  One word in mapped pinned host memory per
@@ -248,13 +264,14 @@ void launch_count_diff_u32(hipStream_t st, const uint32_t* a, const uint32_t* b,
   hipLaunchKernelGGL(k_count_diff_u32, dim3((unsigned)blocks), dim3(256), 0, st, a, b, n, count);
 }
 
-__global__ void k_collect_status(const int* __restrict__ ctrl, int nwords, int* __restrict__ status, int bit) {
+__global__ void k_collect_status(const int* __restrict__ ctrl, int nwords, int* __restrict__ status, int bit, size_t bstride) {
+  PF_BOFF(ctrl, size_t(blockIdx.z) * bstride);   // every pair of a batch reports into the same word
   int bad = 0;
   for (int i = threadIdx.x; i < nwords; i += blockDim.x) if ((i & 1) && ctrl[i]) bad = 1;
   if (__any(bad) && (threadIdx.x & 63) == 0) __hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-void launch_collect_status(hipStream_t st, const int* ctrl, int nwords, int* status, int bit) {
-  hipLaunchKernelGGL(k_collect_status, dim3(1), dim3(64), 0, st, ctrl, nwords, status, bit);
+void launch_collect_status(hipStream_t st, const int* ctrl, int nwords, int* status, int bit, Batch bt) {
+  hipLaunchKernelGGL(k_collect_status, dim3(1, 1, bt.n), dim3(64), 0, st, ctrl, nwords, status, bit, bt.stride);
 }
 
 }  // namespace pf

@@ -595,7 +595,12 @@ __device__ __forceinline__ void d_make_record(size_t tid, size_t total, const fl
 __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g0, const float2* __restrict__ g1, const float2* __restrict__ blurred,
                                                     const uint8_t* __restrict__ gate, const float2* __restrict__ flow, int W, int H, int forward,
                                                     int transposed, int nstepsPad, int nbandsPad, float rW, float4* __restrict__ rec, int uLo, int uHi,
-                                                    int bandLo, unsigned long long* __restrict__ top0) {
+                                                    int bandLo, unsigned long long* __restrict__ top0, size_t bstride) {
+  {   // blockIdx.z = pair of a batched launch (every pointer is pair 0's)
+    const size_t bo = size_t(blockIdx.z) * bstride;
+    PF_BOFF(g0, bo); PF_BOFF(g1, bo); PF_BOFF(blurred, bo); PF_BOFF(gate, bo); PF_BOFF(flow, bo); PF_BOFF(rec, bo);
+    if (top0 != nullptr) PF_BOFF(top0, bo);
+  }
   const size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
   if (top0 != nullptr && tid < size_t(uHi - uLo)) {
@@ -634,7 +639,12 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
                                                 unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H,
                                                 int nstepsPad, int nbands, float rW, float rEps, int uLo, int LSv, int bandLo, long long budgetTicks,
                                                 const float2* __restrict__ g0, const float2* __restrict__ blurred, const uint8_t* __restrict__ gate,
-                                                int nwgSweep, int* __restrict__ prepcnt) {
+                                                int nwgSweep, int* __restrict__ prepcnt, size_t bstride) {
+  {   // blockIdx.z = pair of a batched launch: an independent sweep with its own ticket, granules and records
+    const size_t bo = size_t(blockIdx.z) * bstride;
+    PF_BOFF(rec, bo); PF_BOFF(g1, bo); PF_BOFF(flow, bo); PF_BOFF(boundary, bo); PF_BOFF(ctrl, bo); PF_BOFF(g0, bo); PF_BOFF(blurred, bo); PF_BOFF(gate, bo);
+    if (prepcnt != nullptr) PF_BOFF(prepcnt, bo);
+  }
   if (MODE == 2 && int(blockIdx.x) >= nwgSweep) {
     // ======================= prepass block (MODE 2): 704 records, written through to memory, then counted in =======================
     const int slotsPerWG = kWaves * nstepsPad * kRows;
@@ -1012,16 +1022,16 @@ bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
   constexpr int mode = 0;
 #endif
   if (mode == 0)
-    hipExtLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((prepThreads + 255) / 256)), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate, a.flow,
+    hipExtLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((prepThreads + 255) / 256), 1, a.bt.n), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate, a.flow,
                           a.W, a.H, a.forward, tr, nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo,
-                          bandLo > 0 ? a.boundary : (unsigned long long*)nullptr);
+                          bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride);
   hipEvent_t evs = mode == 0 ? nullptr : a.ev_start;   // without a prepass kernel the sweep launch carries both events
   // wall-clock budget of every wait inside the launch, in 100 MHz ticks: 2 s + 1000 x the expected duration (~0.5 us per step)
   const long long budget = 200000000ll + 1000ll * 50ll * (long long)(nstepsPad + 9 * nbands);
   const unsigned nthreads = 64 * (2 * kWaves + 3);
-  const dim3 grid(mode == 2 ? nwg + (unsigned)((total + nthreads - 1) / nthreads) : nwg), block(nthreads);
+  const dim3 grid(mode == 2 ? nwg + (unsigned)((total + nthreads - 1) / nthreads) : nwg, 1, a.bt.n), block(nthreads);
   const float4* r4 = mode == 1 ? nullptr : reinterpret_cast<const float4*>(rec);
-#define PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, MDV) hipExtLaunchKernelGGL((k_sweep2<TRV, FWV, SPV, MDV>), grid, block, 0, st, evs, a.ev_stop, 0, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.g0, a.blurred, a.gate, nwg, a.prepcnt)
+#define PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, MDV) hipExtLaunchKernelGGL((k_sweep2<TRV, FWV, SPV, MDV>), grid, block, 0, st, evs, a.ev_stop, 0, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.g0, a.blurred, a.gate, nwg, a.prepcnt, a.bt.stride)
 #ifdef PF_EXPERIMENTS
 #define PF_LAUNCH_SWEEP2__(TRV, FWV, SPV) do { if (mode == 2) PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 2); else if (mode == 1) PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 1); else PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 0); } while (0)
 #else

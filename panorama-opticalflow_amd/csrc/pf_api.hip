@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -29,6 +30,7 @@ struct DevBuf {
 };
 
 struct ProfEntry { double ms = 0; int n = 0; };
+constexpr int kGateWords = 4 * pf::kLevelTableMax + 2;   // per pair: boxes of every level, level-0 count, epoch flag (k_gate_bbox_all)
 struct ProfPending { int id; hipEvent_t a, b; };
 
 }  // namespace
@@ -59,6 +61,7 @@ struct pf_ctx {
   hipStream_t s_copy = nullptr;         // uploads that overlap compute (created on first use, like s_aux: a context that only solves
                                         // pairs drives three streams, so that six lanes of the throughput mode fit the hardware queues)
   bool drained = true;                  // false between "work enqueued" and finish(): what CallGuard looks at
+  size_t slab_stride = 0; int slab_pairs = 0;   // layout the "batch_slab" buffer was last initialised for (alloc_solve_batch)
   std::vector<pf_ctx*> lanes;           // throughput mode: further stream/buffer sets on the same device (pf_novel_view_batch_dev)
   int* h_gate = nullptr; int* d_gate = nullptr; int gate_epoch = 0;   // mapped pinned: per-level gate boxes + count + epoch flag (k_gate_bbox_all)
   int* h_status = nullptr;              // mapped pinned host word: bit d set = a sweep band of direction d timed out
@@ -203,12 +206,13 @@ struct LevelBufs { float *flow_a, *flow_b, *blurred, *tmp, *rec; };
 // box = bounding box (min x, min y, max x, max y) of the gated pixels of this level, or nullptr for "everything"
 void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, const float* a0, const float* a1, const uint8_t* gate, int w, int h, int sparse,
                const int* box, const LevelBufs& b, unsigned long long* bnd_fwd, unsigned long long* bnd_bwd, int* ctrl_fwd, int* ctrl_bwd, float** result,
-               int* pc_fwd = nullptr, int* pc_bwd = nullptr, const float* ups_src = nullptr, int ups_w = 0, int ups_h = 0) {
+               int* pc_fwd = nullptr, int* pc_bwd = nullptr, const float* ups_src = nullptr, int ups_w = 0, int ups_h = 0, Batch bt = Batch()) {
   // ups_src: flow_a does not hold this level's incoming flow yet -- it is the upsample of the coarser level's result (ups_w x ups_h),
   // computed by the Gaussian's tile loader on the way (small levels: one launch instead of two)
-  if (ups_src) { PROF(c, st, "gauss15_blurredFlow"); launch_gauss15_upsample(st, ups_src, ups_w, ups_h, 1.0f / kPyrScaleFactor, b.flow_a, b.blurred, w, h, c->g15); }
-  else { PROF(c, st, "gauss15_blurredFlow"); launch_gauss15(st, b.flow_a, b.tmp, b.blurred, w, h, c->g15); }
+  if (ups_src) { PROF(c, st, "gauss15_blurredFlow"); launch_gauss15_upsample(st, ups_src, ups_w, ups_h, 1.0f / kPyrScaleFactor, b.flow_a, b.blurred, w, h, c->g15, bt); }
+  else { PROF(c, st, "gauss15_blurredFlow"); launch_gauss15(st, b.flow_a, b.tmp, b.blurred, w, h, c->g15, bt); }
   SweepArgs sa;
+  sa.bt = bt;
   sa.g0 = reinterpret_cast<const float2*>(g0); sa.g1 = reinterpret_cast<const float2*>(g1);
   sa.blurred = reinterpret_cast<const float2*>(b.blurred); sa.gate = gate; sa.W = w; sa.H = h; sa.sparse = sparse;
   if (box) { sa.ax0 = box[0]; sa.ay0 = box[1]; sa.ax1 = box[2] + 1; sa.ay1 = box[3] + 1; }   // empty (max < min): the sweeps are the identity
@@ -233,17 +237,17 @@ void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, cons
     if (launched) c->prof_pending.push_back(p); else { c->ev_pool.push_back(p.a); c->ev_pool.push_back(p.b); }
   };
   { sa.flow = reinterpret_cast<float2*>(b.flow_a); sa.boundary = bnd_fwd; sa.ctrl = ctrl_fwd; sa.prepcnt = pc_fwd; sa.forward = 1; sweep(sa); }
-  { PROF(c, st, "median5"); launch_median5(st, b.flow_a, b.flow_b, w, h); }
+  { PROF(c, st, "median5"); launch_median5(st, b.flow_a, b.flow_b, w, h, bt); }
   { sa.flow = reinterpret_cast<float2*>(b.flow_b); sa.boundary = bnd_bwd; sa.ctrl = ctrl_bwd; sa.prepcnt = pc_bwd; sa.forward = 0; sweep(sa); }
   if ((long)w * h <= fuse_small_px(c)) {
     // throughput mode, small levels: the second median rides in the diffusion's tile loader (one launch fewer; result in b.tmp,
     // which nothing else uses: it must not be flow_a, the plane the next level's incoming flow is written to)
-    PROF(c, st, "gauss15_diffusion"); launch_median_gauss15_mix(st, b.flow_b, a0, a1, w, h, c->g15, b.tmp);
+    PROF(c, st, "gauss15_diffusion"); launch_median_gauss15_mix(st, b.flow_b, a0, a1, w, h, c->g15, b.tmp, bt);
     *result = b.tmp;
     return;
   }
-  { PROF(c, st, "median5"); launch_median5(st, b.flow_b, b.flow_a, w, h); }
-  { PROF(c, st, "gauss15_diffusion"); launch_gauss15_mix(st, b.flow_a, b.tmp, a0, a1, w, h, c->g15, b.flow_b); }
+  { PROF(c, st, "median5"); launch_median5(st, b.flow_b, b.flow_a, w, h, bt); }
+  { PROF(c, st, "gauss15_diffusion"); launch_gauss15_mix(st, b.flow_a, b.tmp, a0, a1, w, h, c->g15, b.flow_b, bt); }
   *result = b.flow_b;
 }
 
@@ -268,16 +272,31 @@ struct SolveBufs {
   std::vector<size_t> bnd_off; size_t bnd_total;
   LevelBufs lb[2]; unsigned long long* bnd[2]; int* ctrl[2]; float* ratio[2];
   int* prepcnt[2]; std::vector<size_t> pc_off; size_t pc_total;   // per sweep launch: one "records ready" counter per sweep workgroup
+  int* gate_work = nullptr;     // batch slabs only: this pair's work area of k_gate_bbox_all (a lone solve uses the context's "gate_work")
+  float* nv_flow[2] = {nullptr, nullptr};   // batch slabs only: internal flow planes for pairs whose caller does not want the flows
 };
-int alloc_solve(pf_ctx* c, const Geometry& g, int ndirs, SolveBufs& b) {
+// Where a solve's buffers come from: the context's named grow-only arena (a lone solve), or -- for a batch of pairs solved by the same
+// launches -- one slab per pair, all with the same layout and `stride` bytes apart, so that a kernel reaches pair z's copy of any buffer
+// by adding z * stride to pair 0's pointer (pf_common.hpp: Batch).  base == nullptr is the sizing pass.
+struct Carver {
+  pf_ctx* c; bool slab; char* base; size_t off;
+  void* get(const char* name, size_t bytes) {
+    if (!slab) return ensure(c, name, bytes);
+    const size_t o = off;
+    off += (bytes + 255) & ~size_t(255);
+    return base ? static_cast<void*>(base + o) : reinterpret_cast<void*>(size_t(256));   // sizing pass: any non-null value
+  }
+};
+int alloc_solve(Carver& cv, const Geometry& g, int ndirs, SolveBufs& b) {
+  pf_ctx* c = cv.c;
   const size_t n0 = size_t(g.w0) * g.h0;
   const char* nI[2] = {"pyrI0", "pyrI1"}; const char* nA[2] = {"pyrA0", "pyrA1"}; const char* nG[2] = {"grad0", "grad1"};
   for (int i = 0; i < 2; ++i) {
-    b.pyrI[i] = (float*)ensure(c, nI[i], g.P * 4); b.pyrA[i] = (float*)ensure(c, nA[i], g.P * 4); b.grad[i] = (float*)ensure(c, nG[i], g.P * 8);
+    b.pyrI[i] = (float*)cv.get(nI[i], g.P * 4); b.pyrA[i] = (float*)cv.get(nA[i], g.P * 4); b.grad[i] = (float*)cv.get(nG[i], g.P * 8);
     if (!b.pyrI[i] || !b.pyrA[i] || !b.grad[i]) return PF_ERR_NOMEM;
   }
-  b.gate = (uint8_t*)ensure(c, "gate", g.P);
-  b.half_tmp = (float*)ensure(c, "half_tmp", n0 * 4);
+  b.gate = (uint8_t*)cv.get("gate", g.P);
+  b.half_tmp = (float*)cv.get("half_tmp", n0 * 4);
   if (!b.gate || !b.half_tmp) return PF_ERR_NOMEM;
   // hand-off rows + control words of every sweep launch of this solve
   b.bnd_off.assign(g.n, 0);
@@ -289,18 +308,43 @@ int alloc_solve(pf_ctx* c, const Geometry& g, int ndirs, SolveBufs& b) {
   const char* nb[2][8] = {{"d0_flow_a", "d0_flow_b", "d0_blurred", "d0_tmp", "d0_bnd", "d0_ctrl", "d0_ratio", "d0_rec"},
                           {"d1_flow_a", "d1_flow_b", "d1_blurred", "d1_tmp", "d1_bnd", "d1_ctrl", "d1_ratio", "d1_rec"}};
   for (int d = 0; d < ndirs; ++d) {
-    b.lb[d].flow_a = (float*)ensure(c, nb[d][0], n0 * 8); b.lb[d].flow_b = (float*)ensure(c, nb[d][1], n0 * 8);
-    b.lb[d].blurred = (float*)ensure(c, nb[d][2], n0 * 8); b.lb[d].tmp = (float*)ensure(c, nb[d][3], n0 * 8);
-    b.bnd[d] = (unsigned long long*)ensure(c, nb[d][4], b.bnd_total * 2 * 8);
-    b.ctrl[d] = (int*)ensure(c, nb[d][5], size_t(g.n) * 2 * 2 * sizeof(int));
-    b.ratio[d] = (float*)ensure(c, nb[d][6], 256);
-    b.prepcnt[d] = (int*)ensure(c, d == 0 ? "d0_prepcnt" : "d1_prepcnt", b.pc_total * sizeof(int));
+    b.lb[d].flow_a = (float*)cv.get(nb[d][0], n0 * 8); b.lb[d].flow_b = (float*)cv.get(nb[d][1], n0 * 8);
+    b.lb[d].blurred = (float*)cv.get(nb[d][2], n0 * 8); b.lb[d].tmp = (float*)cv.get(nb[d][3], n0 * 8);
+    b.bnd[d] = (unsigned long long*)cv.get(nb[d][4], b.bnd_total * 2 * 8);
+    b.ctrl[d] = (int*)cv.get(nb[d][5], size_t(g.n) * 2 * 2 * sizeof(int));
+    b.ratio[d] = (float*)cv.get(nb[d][6], 256);
+    b.prepcnt[d] = (int*)cv.get(d == 0 ? "d0_prepcnt" : "d1_prepcnt", b.pc_total * sizeof(int));
     if (!b.prepcnt[d]) return PF_ERR_NOMEM;
-    b.lb[d].rec = (float*)ensure(c, nb[d][7], sweep2_rec_bytes(g.w0, g.h0));
+    b.lb[d].rec = (float*)cv.get(nb[d][7], sweep2_rec_bytes(g.w0, g.h0));
     if (!b.lb[d].rec) return PF_ERR_NOMEM;
     if (!b.lb[d].flow_a || !b.lb[d].flow_b || !b.lb[d].blurred || !b.lb[d].tmp || !b.bnd[d] || !b.ctrl[d] || !b.ratio[d]) return PF_ERR_NOMEM;
   }
-  if (!ensure(c, "gate_box", size_t(kLevelTableMax) * 4 * sizeof(int)) || !ensure(c, "gate_count", 256)) return PF_ERR_NOMEM;
+  if (cv.slab) {
+    b.gate_work = (int*)cv.get("gate_work", (4 * kLevelTableMax + 2) * sizeof(int));
+    for (int d = 0; d < 2; ++d) b.nv_flow[d] = (float*)cv.get(d ? "nv_flow_r2l" : "nv_flow_l2r", size_t(g.cols) * g.rows * 8);
+  } else if (!ensure(c, "gate_box", size_t(kLevelTableMax) * 4 * sizeof(int)) || !ensure(c, "gate_count", 256)) return PF_ERR_NOMEM;
+  (void)c;
+  return 0;
+}
+int alloc_solve(pf_ctx* c, const Geometry& g, int ndirs, SolveBufs& b) { Carver cv{c, false, nullptr, 0}; return alloc_solve(cv, g, ndirs, b); }
+// slabs of a batch of nb pairs: returns pair 0's buffers and the slab stride
+int alloc_solve_batch(pf_ctx* c, const Geometry& g, int nb, SolveBufs& b, size_t& stride) {
+  Carver sizing{c, true, nullptr, 0};
+  if (int e = alloc_solve(sizing, g, 2, b)) return e;
+  stride = (sizing.off + 4095) & ~size_t(4095);
+  const bool fresh = c->bufs.find("batch_slab") == c->bufs.end() || c->bufs["batch_slab"].cap < stride * size_t(nb);
+  char* base = (char*)ensure(c, "batch_slab", stride * size_t(nb));
+  if (!base) return PF_ERR_NOMEM;
+  Carver cv{c, true, base, 0};
+  if (int e = alloc_solve(cv, g, 2, b)) return e;
+  if (fresh || c->slab_stride != stride || c->slab_pairs < nb) {   // new memory or a new layout: (re)initialise the self-resetting work areas
+    std::vector<int> init(4 * kLevelTableMax + 2, 0);
+    for (int l = 0; l < kLevelTableMax; ++l) { init[4 * l] = 0x7fffffff; init[4 * l + 1] = 0x7fffffff; init[4 * l + 2] = -1; init[4 * l + 3] = -1; }
+    for (int p = 0; p < nb; ++p)
+      if (hipMemcpy(reinterpret_cast<char*>(b.gate_work) + size_t(p) * stride, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(c, PF_ERR_DEVICE, "initialising the batch slabs failed");
+    c->slab_stride = stride; c->slab_pairs = nb;
+  }
   return 0;
 }
 
@@ -317,8 +361,9 @@ int* gate_work(pf_ctx* c) {
 }
 // Host side of k_gate_bbox_all: poll the epoch flag in mapped pinned memory (microseconds) instead of synchronising the
 // stream; boxes (4 ints per level) and the level-0 count are then already in host memory.
-int wait_gate_boxes(pf_ctx* c, hipStream_t st, int epoch, int nlevels, std::vector<int>& box, unsigned& count0) {
-  volatile int* flag = c->h_gate + 4 * kLevelTableMax + 1;
+int wait_gate_boxes(pf_ctx* c, hipStream_t st, int epoch, int nlevels, std::vector<int>& box, unsigned& count0, int pair = 0) {
+  const int* hg = c->h_gate + size_t(pair) * kGateWords;
+  volatile const int* flag = hg + 4 * kLevelTableMax + 1;
   const auto t0 = std::chrono::steady_clock::now();
   long spins = 0;
   while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != epoch) {
@@ -327,20 +372,32 @@ int wait_gate_boxes(pf_ctx* c, hipStream_t st, int epoch, int nlevels, std::vect
       if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != epoch) return fail(c, PF_ERR_DEVICE, "gate bounding boxes never arrived");
     }
   }
-  box.assign(c->h_gate, c->h_gate + size_t(nlevels) * 4);
-  count0 = (unsigned)c->h_gate[4 * kLevelTableMax];
+  box.assign(hg, hg + size_t(nlevels) * 4);
+  count0 = (unsigned)hg[4 * kLevelTableMax];
   return 0;
 }
 
-// The whole solver for 1 or 2 directions on device-resident packed BGRA images.
-// dir 0: I0 = img0, I1 = img1, hint0;  dir 1: I0 = img1, I1 = img0, hint1.  out[d]: cols x rows float2 (pad cropped).
-int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int rows, int pad, int max_pct, int ndirs, const int* hints,
-          float* const* d_out) {
+// The whole solver for 1 or 2 directions on device-resident packed BGRA images, for nb same-size pairs at once.
+// dir 0: I0 = img0, I1 = img1, hint0;  dir 1: I0 = img1, I1 = img0, hint1.  out[p * 2 + d]: cols x rows float2 (pad cropped).
+// nb == 1: the context's arena.  nb > 1 (throughput mode): the pairs' buffers are slabs of one layout, every kernel covers all pairs
+// (blockIdx.z = pair) -- ONE kernel boundary per step of the algorithm for nb pairs; the sweeps of a level share one window, the
+// union of the pairs' bounding boxes (a sweep over a larger window gives the same result: pixels outside a pair's own box are not
+// gated and keep their flow).
+int solve_n(pf_ctx* c, int nb, const uint8_t* const* d_img0, const uint8_t* const* d_img1, int cols, int rows, int pad, int max_pct, int ndirs, const int* hints,
+            float* const* d_out, float** used_out = nullptr /* [nb * 2]: where each flow went (a NULL d_out entry of a batch = a plane inside the pair's slab) */) {
   if (int e = check_dims(c, cols, rows, pad)) return e;
   if (max_pct < 0 || max_pct > 100) return fail(c, PF_ERR_ARG, "max_percentage %d out of range", max_pct);
+  if (nb < 1 || nb > kMaxBatch) return fail(c, PF_ERR_ARG, "batch of %d pairs (1..%d)", nb, kMaxBatch);
   const Geometry g = make_geometry(cols, rows, pad);
   SolveBufs sb;
-  if (int e = alloc_solve(c, g, ndirs, sb)) return e;
+  Batch bt;
+  if (nb == 1) { if (int e = alloc_solve(c, g, ndirs, sb)) return e; }
+  else {
+    if (g.n > kLevelTableMax || g.P >= (size_t(1) << 31)) return fail(c, PF_ERR_ARG, "image too large for a batched solve");
+    size_t stride = 0;
+    if (int e = alloc_solve_batch(c, g, nb, sb, stride)) return e;
+    bt.n = nb; bt.stride = stride;
+  }
   float** pyrI = sb.pyrI; float** pyrA = sb.pyrA; float** grad = sb.grad;
   uint8_t* gate = sb.gate; float* half_tmp = sb.half_tmp;
   const std::vector<size_t>& bnd_off = sb.bnd_off; const size_t bnd_total = sb.bnd_total;
@@ -350,11 +407,12 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   // --- shared front end on the main stream: half-res planes, pyramids, gradients + gate of ALL levels.
   // (Measured and rejected: the alpha path on a second stream -- alpha pyramids, gate, boxes beside the grey path: +0.3 ms
   // per pair with 72 instead of 36 small pyramid launches in front of the boxes; profiles/r02_frontend_ab.txt.) ---
-  const uint8_t* imgs[2] = {d_img0, d_img1};
   hipStream_t sg = sm;
   for (int i = 0; i < 2; ++i) {
-    { PROF(c, sm, "downscale_gray"); launch_downscale_gray(sm, imgs[i], cols, rows, pad, half_tmp, pyrA[i], g.w0, g.h0); }
-    { PROF(c, sm, "preblur5"); launch_gauss_small(sm, half_tmp, pyrI[i], g.w0, g.h0, 1, c->g5); }
+    ExtPtrs imgs{};
+    for (int p = 0; p < nb; ++p) imgs.p[p] = i ? d_img1[p] : d_img0[p];
+    { PROF(c, sm, "downscale_gray"); launch_downscale_gray(sm, nullptr, cols, rows, pad, half_tmp, pyrA[i], g.w0, g.h0, bt, &imgs); }
+    { PROF(c, sm, "preblur5"); launch_gauss_small(sm, half_tmp, pyrI[i], g.w0, g.h0, 1, c->g5, bt); }
   }
   // pyramids: one launch per level while the levels are large, then two and three levels per launch (the chain of dependent
   // ~5 us launches is otherwise ~0.2 ms in front of everything; kernels_pre.hip: k_pyr_chain)
@@ -366,9 +424,9 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
     if (chainMode) { if (px <= 40000 && l + 2 < g.n) k = 3; else if (px <= 160000 && l + 1 < g.n) k = 2; }
     if (k == 1)
       launch_pyr_down4(sm, pyrI[0] + g.off[l - 1], pyrI[1] + g.off[l - 1], pyrA[0] + g.off[l - 1], pyrA[1] + g.off[l - 1], g.ws[l - 1], g.hs[l - 1],
-                       pyrI[0] + g.off[l], pyrI[1] + g.off[l], pyrA[0] + g.off[l], pyrA[1] + g.off[l], g.ws[l], g.hs[l]);
+                       pyrI[0] + g.off[l], pyrI[1] + g.off[l], pyrA[0] + g.off[l], pyrA[1] + g.off[l], g.ws[l], g.hs[l], bt);
     else
-      launch_pyr_chain4(sm, pyrI[0], pyrI[1], pyrA[0], pyrA[1], g.ws.data(), g.hs.data(), g.off.data(), l - 1, k);
+      launch_pyr_chain4(sm, pyrI[0], pyrI[1], pyrA[0], pyrA[1], g.ws.data(), g.hs.data(), g.off.data(), l - 1, k, bt);
     l += k;
   }
   // The host needs the per-level bounding boxes of the gate (they size the sweep launches) and the level-0 gate count (dense
@@ -383,13 +441,13 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   if (g.n <= kLevelTableMax && g.P < (size_t(1) << 31)) {
     LevelTable t; t.n = g.n;
     for (int l = 0; l < g.n; ++l) { t.w[l] = g.ws[l]; t.h[l] = g.hs[l]; t.off[l] = (unsigned)g.off[l]; }
-    int* work = gate_work(c);
+    int* work = nb == 1 ? gate_work(c) : sb.gate_work;
     if (!work) return PF_ERR_NOMEM;
     epoch = ++c->gate_epoch;
-    { PROF(c, sg, "gate"); launch_gate_bbox_all(sg, pyrA[0], pyrA[1], gate, t, g.P, work, c->d_gate, epoch); }
+    { PROF(c, sg, "gate"); launch_gate_bbox_all(sg, pyrA[0], pyrA[1], gate, t, g.P, work, c->d_gate, epoch, bt, kGateWords * sizeof(int)); }
     // gradients: the coarse levels first (a few percent of the pixels) -- the directions start on those -- the fine levels in a
     // second launch that runs while the coarse levels are already being solved (ev_fine, waited for at level split - 1)
-    { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], t, g.off[split], g.P, c->g3_05); }
+    { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], t, g.off[split], g.P, c->g3_05, 0, bt); }
     have_table = true; table = t;
   } else {
     for (int l = 0; l < g.n; ++l) {
@@ -401,9 +459,9 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   }
   for (int d = 0; d < ndirs; ++d) {
     PROF(c, sm, "init_handoff");
-    launch_fill_u64(sm, bnd[d], bnd_total * 2, kNotReady);
-    HIPCHK(c, hipMemsetAsync(ctrl[d], 0, size_t(g.n) * 2 * 2 * sizeof(int), sm));
-    HIPCHK(c, hipMemsetAsync(sb.prepcnt[d], 0, sb.pc_total * sizeof(int), sm));
+    launch_fill_u64(sm, bnd[d], bnd_total * 2, kNotReady, bt);
+    launch_fill_u32(sm, reinterpret_cast<unsigned*>(ctrl[d]), size_t(g.n) * 2 * 2, 0u, bt);
+    launch_fill_u32(sm, reinterpret_cast<unsigned*>(sb.prepcnt[d]), sb.pc_total, 0u, bt);
   }
   HIPCHK(c, hipEventRecord(c->ev_pre, sm));
   // Fine levels in two launches behind the coarse ones: levels [split2, split) at full width (needed first, a quarter of the fine
@@ -411,12 +469,25 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
   // needed for milliseconds; at full width it took every wave slot of the chip and slowed the first sweeps several times over.
   const int fineBlocks = c->cfg.fine_gradient_blocks;
   const int split2 = split > 4 ? 4 : 0;
-  if (have_table && split > 0) { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], table, g.off[split2], g.off[split], c->g3_05); }
+  if (have_table && split > 0) { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], table, g.off[split2], g.off[split], c->g3_05, 0, bt); }
   HIPCHK(c, hipEventRecord(c->ev_fine, sm));
-  if (have_table && split2 > 0) { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], table, 0, g.off[split2], c->g3_05, fineBlocks); }
+  if (have_table && split2 > 0) { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], table, 0, g.off[split2], c->g3_05, fineBlocks, bt); }
   HIPCHK(c, hipEventRecord(c->ev_fine2, sm));
+  double area0 = (double)g.ws[0] * g.hs[0];   // the sweeps only cover the window of gated pixels: density inside that window is what counts
   if (have_table) {
-    if (int e = wait_gate_boxes(c, sg, epoch, g.n, boxes, h_cnt)) return e;
+    // one set of boxes per pair; a batch sweeps the union (a superset of each pair's own window: same results)
+    for (int p = 0; p < nb; ++p) {
+      std::vector<int> bp; unsigned cnt = 0;
+      if (int e = wait_gate_boxes(c, sg, epoch, g.n, bp, cnt, p)) return e;
+      h_cnt += cnt;
+      if (p == 0) boxes = bp;
+      else for (int l = 0; l < g.n; ++l) {
+        if (bp[4 * l + 2] < bp[4 * l] || bp[4 * l + 3] < bp[4 * l + 1]) continue;                          // this pair gates nothing at level l
+        if (boxes[4 * l + 2] < boxes[4 * l] || boxes[4 * l + 3] < boxes[4 * l + 1]) { for (int k = 0; k < 4; ++k) boxes[4 * l + k] = bp[4 * l + k]; continue; }
+        boxes[4 * l] = std::min(boxes[4 * l], bp[4 * l]); boxes[4 * l + 1] = std::min(boxes[4 * l + 1], bp[4 * l + 1]);
+        boxes[4 * l + 2] = std::max(boxes[4 * l + 2], bp[4 * l + 2]); boxes[4 * l + 3] = std::max(boxes[4 * l + 3], bp[4 * l + 3]);
+      }
+    }
     if (!c->cfg.sweep_window) boxes.clear();
   } else {
     unsigned* d_cnt = (unsigned*)ensure(c, "gate_count", 256);
@@ -426,9 +497,8 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
     HIPCHK(c, hipMemcpyAsync(&h_cnt, d_cnt, 4, hipMemcpyDeviceToHost, sg));
     HIPCHK(c, hipStreamSynchronize(sg));
   }
-  double area0 = (double)g.ws[0] * g.hs[0];   // the sweeps only cover the window of gated pixels: density inside that window is what counts
   if (!boxes.empty() && boxes[2] >= boxes[0] && boxes[3] >= boxes[1]) area0 = double(boxes[2] - boxes[0] + 1) * double(boxes[3] - boxes[1] + 1);
-  int sparse = (double)h_cnt < 0.5 * area0 ? 1 : 0;
+  int sparse = (double)h_cnt < 0.5 * area0 * nb ? 1 : 0;
   if (c->cfg.sparse_sweep >= 0) sparse = c->cfg.sparse_sweep ? 1 : 0;   // forced variant: results are identical either way
   // critical path of the exact sweeps given the windows: (w + h - 1) anti-diagonals per sweep, two sweeps per level
   c->last_swept_steps = 0;
@@ -457,10 +527,10 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
     const int w = g.ws[level], h = g.hs[level];
     const size_t o = g.off[level];
     if (level == g.n - 1) {
-      hipMemsetAsync(b.flow_a, 0, size_t(w) * h * 8, st);  // PixFlow.hpp:298
+      launch_fill_u32(st, reinterpret_cast<unsigned*>(b.flow_a), size_t(w) * h * 2, 0u, bt);  // PixFlow.hpp:298
       if (max_pct > 0 && hints[d] != PF_HINT_UNKNOWN) {
         PROF(c, st, "adjust_initial_flow");
-        launch_adjust_initial_flow(st, pyrI[i0] + o, pyrI[i1] + o, pyrA[i0] + o, pyrA[i1] + o, w, h, hints[d], max_pct, ratio[d], b.flow_a);
+        launch_adjust_initial_flow(st, pyrI[i0] + o, pyrI[i1] + o, pyrA[i0] + o, pyrA[i1] + o, w, h, hints[d], max_pct, ratio[d], b.flow_a, bt);
       }
     }
     float* res = nullptr;
@@ -470,16 +540,23 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
               bnd[d] + bnd_off[level],
               bnd[d] + bnd_total + bnd_off[level], ctrl[d] + level * 4, ctrl[d] + level * 4 + 2, &res,
               sb.prepcnt[d] + sb.pc_off[level], sb.prepcnt[d] + sb.pc_off[level] + sweep2_num_wgs_max(w, h),
-              upsHere ? prev_res[d] : nullptr, upsHere ? g.ws[level + 1] : 0, upsHere ? g.hs[level + 1] : 0);
+              upsHere ? prev_res[d] : nullptr, upsHere ? g.ws[level + 1] : 0, upsHere ? g.hs[level + 1] : 0, bt);
     prev_res[d] = res;
     if (level > 0) {
       if (!fuse_ups(level - 1)) {
         PROF(c, st, "upsample_cubic");
-        launch_upsample_cubic(st, res, w, h, b.flow_a, g.ws[level - 1], g.hs[level - 1], 1.0f / kPyrScaleFactor);
+        launch_upsample_cubic(st, res, w, h, b.flow_a, g.ws[level - 1], g.hs[level - 1], 1.0f / kPyrScaleFactor, bt);
       }
     } else {
       PROF(c, st, "final_flow");
-      launch_final_flow(st, res, w, h, g.ce, rows, pad, 1.0f / kDownscaleFactor, c->g3_1, d_out[d]);
+      ExtPtrs outs{};
+      for (int p = 0; p < nb; ++p) {
+        float* o = d_out[p * 2 + d];
+        if (!o && nb > 1) o = reinterpret_cast<float*>(reinterpret_cast<char*>(sb.nv_flow[d]) + size_t(p) * bt.stride);
+        outs.p[p] = o;
+        if (used_out) used_out[p * 2 + d] = o;
+      }
+      launch_final_flow(st, res, w, h, g.ce, rows, pad, 1.0f / kDownscaleFactor, c->g3_1, nullptr, bt, &outs);
     }
   };
   // (Measured and rejected: one host thread per direction -- +0.1 ms per pair; the GPU, not the host, paces the launches.)
@@ -508,12 +585,17 @@ int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int
       for (int d = 0; d < ndirs; ++d) enqueue_level(d, level);
   }
   for (int d = 0; d < ndirs; ++d) {
-    launch_collect_status(c->s_dir[d], ctrl[d], g.n * 4, c->d_status, 1 << d);
+    launch_collect_status(c->s_dir[d], ctrl[d], g.n * 4, c->d_status, 1 << d, bt);
     HIPCHK(c, hipEventRecord(c->ev_dir[d], c->s_dir[d]));
     HIPCHK(c, hipStreamWaitEvent(sm, c->ev_dir[d], 0));
   }
   HIPCHK(c, hipGetLastError());
   return 0;
+}
+int solve(pf_ctx* c, const uint8_t* d_img0, const uint8_t* d_img1, int cols, int rows, int pad, int max_pct, int ndirs, const int* hints,
+          float* const* d_out) {
+  float* outs[2] = {d_out[0], ndirs > 1 ? d_out[1] : nullptr};
+  return solve_n(c, 1, &d_img0, &d_img1, cols, rows, pad, max_pct, ndirs, hints, outs);
 }
 
 // after the streams have drained: did any sweep band give up?  (the word lives in mapped pinned host memory and was
@@ -590,7 +672,7 @@ void pf_config_init(pf_config* cfg) {
   memset(cfg, 0, sizeof *cfg);
   cfg->struct_size = (int)sizeof *cfg;
   cfg->stagger_levels = -1; cfg->fuse_small_level_px = -1; cfg->fine_gradient_blocks = 64; cfg->pyramid_chaining = 1;
-  cfg->sweep_window = 1; cfg->sparse_sweep = -1; cfg->sweep_impl = 2; cfg->record_path = 0;
+  cfg->sweep_window = 1; cfg->sparse_sweep = -1; cfg->sweep_impl = 2; cfg->record_path = 0; cfg->batch_pairs = -1;
 }
 
 pf_ctx* pf_create(int device, int max_cols, int max_rows) {
@@ -629,9 +711,9 @@ pf_ctx* create_ctx(const pf_config& cfg, bool lane) {
        hipEventCreateWithFlags(&c->ev_stagger, hipEventDisableTiming) == hipSuccess;
   for (int d = 0; d < 2 && ok; ++d) ok = hipEventCreateWithFlags(&c->ev_dir[d], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&c->h_status, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void**)&c->d_status, c->h_status, 0) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&c->h_gate, (4 * kLevelTableMax + 2) * sizeof(int), hipHostMallocMapped) == hipSuccess &&
+  ok = ok && hipHostMalloc((void**)&c->h_gate, kMaxBatch * kGateWords * sizeof(int), hipHostMallocMapped) == hipSuccess &&   // one area per pair of a batch
        hipHostGetDevicePointer((void**)&c->d_gate, c->h_gate, 0) == hipSuccess;
-  if (ok) { *c->h_status = 0; memset(c->h_gate, 0, (4 * kLevelTableMax + 2) * sizeof(int)); }
+  if (ok) { *c->h_status = 0; memset(c->h_gate, 0, kMaxBatch * kGateWords * sizeof(int)); }
   if (!ok) { fail(nullptr, PF_ERR_DEVICE, "stream/event creation failed"); delete c; return nullptr; }
   c->cfg = cfg;
   c->g5 = make_gauss(5, 0.25); c->g3_05 = make_gauss(3, 0.5); c->g3_1 = make_gauss(3, 1.0); c->g15 = make_gauss(15, 8.0);
@@ -674,6 +756,7 @@ pf_ctx* pf_create_cfg(const pf_config* user) {
     return nullptr;
   }
 #endif
+  if (cfg.batch_pairs == 0 || cfg.batch_pairs < -1 || cfg.batch_pairs > kMaxBatch) { fail(nullptr, PF_ERR_ARG, "pf_create_cfg: batch_pairs must be -1 or 1..%d", kMaxBatch); return nullptr; }
   if (cfg.fine_gradient_blocks < 1 || cfg.stagger_levels < -1 || cfg.fuse_small_level_px < -1 || cfg.sparse_sweep < -1 || cfg.sparse_sweep > 1) {
     fail(nullptr, PF_ERR_ARG, "pf_create_cfg: knob out of range");
     return nullptr;
@@ -808,10 +891,47 @@ int pf_novel_view_dev(pf_ctx* c, const uint8_t* d_l, const uint8_t* d_r, int col
 
 // ---- throughput mode ----
 // One pair keeps ~70 workgroups of a sweep busy (two directions x ~35 bands-of-4): the exact sweeps are a dependency chain, so
-// most of the 256 CUs idle.  When pairs are plentiful, `in_flight` of them run side by side on the same GPU, each on its
-// own stream / buffer set ("lane", created on first use and kept) driven by its own host thread; pair i goes to lane
-// i % in_flight.  Results are identical to n_pairs calls of pf_novel_view_dev.  Set GPU_MAX_HW_QUEUES >= 4 * in_flight
-// before the first HIP call (the runtime's default of 4 hardware queues would serialise the lanes' streams).
+// most of the 256 CUs idle.  When pairs are plentiful, `in_flight` of them are on the GPU at the same time, in two ways that combine:
+//   * BATCHES (round 3): B pairs go through the SAME launches (blockIdx.z = pair, solve_n): one kernel boundary per step of the
+//     algorithm for B pairs.  With several independent streams the kernels themselves barely slow down, but the gap between a
+//     stream's dependent kernels grows with the number of busy hardware queues (2.7 -> 23 us per launch from 1 to 2 pairs in
+//     flight, profiles/r02_throughput_mode.txt); a batch pays each gap once for B pairs;
+//   * LANES: further stream / buffer sets on the same device ("lane", created on first use and kept), each driven by its own host
+//     thread and each working through its own batches, out of phase with the others.
+// in_flight = lanes x pairs per batch; pf_config::batch_pairs picks the split (-1: see batch_split()).  Results are identical to
+// n_pairs calls of pf_novel_view_dev.  Set GPU_MAX_HW_QUEUES >= 3 * lanes + 2 before the first HIP call.
+namespace {
+void batch_split(const pf_ctx* c, int in_flight, int& lanes, int& per_batch) {
+  // measured (24 strips of 2000x4000, Mpix/s, tests/micro/tp_batch_sweep.sh): 6 in flight as 6 lanes 838, 3 x 2 911, 2 x 3 974, one batch of 6 1071;
+  // 8 in flight as 4 x 2 1032, 2 x 4 1131, one batch of 8 1237; 12 = 2 lanes x 6 1326; 16 = 2 x 8 1368: the fewest lanes win
+  per_batch = c->cfg.batch_pairs > 0 ? c->cfg.batch_pairs : (in_flight <= kMaxBatch ? in_flight : (in_flight + 1) / 2);
+  if (per_batch > kMaxBatch) per_batch = kMaxBatch;
+  if (per_batch > in_flight) per_batch = in_flight;
+  lanes = (in_flight + per_batch - 1) / per_batch;
+}
+// one batch: pairs [first, first + count) of the arrays through one set of launches on `lane`
+int novel_view_group(pf_ctx* lane, int first, int count, const uint8_t* const* d_l, const uint8_t* const* d_r, int cols, int rows, int max_pct,
+                     const float* const* d_blend, uint8_t* const* d_out, float* const* d_l2r, float* const* d_r2l) {
+  if (count == 1)
+    return pf_novel_view_dev(lane, d_l[first], d_r[first], cols, rows, max_pct, d_blend[first], d_out[first], d_l2r ? d_l2r[first] : nullptr, d_r2l ? d_r2l[first] : nullptr);
+  if (int e = use(lane)) return e;
+  CallGuard guard_(lane);
+  if (int e = check_dims(lane, cols, rows, cols / 20)) return e;
+  float* outs[2 * kMaxBatch]; float* used[2 * kMaxBatch];
+  for (int p = 0; p < count; ++p) {
+    if (!d_l[first + p] || !d_r[first + p] || !d_blend[first + p] || !d_out[first + p]) return fail(lane, PF_ERR_ARG, "null device pointer (pair %d)", first + p);
+    outs[2 * p] = d_l2r ? d_l2r[first + p] : nullptr; outs[2 * p + 1] = d_r2l ? d_r2l[first + p] : nullptr;
+  }
+  const int hints[2] = {PF_HINT_LEFT, PF_HINT_RIGHT};
+  if (int e = solve_n(lane, count, d_l + first, d_r + first, cols, rows, cols / 20, max_pct, 2, hints, outs, used)) return e;
+  BlendPtrs bp{};
+  for (int p = 0; p < count; ++p) { bp.L[p] = d_l[first + p]; bp.R[p] = d_r[first + p]; bp.fLR[p] = used[2 * p]; bp.fRL[p] = used[2 * p + 1]; bp.blend[p] = d_blend[first + p]; bp.out[p] = d_out[first + p]; }
+  { PROF(lane, lane->s_main, "blend"); launch_blend_batch(lane->s_main, bp, count, cols, rows); }
+  HIPCHK(lane, hipGetLastError());
+  if (int e = finish(lane)) return e;
+  return check_sweeps(lane);
+}
+}  // namespace
 int pf_novel_view_batch_dev(pf_ctx* c, int n_pairs, const uint8_t* const* d_l, const uint8_t* const* d_r, int cols, int rows, int max_pct,
                             const float* const* d_blend, uint8_t* const* d_out, float* const* d_l2r, float* const* d_r2l, int in_flight) {
   if (int e = use(c)) return e;
@@ -819,29 +939,33 @@ int pf_novel_view_batch_dev(pf_ctx* c, int n_pairs, const uint8_t* const* d_l, c
   if (in_flight < 1) in_flight = 1;
   if (in_flight > 16) in_flight = 16;
   if (in_flight > n_pairs) in_flight = n_pairs > 0 ? n_pairs : 1;
-  while ((int)c->lanes.size() < in_flight - 1) {
-    pf_config lc = c->cfg; lc.max_cols = cols; lc.max_rows = rows;
+  int nlanes = 1, per_batch = 1;
+  batch_split(c, in_flight, nlanes, per_batch);
+  while ((int)c->lanes.size() < nlanes - 1) {
+    pf_config lc = c->cfg; lc.max_cols = per_batch > 1 ? 0 : cols; lc.max_rows = per_batch > 1 ? 0 : rows;   // a batching lane lives in its slabs: nothing to pre-size
     pf_ctx* l = create_ctx(lc, true);
     if (!l) return fail(c, PF_ERR_NOMEM, "cannot create lane %d: %s", (int)c->lanes.size() + 1, g_err.c_str());
     c->lanes.push_back(l);
   }
   for (pf_ctx* l : c->lanes) l->prof = c->prof;   // profiling covers every lane (collected into the lane's own totals)
-  std::vector<int> rc(in_flight, 0);
-  std::vector<std::string> msg(in_flight);
+  const int ngroups = (n_pairs + per_batch - 1) / per_batch;
+  std::vector<int> rc(nlanes, 0);
+  std::vector<std::string> msg(nlanes);
   auto run = [&](int k) {
     pf_ctx* lane = k == 0 ? c : c->lanes[k - 1];
     struct Restore { pf_ctx* l; long v; bool b; ~Restore() { l->fuse_ups_px = v; l->is_lane = b; } } restore{lane, lane->fuse_ups_px, lane->is_lane};
-    if (in_flight > 1) { lane->fuse_ups_px = 262144; lane->is_lane = true; }   // side by side, launches count more than their length (see solve())
-    for (int i = k; i < n_pairs; i += in_flight) {
-      const int e = pf_novel_view_dev(lane, d_l[i], d_r[i], cols, rows, max_pct, d_blend[i], d_out[i], d_l2r ? d_l2r[i] : nullptr, d_r2l ? d_r2l[i] : nullptr);
+    if (in_flight > 1) { lane->fuse_ups_px = 262144; lane->is_lane = true; }   // side by side, launches count more than their length (see solve_n())
+    for (int gidx = k; gidx < ngroups; gidx += nlanes) {
+      const int first = gidx * per_batch, count = std::min(per_batch, n_pairs - first);
+      const int e = novel_view_group(lane, first, count, d_l, d_r, cols, rows, max_pct, d_blend, d_out, d_l2r, d_r2l);
       if (e) { rc[k] = e; msg[k] = lane->err; return; }
     }
   };
   std::vector<std::thread> th;
-  for (int k = 1; k < in_flight; ++k) th.emplace_back(run, k);
+  for (int k = 1; k < nlanes; ++k) th.emplace_back(run, k);
   run(0);
   for (auto& t : th) t.join();
-  for (int k = 0; k < in_flight; ++k) if (rc[k]) return fail(c, rc[k], "lane %d: %s", k, msg[k].c_str());
+  for (int k = 0; k < nlanes; ++k) if (rc[k]) return fail(c, rc[k], "lane %d: %s", k, msg[k].c_str());
   if (c->prof)   // per-kernel-family times of the lanes are reported with the owning context's
     for (pf_ctx* l : c->lanes)
       for (size_t i = 0; i < l->prof_names.size(); ++i) {
@@ -974,6 +1098,48 @@ int pf_stitch_prepare(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, i
   if (ovl) if (int e = down2d(c, ovl, step, dol, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
   if (ovr) if (int e = down2d(c, ovr, step, dor, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
   if (blend_out) if (int e = down2d(c, blend_out, bstep, db, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
+  if (merged_dis) if (int e = down2d(c, merged_dis, size_t(cols) * 4, dmd, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
+  HIPCHK(c, hipGetLastError());
+  if (int e = finish(c)) return e;
+  return check_sweeps(c);
+}
+
+// Stitchtools::MatchImages (StitchTool.cpp:38-50) + the overlap masking of prepare() (:17-33) alone: map and the two masked images.
+int pf_stitch_match(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int rows, size_t step, uint8_t* map_out, size_t mstep, uint8_t* ovl, uint8_t* ovr) {
+  if (int e = use(c)) return e;
+  CallGuard guard_(c);
+  if (!l || !r) return fail(c, PF_ERR_ARG, "null pointer");
+  if (int e = check_image(c, cols, rows)) return e;
+  if (step < size_t(cols) * 4 || (map_out && mstep < size_t(cols))) return fail(c, PF_ERR_ARG, "row step too small");
+  const size_t n = size_t(cols) * rows;
+  uint8_t* dl = (uint8_t*)ensure(c, "h_img0", n * 4); uint8_t* dr = (uint8_t*)ensure(c, "h_img1", n * 4);
+  uint8_t* dm = (uint8_t*)ensure(c, "st_map", n); uint8_t* dol = (uint8_t*)ensure(c, "st_ovl", n * 4); uint8_t* dor = (uint8_t*)ensure(c, "st_ovr", n * 4);
+  if (!dl || !dr || !dm || !dol || !dor) return PF_ERR_NOMEM;
+  if (int e = up2d(c, dl, size_t(cols) * 4, l, step, size_t(cols) * 4, rows)) return e;
+  if (int e = up2d(c, dr, size_t(cols) * 4, r, step, size_t(cols) * 4, rows)) return e;
+  { PROF(c, c->s_main, "match_images"); launch_match_images(c->s_main, dl, dr, cols, rows, dm, dol, dor); }
+  if (map_out) if (int e = down2d(c, map_out, mstep, dm, cols, cols, rows)) return e;
+  if (ovl) if (int e = down2d(c, ovl, step, dol, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
+  if (ovr) if (int e = down2d(c, ovr, step, dor, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
+  HIPCHK(c, hipGetLastError());
+  return finish(c);
+}
+
+// Stitchtools::GenerateBlend (StitchTool.cpp:98-146) from a GIVEN map -- the reference reads its public `Map` member there, so a
+// caller that edits the map between MatchImages() and GenerateBlend() gets the ramp of the edited map.
+int pf_stitch_generate_blend(pf_ctx* c, const uint8_t* map, size_t mstep, int cols, int rows, float* blend_out, size_t bstep, float* merged_dis) {
+  if (int e = use(c)) return e;
+  CallGuard guard_(c);
+  if (!map || !blend_out) return fail(c, PF_ERR_ARG, "null pointer");
+  if (int e = check_image(c, cols, rows)) return e;
+  if (mstep < size_t(cols) || bstep < size_t(cols) * 4) return fail(c, PF_ERR_ARG, "row step too small");
+  const size_t n = size_t(cols) * rows;
+  uint8_t* dm = (uint8_t*)ensure(c, "st_map", n); float* db = (float*)ensure(c, "st_blend", n * 4); float* dmd = (float*)ensure(c, "st_md", n * 4);
+  if (!dm || !db || !dmd) return PF_ERR_NOMEM;
+  if (int e = up2d(c, dm, cols, map, mstep, cols, rows)) return e;
+  { PROF(c, c->s_main, "countblend"); launch_countblend(c->s_main, dm, cols, rows, db, dmd); }
+  if (int e = blend_smooth_dev(c, db, dmd, cols, rows)) return e;
+  if (int e = down2d(c, blend_out, bstep, db, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
   if (merged_dis) if (int e = down2d(c, merged_dis, size_t(cols) * 4, dmd, size_t(cols) * 4, size_t(cols) * 4, rows)) return e;
   HIPCHK(c, hipGetLastError());
   if (int e = finish(c)) return e;

@@ -74,14 +74,26 @@ __device__ __forceinline__ void d_resize_linear_px(const float* __restrict__ src
   }
 }
 
+// ---- batch dimension -------------------------------------------------------------------------------------------------------
+// A launch may cover `n` same-size pairs at once (throughput mode: one kernel boundary for n pairs instead of n).  The pairs'
+// working buffers lie in identically laid-out slabs `stride` bytes apart, so a kernel reaches pair z's copy of ANY internal buffer
+// by adding z * stride to the pointer it was given for pair 0 (blockIdx.z = pair; kernels that already use z for planes keep the
+// plane in its low bits).  Caller-owned buffers (input images, blend ramp, outputs) come as per-pair pointer tables instead.
+constexpr int kMaxBatch = 8;
+struct Batch { int n = 1; size_t stride = 0; };
+struct ExtPtrs { const void* p[kMaxBatch]; };   // caller-owned buffers of the pairs of a batch (read-only or written, by use)
+#define PF_BOFF(ptr, off) (ptr = reinterpret_cast<decltype(ptr)>(reinterpret_cast<uintptr_t>(ptr) + (off)))
+
 // ---- launch wrappers (defined in the kernels_*.hip files) ----
 // preprocessing
-void launch_downscale_gray(hipStream_t st, const uint8_t* bgra, int cols, int rows, int pad, float* gray, float* alpha, int dw, int dh);
-void launch_gauss_small(hipStream_t st, const float* src, float* dst, int w, int h, int cn, const Gauss& g);
+void launch_downscale_gray(hipStream_t st, const uint8_t* bgra, int cols, int rows, int pad, float* gray, float* alpha, int dw, int dh, Batch bt = Batch(),
+                           const ExtPtrs* imgs = nullptr /* batched: the pairs' input images instead of bgra */);
+void launch_gauss_small(hipStream_t st, const float* src, float* dst, int w, int h, int cn, const Gauss& g, Batch bt = Batch());
 void launch_resize_linear(hipStream_t st, const float* src, int sw, int sh, float* dst, int dw, int dh, int cn, float mul, bool do_mul);
 void launch_pyr_down4(hipStream_t st, const float* s0, const float* s1, const float* s2, const float* s3, int sw, int sh, float* d0,
-                      float* d1, float* d2, float* d3, int dw, int dh);
-void launch_pyr_chain4(hipStream_t st, float* p0, float* p1, float* p2, float* p3, const int* ws, const int* hs, const size_t* off, int first, int k);
+                      float* d1, float* d2, float* d3, int dw, int dh, Batch bt = Batch());
+void launch_pyr_chain4(hipStream_t st, float* p0, float* p1, float* p2, float* p3, const int* ws, const int* hs, const size_t* off, int first, int k,
+                       Batch bt = Batch());
 void launch_pyr_down2(hipStream_t st, const float* s0, const float* s1, int sw, int sh, float* d0, float* d1, int dw, int dh);
 // per level
 void launch_gradients(hipStream_t st, const float* img, int w, int h, float* gxy, const Gauss& g3);
@@ -91,23 +103,23 @@ struct LevelTable { int n; int w[kLevelTableMax]; int h[kLevelTableMax]; unsigne
 void launch_gate_bbox(hipStream_t st, const uint8_t* gate, const LevelTable& t, size_t total, int* box);   // box[4*l..]: min x, min y, max x, max y
 // elements [first, total) of the pyramid planes (levels lie back to back, level 0 first)
 void launch_gradients_all(hipStream_t st, const float* pyr0, const float* pyr1, float* grad0, float* grad1, const LevelTable& t, size_t first,
-                          size_t total, const Gauss& g3, int max_blocks = 0);
+                          size_t total, const Gauss& g3, int max_blocks = 0, Batch bt = Batch());
 void launch_gate(hipStream_t st, const float* a0, const float* a1, int n, uint8_t* gate);
 // gate + per-level bounding boxes + level-0 count in one launch, published to mapped pinned host memory behind an epoch flag
 // (work: 4*kLevelTableMax + 2 ints, initialised once to (INT_MAX, INT_MAX, -1, -1)*, 0, 0; host_mapped: same size)
 void launch_gate_bbox_all(hipStream_t st, const float* a0, const float* a1, uint8_t* gate, const LevelTable& t, size_t total, int* work, int* host_mapped,
-                          int epoch);
+                          int epoch, Batch bt = Batch(), size_t host_stride = 0 /* bytes between the pairs' mapped host areas */);
 void launch_count_gate(hipStream_t st, const uint8_t* gate, int n, unsigned* count /* zeroed by the caller */);
-void launch_gauss15(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const Gauss& g15);
-void launch_median_gauss15_mix(hipStream_t st, const float* flow, const float* a0, const float* a1, int w, int h, const Gauss& g15, float* out);
-void launch_gauss15_upsample(hipStream_t st, const float* coarse, int sw, int sh, float mul, float* up, float* dst, int w, int h, const Gauss& g15);
+void launch_gauss15(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const Gauss& g15, Batch bt = Batch());
+void launch_median_gauss15_mix(hipStream_t st, const float* flow, const float* a0, const float* a1, int w, int h, const Gauss& g15, float* out, Batch bt = Batch());
+void launch_gauss15_upsample(hipStream_t st, const float* coarse, int sw, int sh, float mul, float* up, float* dst, int w, int h, const Gauss& g15, Batch bt = Batch());
 void launch_gauss15_mix(hipStream_t st, float* flow, float* tmp, const float* a0, const float* a1, int w, int h, const Gauss& g15,
-                        float* out);
-void launch_median5(hipStream_t st, const float* src, float* dst, int w, int h);   // direct form below 3 Mpix, LDS-tiled form above
-void launch_median5_form(hipStream_t st, const float* src, float* dst, int w, int h, bool tiled);   // a given form at any size (tests)
-void launch_upsample_cubic(hipStream_t st, const float* src, int sw, int sh, float* dst, int dw, int dh, float mul);
+                        float* out, Batch bt = Batch());
+void launch_median5(hipStream_t st, const float* src, float* dst, int w, int h, Batch bt = Batch());   // direct form below 3 Mpix, LDS-tiled form above
+void launch_median5_form(hipStream_t st, const float* src, float* dst, int w, int h, bool tiled, Batch bt = Batch());   // a given form at any size (tests)
+void launch_upsample_cubic(hipStream_t st, const float* src, int sw, int sh, float* dst, int dw, int dh, float mul, Batch bt = Batch());
 void launch_final_flow(hipStream_t st, const float* flow0, int sw, int sh, int pad_cols, int rows, int pad, float mul, const Gauss& g3,
-                       float* out);
+                       float* out, Batch bt = Batch(), const ExtPtrs* outs = nullptr /* batched: the pairs' output planes instead of out */);
 // sweep
 struct SweepArgs {
   const float2* g0;       // (I0x,I0y) at the pixel
@@ -123,6 +135,7 @@ struct SweepArgs {
   // sweep kernel come from the dispatch packets' own timestamps), so that timing a sweep puts no marker packets on its stream
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   int* prepcnt = nullptr; // v2 sweep, prepass inside the launch: one counter per sweep workgroup (sweep2_num_wgs_max ints), ZEROED before the launch
+  Batch bt;               // v2 sweep: bt.n same-size pairs in one launch (every pointer above is pair 0's; pair z's lies z * bt.stride bytes on)
   int prep_mode = 0;      // lab build only (-DPF_EXPERIMENTS): 1 / 2 = the two rejected record paths (pf_config::record_path)
   int ax0 = 0, ay0 = 0, ax1 = 1 << 30, ay1 = 1 << 30;   // bounding box [ax0,ax1) x [ay0,ay1) of the gated pixels (default: everything); v2 sweep only
 };
@@ -138,10 +151,12 @@ size_t sweep_relax_boundary_elems(int W, int H);
 bool launch_sweep_relax(hipStream_t st, const SweepArgs& a);   // lab build only (pf_config::sweep_impl = 3): event-driven relaxation on LDS-resident tiles, kernels_relax.inl
 // coarsest-level search
 void launch_adjust_initial_flow(hipStream_t st, const float* i0, const float* i1, const float* a0, const float* a1, int w, int h, int hint,
-                                int max_pct, float* i1eq_tmp, float* flow);
+                                int max_pct, float* i1eq_tmp, float* flow, Batch bt = Batch());
 // blend
 void launch_blend(hipStream_t st, const uint8_t* L, const uint8_t* R, const float* flowLR, const float* flowRL, const float* blend, int cols,
                   int rows, uint8_t* out);
+struct BlendPtrs { const uint8_t* L[kMaxBatch]; const uint8_t* R[kMaxBatch]; const float* fLR[kMaxBatch]; const float* fRL[kMaxBatch]; const float* blend[kMaxBatch]; uint8_t* out[kMaxBatch]; };
+void launch_blend_batch(hipStream_t st, const BlendPtrs& p, int n, int cols, int rows);
 // stitch
 void launch_match_images(hipStream_t st, const uint8_t* L, const uint8_t* R, int cols, int rows, uint8_t* map, uint8_t* ovL, uint8_t* ovR);
 void launch_countblend(hipStream_t st, const uint8_t* map, int cols, int rows, float* blend, float* mergedDis);
@@ -151,9 +166,10 @@ size_t tile_blur_lds_bytes(int step, int k);
 void launch_tile_blur(hipStream_t st, float* blend, const float* mergedDis, int cols, int rows, int step, int k, void* work);
 void launch_gather(hipStream_t st, const uint8_t* L, const uint8_t* R, const uint8_t* merged, const uint8_t* map, int cols, int rows,
                    uint8_t* out);
-void launch_fill_u64(hipStream_t st, unsigned long long* p, size_t n, unsigned long long v);
+void launch_fill_u64(hipStream_t st, unsigned long long* p, size_t n, unsigned long long v, Batch bt = Batch());
+void launch_fill_u32(hipStream_t st, unsigned* p, size_t n, unsigned v, Batch bt = Batch());   // memset that knows the batch dimension
 void launch_checksum64(hipStream_t st, const void* p, size_t bytes, unsigned long long* acc /* zeroed by the caller */);
 void launch_count_diff_u32(hipStream_t st, const uint32_t* a, const uint32_t* b, size_t n, int* count /* zeroed by the caller */);
-void launch_collect_status(hipStream_t st, const int* ctrl, int nwords, int* status_mapped, int bit);
+void launch_collect_status(hipStream_t st, const int* ctrl, int nwords, int* status_mapped, int bit, Batch bt = Batch());
 
 }  // namespace pf

@@ -23,29 +23,32 @@ class Stitchtools {
   Stitchtools() {}
   ~Stitchtools() {}
 
-  // CPU/StitchTool.cpp:7-36
+  // CPU/StitchTool.cpp:7-36.  One fused device pass (pf_stitch_prepare) = MatchImages() + the overlap masking + GenerateBlend(): nothing can
+  // edit Map between them here, so the result is what calling the two public methods in sequence gives.
   void prepare(const Mat& colorImageL, const Mat& colorImageR) {
     if (colorImageL.type() != CV_8UC4 || colorImageR.type() != CV_8UC4 || colorImageL.rows != colorImageR.rows || colorImageL.cols != colorImageR.cols)
       throw util::VrCamException("Stitchtools::prepare: inputs must be two CV_8UC4 images of equal size");
     ImageL = colorImageL.clone();
     ImageR = colorImageR.clone();
     raw_ = Mat(); rawDis_ = Mat();
-    MatchImages();
-    GenerateBlend();
-  }
-  // CPU/StitchTool.cpp:38-50 (+ the overlap masking of :17-33).  One device pass produces everything
-  // prepare() needs; GenerateBlend() then only publishes the ramp.
-  void MatchImages() {
     const int r = ImageL.rows, c = ImageL.cols;
     Map = Mat(r, c, CV_8UC1); OverlappedL = Mat(r, c, CV_8UC4); OverlappedR = Mat(r, c, CV_8UC4);
-    ramp_ = Mat(r, c, CV_32FC1); MergedDis = Mat(r, c, CV_32FC1);
+    Blend = Mat(r, c, CV_32FC1); MergedDis = Mat(r, c, CV_32FC1);
     pano::check(pf_stitch_prepare(pano::context(), ImageL.data, ImageR.data, c, r, ImageL.step, Map.data, Map.step, OverlappedL.data, OverlappedR.data,
-                                  ramp_.ptr<float>(), ramp_.step, MergedDis.ptr<float>()));
+                                  Blend.ptr<float>(), Blend.step, MergedDis.ptr<float>()));
   }
-  // CPU/StitchTool.cpp:98-146
+  // CPU/StitchTool.cpp:38-50: Map from the two alpha channels (+ the overlap-masked copies prepare() derives from it, :17-33).
+  void MatchImages() {
+    if (ImageL.empty()) throw util::VrCamException("Stitchtools::MatchImages: prepare first");
+    const int r = ImageL.rows, c = ImageL.cols;
+    Map = Mat(r, c, CV_8UC1); OverlappedL = Mat(r, c, CV_8UC4); OverlappedR = Mat(r, c, CV_8UC4);
+    pano::check(pf_stitch_match(pano::context(), ImageL.data, ImageR.data, c, r, ImageL.step, Map.data, Map.step, OverlappedL.data, OverlappedR.data));
+  }
+  // CPU/StitchTool.cpp:98-146: the blend ramp of the CURRENT Map member (a caller may have edited it since MatchImages(), as with the reference).
   void GenerateBlend() {
-    if (ramp_.empty()) MatchImages();
-    Blend = ramp_.clone();
+    if (Map.empty()) throw util::VrCamException("Stitchtools::GenerateBlend: MatchImages first");
+    Blend = Mat(Map.rows, Map.cols, CV_32FC1); MergedDis = Mat(Map.rows, Map.cols, CV_32FC1);
+    pano::check(pf_stitch_generate_blend(pano::context(), Map.data, Map.step, Map.cols, Map.rows, Blend.ptr<float>(), Blend.step, MergedDis.ptr<float>()));
   }
   // CPU/StitchTool.cpp:148-191.  x is in wrap-extended map coordinates (cols/5 columns were prepended, :102-111).
   // Like the reference it returns the RAW ratio minLdis / (minRdis + minLdis) of that pixel -- not the smoothed ramp --
@@ -82,7 +85,6 @@ class Stitchtools {
   void setMergedmiddle(const Mat& image) { Mergedmiddle = image.clone(); }
 
  private:
-  Mat ramp_;            // smoothed ramp of the last MatchImages() pass
   Mat raw_, rawDis_;    // unsmoothed ramp / MergedDis for countblend(), computed on first use
 };
 

@@ -35,7 +35,7 @@ class Config(C.Structure):
     """pf_config (include/panoflow.h)"""
     _fields_ = [("struct_size", C.c_int), ("device", C.c_int), ("max_cols", C.c_int), ("max_rows", C.c_int), ("stagger_levels", C.c_int),
                 ("fuse_small_level_px", C.c_long), ("fine_gradient_blocks", C.c_int), ("pyramid_chaining", C.c_int), ("sweep_window", C.c_int),
-                ("sparse_sweep", C.c_int), ("sweep_impl", C.c_int), ("record_path", C.c_int)]
+                ("sparse_sweep", C.c_int), ("batch_pairs", C.c_int), ("sweep_impl", C.c_int), ("record_path", C.c_int)]
 
 
 def lib(exp=False):
@@ -80,7 +80,7 @@ def lib(exp=False):
 
 EXPORTS = [
     "pf_device_count", "pf_create", "pf_config_init", "pf_create_cfg", "pf_destroy", "pf_last_error", "pf_version", "pf_max_percentage_by_name",
-    "pf_flow", "pf_flow_bidir", "pf_blend", "pf_novel_view", "pf_stitch_prepare", "pf_stitch_raw_blend", "pf_stitch_gather", "pf_stitch_step", "pf_stitch_prefetch",
+    "pf_flow", "pf_flow_bidir", "pf_blend", "pf_novel_view", "pf_stitch_prepare", "pf_stitch_match", "pf_stitch_generate_blend", "pf_stitch_raw_blend", "pf_stitch_gather", "pf_stitch_step", "pf_stitch_prefetch",
     "pf_dev_alloc", "pf_dev_free", "pf_host_alloc", "pf_host_free", "pf_upload", "pf_download", "pf_sync", "pf_checksum_dev",
     "pf_flow_bidir_dev", "pf_blend_dev", "pf_novel_view_dev", "pf_novel_view_batch_dev",
     "pf_stage_preprocess", "pf_stage_pyr_down", "pf_stage_gradients", "pf_stage_gauss", "pf_stage_median5", "pf_stage_sweep",
@@ -239,6 +239,20 @@ class Context:
         self._chk(self.l.pf_stitch_prepare(self.h, _p(a), _p(b), cols, rows, C.c_size_t(cols * 4), _p(mp), C.c_size_t(cols), _p(ovl), _p(ovr), _p(bl),
                                            C.c_size_t(cols * 4), _p(md)))
         return mp, ovl, ovr, bl, md
+
+    def stitch_match(self, L, R):
+        """MatchImages + overlap masking only"""
+        a = _u8(L); b = _u8(R); rows, cols, _ = a.shape
+        mp = np.empty((rows, cols), np.uint8); ovl = np.empty_like(a); ovr = np.empty_like(a)
+        self._chk(self.l.pf_stitch_match(self.h, _p(a), _p(b), cols, rows, C.c_size_t(cols * 4), _p(mp), C.c_size_t(cols), _p(ovl), _p(ovr)))
+        return mp, ovl, ovr
+
+    def stitch_generate_blend(self, mp):
+        """GenerateBlend from a given map (the reference reads its public Map member)"""
+        m = _u8(mp); rows, cols = m.shape
+        bl = np.empty((rows, cols), np.float32); md = np.empty((rows, cols), np.float32)
+        self._chk(self.l.pf_stitch_generate_blend(self.h, _p(m), C.c_size_t(cols), cols, rows, _p(bl), C.c_size_t(cols * 4), _p(md)))
+        return bl, md
 
     def stitch_raw_blend(self, L, R):
         """GenerateBlend before its smoothing (what countblend returns in the overlap) + MergedDis."""

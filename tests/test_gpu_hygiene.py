@@ -151,3 +151,28 @@ def test_device_checksum(pf):
         torch.cuda.synchronize()
         assert c.checksum_dev(w.data_ptr(), n) != h
     c.close()
+
+
+def test_generate_blend_reads_the_current_map(ctx, orc, synth):
+    """Stitchtools::GenerateBlend (StitchTool.cpp:98-146) works on the public Map member: pf_stitch_match / pf_stitch_generate_blend are
+    the two halves of prepare(), and the ramp of an EDITED map equals the oracle's ramp for images that have exactly that map."""
+    cols, rows = 420, 300
+    L, R = synth.make_canvas_pair(cols, rows, 5)
+    L = L.numpy(); R = R.numpy()
+    mp, ovl, ovr = ctx.stitch_match(L, R)
+    rmp, rovl, rovr, rbl, rmd = orc.stitch_prepare(L, R, True)
+    assert np.array_equal(mp, rmp) and np.array_equal(ovl, rovl) and np.array_equal(ovr, rovr)
+    bl, md = ctx.stitch_generate_blend(mp)
+    assert np.array_equal(bl, rbl) and np.array_equal(md, rmd)
+    # edit the map: carve a block of the overlap out for the left image, and drop a stripe entirely
+    ed = mp.copy()
+    ys, xs = np.nonzero(mp == 150)
+    y0, x0 = int(ys.mean()), int(xs.mean())
+    ed[y0 - 20:y0 + 20, x0 - 15:x0 + 15] = 100
+    ed[5:9, :] = 0
+    L2 = L.copy(); R2 = R.copy()
+    L2[..., 3] = np.where(ed >= 100, 255, 0); R2[..., 3] = np.where((ed == 50) | (ed == 150), 255, 0)
+    emp, _, _, ebl, emd = orc.stitch_prepare(L2, R2, True)
+    assert np.array_equal(emp, ed)
+    bl2, md2 = ctx.stitch_generate_blend(ed)
+    assert np.array_equal(bl2, ebl) and np.array_equal(md2, emd) and not np.array_equal(bl2, bl)
