@@ -407,6 +407,24 @@ def main():
             del pairs_b, outs_b, os_
             ct.close()
             torch.cuda.empty_cache()
+            # ... and the same on the per-GPU workload's size: 8 dense 9000x4000 pairs through one set of launches
+            nb2 = 8
+            pairs_c = [synth.make_pair(cols, rows, 6000 + i, dev)[:3] for i in range(nb2)]
+            outs_c = [torch.empty((rows, cols, 4), dtype=torch.uint8, device=dev) for _ in range(nb2)]
+            torch.cuda.synchronize()
+            ct = pf.Context(local_rank)
+            call_c = lambda: ct.novel_view_batch_dev([p[0].data_ptr() for p in pairs_c], [p[1].data_ptr() for p in pairs_c], cols, rows, max_pct,
+                                                      [p[2].data_ptr() for p in pairs_c], [o.data_ptr() for o in outs_c], None, None, in_flight=nb2)
+            call_c()
+            tcs = []
+            for _ in range(3):
+                t1 = time.perf_counter(); call_c(); tcs.append(time.perf_counter() - t1)
+            tcm = statistics.median(tcs)
+            res["throughput_mode"]["pairs_%dx%d" % (cols, rows)] = {"value": round(nb2 * mpix / tcm, 3), "unit": "Mpix/s", "pairs": nb2, "in_flight": nb2, "runs": 3, "warmup": 1,
+                                                                     "statistic": "median", "roofline_path_frac": round(nb2 * b_alg / tcm / 8e12, 6)}
+            del pairs_c, outs_c
+            ct.close()
+            torch.cuda.empty_cache()
         line = json.dumps(res)
     if pfd:
         pfd.close()

@@ -138,10 +138,18 @@ int pf_dist_gather_async(pf_dist* d, const void* d_send, void* d_recv_all, size_
   Rccl* r = rccl();
   DHIP(d, hipSetDevice(d->device));
   if (d->pending) { DHIP(d, hipEventSynchronize(d->done)); d->pending = false; }
+  // One grouped call; a block goes as pieces of at most 256 MiB (a single 1.15 GB send/recv -- eight 9000x4000 strips of the throughput
+  // mode -- arrived incomplete with RCCL 2.26: only the first ~600 MB matched, measured with tools/pano_batch -in_flight 8).
+  constexpr size_t kPiece = size_t(256) << 20;
   NCHK(d, r->GroupStart());
-  ncclResult_t rc = r->Send(d_send, bytes, ncclUint8, 0, d->comm, d->stream);
-  if (d->rank == 0)
-    for (int p = 0; p < d->world && rc == ncclSuccess; ++p) rc = r->Recv(static_cast<char*>(d_recv_all) + size_t(p) * bytes, bytes, ncclUint8, p, d->comm, d->stream);
+  ncclResult_t rc = ncclSuccess;
+  for (size_t o = 0; o < bytes && rc == ncclSuccess; o += kPiece) {
+    const size_t nbytes = bytes - o < kPiece ? bytes - o : kPiece;
+    rc = r->Send(static_cast<const char*>(d_send) + o, nbytes, ncclUint8, 0, d->comm, d->stream);
+    if (d->rank == 0)
+      for (int p = 0; p < d->world && rc == ncclSuccess; ++p)
+        rc = r->Recv(static_cast<char*>(d_recv_all) + size_t(p) * bytes + o, nbytes, ncclUint8, p, d->comm, d->stream);
+  }
   const ncclResult_t re = r->GroupEnd();   // always: an error inside the group must not leave it open
   if (rc != ncclSuccess || re != ncclSuccess) {
     d->err = std::string("grouped ncclSend/ncclRecv failed: ") + r->GetErrorString(rc != ncclSuccess ? rc : re); g_derr = d->err;

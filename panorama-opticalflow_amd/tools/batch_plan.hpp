@@ -22,5 +22,19 @@ inline int pair_of(int round, int rank, int n_pairs, int ndev) { const int p = r
 struct Slot { int round, block; };
 inline Slot slot_of_pair(int pair, int ndev) { return Slot{pair / ndev, pair % ndev}; }
 
+// The same with up to k pairs per device and round (throughput mode: a device solves k of its pairs through one set of launches,
+// pf_novel_view_batch_dev, and sends them to rank 0 as one block of k strips).  Ownership is unchanged -- pair i still belongs to
+// device i % ndev -- a device's j-th round covers its pairs number j*k .. j*k + k - 1.
+inline int rounds_k(int n_pairs, int ndev, int k) {
+  if (ndev <= 0 || k <= 0) return 0;
+  const int per_dev = (n_pairs + ndev - 1) / ndev;
+  return (per_dev + k - 1) / k;
+}
+// pair in slot `slot` (0..k-1) of `rank`'s block in gather round `round`, or -1 when that slot stays empty
+inline int pair_of_k(int round, int rank, int slot, int n_pairs, int ndev, int k) {
+  const int p = rank + (round * k + slot) * ndev;
+  return p < n_pairs ? p : -1;
+}
+
 }  // namespace pano_batch
 #endif

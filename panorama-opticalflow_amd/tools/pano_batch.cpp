@@ -5,7 +5,10 @@
 // into rank 0's HBM: grouped ncclSend/ncclRecv on the gather stream (pf_dist_gather_async), double-buffered so that the
 // gather of round j overlaps the compute of round j+1.  Host code is C++ over the C ABI; no Python, no torch.
 //
-//   pano_batch -pairs 8 -size 9000x4000 -flow_alg pixflow_search_20 [-gpus N] [-verify 1]
+//   pano_batch -pairs 8 -size 9000x4000 -flow_alg pixflow_search_20 [-gpus N] [-verify 1] [-in_flight K]
+//
+// -in_flight K (1..8, default 1): with more pairs than GPUs, each GPU solves K of its pairs through ONE set of kernel launches per
+// round (pf_novel_view_batch_dev: the exact sweeps of a lone pair leave most of the chip idle) and sends them as one block.
 //
 // Inputs are synthetic (textured pair with a smooth displacement, alpha holes at the edges) generated on the host per
 // pair and uploaded once; the clock covers compute + gather with inputs resident in HBM.  -verify 1 (default) checks every
@@ -26,7 +29,7 @@
 
 namespace {
 
-struct Args { int pairs = 8, cols = 9000, rows = 4000, gpus = 0, verify = 1; std::string alg = "pixflow_low"; };
+struct Args { int pairs = 8, cols = 9000, rows = 4000, gpus = 0, verify = 1, in_flight = 1; std::string alg = "pixflow_low"; };
 
 bool parse(int argc, char** argv, Args& a) {
   for (int i = 1; i < argc; ++i) {
@@ -42,9 +45,10 @@ bool parse(int argc, char** argv, Args& a) {
     else if (k == "flow_alg") a.alg = v;
     else if (k == "gpus") a.gpus = atoi(v.c_str());
     else if (k == "verify") a.verify = atoi(v.c_str());
+    else if (k == "in_flight") a.in_flight = atoi(v.c_str());
     else return false;
   }
-  return a.pairs > 0 && a.cols > 0 && a.rows > 0;
+  return a.pairs > 0 && a.cols > 0 && a.rows > 0 && a.in_flight >= 1 && a.in_flight <= 8;
 }
 
 // deterministic synthetic pair: three sinusoid layers per channel, L = T(x + d/2), R = 1.05 T(x - d/2)
@@ -94,20 +98,22 @@ void worker(Shared* s, int dev) {
   if (!dist) die(dev, "pf_dist_init", pf_dist_last_error(nullptr));
   const size_t n = size_t(a.cols) * a.rows, ib = n * 4;
   const std::vector<int> mine = pano_batch::pairs_for_device(a.pairs, dev, ndev);
-  const int nrounds = pano_batch::rounds(a.pairs, ndev);
+  const int K = a.in_flight;
+  const int nrounds = pano_batch::rounds_k(a.pairs, ndev, K);
   // inputs of all my pairs resident in HBM before the clock starts
-  std::vector<void*> dL(mine.size()), dR(mine.size());
+  std::vector<const uint8_t*> dL(mine.size()), dR(mine.size());
   void* dBlend = pf_dev_alloc(ctx, n * 4);
-  void* dOut[2] = {pf_dev_alloc(ctx, ib), pf_dev_alloc(ctx, ib)};
+  void* dOut[2] = {pf_dev_alloc(ctx, ib * K), pf_dev_alloc(ctx, ib * K)};   // a round's K strips, back to back
   void* dRecv[2] = {nullptr, nullptr};
-  if (dev == 0) { dRecv[0] = pf_dev_alloc(ctx, ib * ndev); dRecv[1] = pf_dev_alloc(ctx, ib * ndev); }
+  if (dev == 0) { dRecv[0] = pf_dev_alloc(ctx, ib * K * ndev); dRecv[1] = pf_dev_alloc(ctx, ib * K * ndev); }
   if (!dBlend || !dOut[0] || !dOut[1] || (dev == 0 && (!dRecv[0] || !dRecv[1]))) die(dev, "pf_dev_alloc", pf_last_error(ctx));
   {
     std::vector<uint8_t> L, R; std::vector<float> blend;
     for (size_t k = 0; k < mine.size(); ++k) {
       make_pair(a.cols, a.rows, 1234 + mine[k], L, R, blend);
-      dL[k] = pf_dev_alloc(ctx, ib); dR[k] = pf_dev_alloc(ctx, ib);
-      if (!dL[k] || !dR[k] || pf_upload(ctx, dL[k], L.data(), ib) || pf_upload(ctx, dR[k], R.data(), ib)) die(dev, "upload", pf_last_error(ctx));
+      void* l = pf_dev_alloc(ctx, ib); void* r = pf_dev_alloc(ctx, ib);
+      if (!l || !r || pf_upload(ctx, l, L.data(), ib) || pf_upload(ctx, r, R.data(), ib)) die(dev, "upload", pf_last_error(ctx));
+      dL[k] = static_cast<const uint8_t*>(l); dR[k] = static_cast<const uint8_t*>(r);
       if (k == 0 && pf_upload(ctx, dBlend, blend.data(), n * 4)) die(dev, "upload", pf_last_error(ctx));
     }
     if (mine.empty()) { make_pair(a.cols, a.rows, 1, L, R, blend); if (pf_upload(ctx, dBlend, blend.data(), n * 4)) die(dev, "upload", pf_last_error(ctx)); }
@@ -116,26 +122,34 @@ void worker(Shared* s, int dev) {
   // ~25 us per 144 MB) at its producer and again in rank 0's receive area after the gather; 8 bytes per strip come back.
   auto consume = [&](int round) {   // rank 0: the blocks of `round` are in dRecv[round % 2]
     if (dev != 0 || !a.verify) return;
-    for (int r = 0; r < ndev; ++r) {
-      const int p = pano_batch::pair_of(round, r, a.pairs, ndev);
-      if (p < 0) continue;
-      if (pf_checksum_dev(ctx, static_cast<char*>(dRecv[round % 2]) + size_t(r) * ib, ib, &s->sum_gathered[p])) die(dev, "checksum", pf_last_error(ctx));
-    }
+    for (int r = 0; r < ndev; ++r)
+      for (int q = 0; q < K; ++q) {
+        const int p = pano_batch::pair_of_k(round, r, q, a.pairs, ndev, K);
+        if (p < 0) continue;
+        if (pf_checksum_dev(ctx, static_cast<char*>(dRecv[round % 2]) + (size_t(r) * K + q) * ib, ib, &s->sum_gathered[p])) die(dev, "checksum", pf_last_error(ctx));
+      }
   };
   if (pf_dist_barrier(dist)) die(dev, "barrier", pf_dist_last_error(dist));
   const auto t0 = std::chrono::steady_clock::now();
   for (int j = 0; j < nrounds; ++j) {
-    const int p = pano_batch::pair_of(j, dev, a.pairs, ndev);
-    void* out = dOut[j % 2];
-    if (p >= 0) {
-      const size_t k = size_t(j);   // my k-th pair is handled in round k
-      if (pf_novel_view_dev(ctx, (const uint8_t*)dL[k], (const uint8_t*)dR[k], a.cols, a.rows, s->max_pct, (const float*)dBlend, (uint8_t*)out, nullptr, nullptr))
-        die(dev, "pf_novel_view_dev", pf_last_error(ctx));
-      if (a.verify && pf_checksum_dev(ctx, out, ib, &s->sum_local[p])) die(dev, "checksum", pf_last_error(ctx));
+    char* out = static_cast<char*>(dOut[j % 2]);
+    int count = 0;
+    while (count < K && pano_batch::pair_of_k(j, dev, count, a.pairs, ndev, K) >= 0) ++count;
+    if (count > 0) {
+      const size_t k0 = size_t(j) * K;   // my pairs number k0 .. k0 + count - 1 are handled in round j
+      const float* blends[8]; uint8_t* outs[8];
+      for (int q = 0; q < count; ++q) { blends[q] = static_cast<const float*>(dBlend); outs[q] = reinterpret_cast<uint8_t*>(out + size_t(q) * ib); }
+      const int rc = count == 1
+          ? pf_novel_view_dev(ctx, dL[k0], dR[k0], a.cols, a.rows, s->max_pct, blends[0], outs[0], nullptr, nullptr)
+          : pf_novel_view_batch_dev(ctx, count, &dL[k0], &dR[k0], a.cols, a.rows, s->max_pct, blends, outs, nullptr, nullptr, count);
+      if (rc) die(dev, "pf_novel_view", pf_last_error(ctx));
+      if (a.verify)
+        for (int q = 0; q < count; ++q)
+          if (pf_checksum_dev(ctx, outs[q], ib, &s->sum_local[pano_batch::pair_of_k(j, dev, q, a.pairs, ndev, K)])) die(dev, "checksum", pf_last_error(ctx));
     }
-    // all ranks take part in every round (a rank without a pair in the last round sends its stale buffer, which rank 0 ignores);
+    // all ranks take part in every round (empty slots of the last round carry stale strips, which rank 0 ignores);
     // the call first waits for the previous gather, whose receive area the consumer below then owns
-    if (pf_dist_gather_async(dist, out, dRecv[j % 2], ib)) die(dev, "gather", pf_dist_last_error(dist));
+    if (pf_dist_gather_async(dist, out, dRecv[j % 2], ib * K)) die(dev, "gather", pf_dist_last_error(dist));
     if (j > 0) consume(j - 1);
   }
   if (pf_dist_wait(dist)) die(dev, "wait", pf_dist_last_error(dist));
@@ -145,8 +159,8 @@ void worker(Shared* s, int dev) {
   if (pf_dist_max(dist, &dt)) die(dev, "max", pf_dist_last_error(dist));
   if (dev == 0) s->secs[0] = dt;   // the job's time: the slowest rank's
   pf_dist_destroy(dist);
-  for (void* p : dL) pf_dev_free(ctx, p);
-  for (void* p : dR) pf_dev_free(ctx, p);
+  for (const uint8_t* p : dL) pf_dev_free(ctx, const_cast<uint8_t*>(p));
+  for (const uint8_t* p : dR) pf_dev_free(ctx, const_cast<uint8_t*>(p));
   pf_dev_free(ctx, dBlend); pf_dev_free(ctx, dOut[0]); pf_dev_free(ctx, dOut[1]); pf_dev_free(ctx, dRecv[0]); pf_dev_free(ctx, dRecv[1]);
 }
 
@@ -154,7 +168,7 @@ void worker(Shared* s, int dev) {
 
 int main(int argc, char** argv) {
   Shared s;
-  if (!parse(argc, argv, s.a)) { fprintf(stderr, "usage: pano_batch -pairs P -size COLSxROWS -flow_alg pixflow_low|pixflow_search_20 [-gpus N] [-verify 0|1]\n"); return 2; }
+  if (!parse(argc, argv, s.a)) { fprintf(stderr, "usage: pano_batch -pairs P -size COLSxROWS -flow_alg pixflow_low|pixflow_search_20 [-gpus N] [-verify 0|1] [-in_flight 1..8]\n"); return 2; }
   s.max_pct = pf_max_percentage_by_name(s.a.alg.c_str());
   if (s.max_pct < 0) { fprintf(stderr, "%s\n", pf_last_error(nullptr)); return 1; }
   const int have = pf_device_count();
@@ -180,7 +194,7 @@ int main(int argc, char** argv) {
   int bad = 0;
   if (s.a.verify) for (int p = 0; p < s.a.pairs; ++p) if (!s.sum_local[p] || s.sum_local[p] != s.sum_gathered[p]) { fprintf(stderr, "pair %d: gathered strip differs from its producer's\n", p); ++bad; }
   const double mpix = double(s.a.cols) * s.a.rows * s.a.pairs / 1e6;
-  printf("{\"tool\": \"pano_batch\", \"gpus\": %d, \"pairs\": %d, \"size\": \"%dx%d\", \"flow_alg\": \"%s\", \"seconds\": %.4f, \"Mpix/s\": %.2f, \"verified_pairs\": %d, \"verification\": \"%s\", \"gather\": \"rccl send/recv to rank 0, overlapped\"}\n",
-         s.ndev, s.a.pairs, s.a.cols, s.a.rows, s.a.alg.c_str(), s.secs[0], mpix / s.secs[0], s.a.verify ? s.a.pairs - bad : 0, s.a.verify ? "device-side checksums (pf_checksum_dev), no host copies inside the clock" : "off");
+  printf("{\"tool\": \"pano_batch\", \"gpus\": %d, \"in_flight_per_gpu\": %d, \"pairs\": %d, \"size\": \"%dx%d\", \"flow_alg\": \"%s\", \"seconds\": %.4f, \"Mpix/s\": %.2f, \"verified_pairs\": %d, \"verification\": \"%s\", \"gather\": \"rccl send/recv to rank 0, overlapped\"}\n",
+         s.ndev, s.a.in_flight, s.a.pairs, s.a.cols, s.a.rows, s.a.alg.c_str(), s.secs[0], mpix / s.secs[0], s.a.verify ? s.a.pairs - bad : 0, s.a.verify ? "device-side checksums (pf_checksum_dev), no host copies inside the clock" : "off");
   return bad ? 1 : 0;
 }

@@ -21,6 +21,18 @@ def test_pano_batch_one_gpu_three_pairs():
     assert res["gpus"] == 1 and res["pairs"] == 3 and res["verified_pairs"] == 3 and res["Mpix/s"] > 0
 
 
+def test_pano_batch_in_flight_matches_one_at_a_time():
+    """-in_flight K: a GPU solves K of its pairs through one set of launches per round and gathers them as one block; with a ragged
+    last round.  The gathered strips verify against their producers' checksums, like the one-pair-per-round run."""
+    exe = os.path.join(PKG, "tools", "pano_batch")
+    out = {}
+    for k in ("1", "3"):
+        r = subprocess.run([exe, "-pairs", "5", "-size", "640x480", "-flow_alg", "pixflow_low", "-gpus", "1", "-verify", "1", "-in_flight", k], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out[k] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert out[k]["pairs"] == 5 and out[k]["verified_pairs"] == 5 and out[k]["in_flight_per_gpu"] == int(k)
+
+
 def test_pf_dist_self_gather_and_max(pf):
     c = pf.Context(0)
     d = pf.Dist(0, pf.dist_unique_id(), 0, 1)
