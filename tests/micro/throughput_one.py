@@ -13,7 +13,10 @@ pairs = [synth.make_pair(cols, rows, 7000 + i, dev) for i in range(nb)]
 outs = [torch.empty((rows, cols, 4), dtype=torch.uint8, device=dev) for _ in range(nb)]
 torch.cuda.synchronize()
 bp = int(os.environ.get("TP_BATCH", "-1"))
-c = pf.Context(0, cols, rows, batch_pairs=bp)
+knobs = {"batch_pairs": bp}
+if os.environ.get("TP_STAGGER"): knobs["stagger_levels"] = int(os.environ["TP_STAGGER"])
+if os.environ.get("TP_FUSE"): knobs["fuse_small_level_px"] = int(os.environ["TP_FUSE"])
+c = pf.Context(0, cols, rows, **knobs)
 call = lambda: c.novel_view_batch_dev([p[0].data_ptr() for p in pairs], [p[1].data_ptr() for p in pairs], cols, rows, 0,
                                       [p[2].data_ptr() for p in pairs], [o.data_ptr() for o in outs], None, None, in_flight=infl)
 call()
@@ -21,5 +24,5 @@ best = 1e9
 for _ in range(int(os.environ.get("TP_LOOPS", "2"))):
     t = time.perf_counter(); call(); best = min(best, time.perf_counter() - t)
 ref = pf.Context(0, cols, rows) if os.environ.get("TP_CHECK") else None
-print("queues %s batch_pairs %s in_flight %2d: %.1f Mpix/s (%.2f ms per pair)" % (os.environ.get("GPU_MAX_HW_QUEUES"), bp, infl,
+print("queues %s knobs %s in_flight %2d: %.1f Mpix/s (%.2f ms per pair)" % (os.environ.get("GPU_MAX_HW_QUEUES"), knobs, infl,
                                                                              nb * cols * rows / 1e6 / best, 1000 * best / nb), flush=True)
