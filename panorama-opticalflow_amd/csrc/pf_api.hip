@@ -61,7 +61,7 @@ struct pf_ctx {
   hipStream_t s_copy = nullptr;         // uploads that overlap compute (created on first use, like s_aux: a context that only solves
                                         // pairs drives three streams, so that six lanes of the throughput mode fit the hardware queues)
   bool drained = true;                  // false between "work enqueued" and finish(): what CallGuard looks at
-  size_t slab_stride = 0; int slab_pairs = 0;   // layout the "batch_slab" buffer was last initialised for (alloc_solve_batch)
+  size_t slab_stride = 0, slab_work_off = 0; int slab_pairs = 0;   // layout the "batch_slab" buffer was last initialised for (alloc_solve_batch)
   std::vector<pf_ctx*> lanes;           // throughput mode: further stream/buffer sets on the same device (pf_novel_view_batch_dev)
   int* h_gate = nullptr; int* d_gate = nullptr; int gate_epoch = 0;   // mapped pinned: per-level gate boxes + count + epoch flag (k_gate_bbox_all)
   int* h_status = nullptr;              // mapped pinned host word: bit d set = a sweep band of direction d timed out
@@ -337,13 +337,14 @@ int alloc_solve_batch(pf_ctx* c, const Geometry& g, int nb, SolveBufs& b, size_t
   if (!base) return PF_ERR_NOMEM;
   Carver cv{c, true, base, 0};
   if (int e = alloc_solve(cv, g, 2, b)) return e;
-  if (fresh || c->slab_stride != stride || c->slab_pairs < nb) {   // new memory or a new layout: (re)initialise the self-resetting work areas
+  const size_t work_off = size_t(reinterpret_cast<char*>(b.gate_work) - base);
+  if (fresh || c->slab_stride != stride || c->slab_work_off != work_off || c->slab_pairs < nb) {   // new memory or a new layout: (re)initialise the self-resetting work areas
     std::vector<int> init(4 * kLevelTableMax + 2, 0);
     for (int l = 0; l < kLevelTableMax; ++l) { init[4 * l] = 0x7fffffff; init[4 * l + 1] = 0x7fffffff; init[4 * l + 2] = -1; init[4 * l + 3] = -1; }
     for (int p = 0; p < nb; ++p)
       if (hipMemcpy(reinterpret_cast<char*>(b.gate_work) + size_t(p) * stride, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
         return fail(c, PF_ERR_DEVICE, "initialising the batch slabs failed");
-    c->slab_stride = stride; c->slab_pairs = nb;
+    c->slab_stride = stride; c->slab_work_off = work_off; c->slab_pairs = nb;
   }
   return 0;
 }

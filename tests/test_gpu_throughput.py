@@ -97,3 +97,27 @@ def test_oversubscribed_gpu_does_not_time_out(pf, synth):
         got = _fetch(c, {"o": o[0], "f0": o[1], "f1": o[2]}, cols, rows)
         assert all(np.array_equal(a, b) for a, b in zip(got, ref))
     c.close()
+
+
+def test_batches_of_changing_size_on_one_context(pf, synth):
+    """the slabs of a batch are re-laid-out when the image size (or the batch size) changes: sizes A, B, A, then a larger batch, on one context,
+    every result equal to a single call's"""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    c = pf.Context(0)
+    ref_ctx = pf.Context(0)
+    for (cols, rows, n, infl) in ((640, 480, 3, 3), (512, 704, 4, 4), (640, 480, 3, 3), (512, 704, 6, 6), (336, 272, 8, 8)):
+        pairs = [_dev_pair(pf, c, synth, cols, rows, 300 + 7 * i + cols) for i in range(n)]
+        ref = []
+        for d in pairs:
+            ref_ctx.novel_view_dev(d["L"], d["R"], cols, rows, 0, d["b"], d["o"], d["f0"], d["f1"])
+            ref.append(_fetch(ref_ctx, d, cols, rows))
+            c.upload(d["o"], np.zeros((rows, cols, 4), np.uint8))
+        c.novel_view_batch_dev([d["L"] for d in pairs], [d["R"] for d in pairs], cols, rows, 0, [d["b"] for d in pairs], [d["o"] for d in pairs],
+                               [d["f0"] for d in pairs], [d["f1"] for d in pairs], in_flight=infl)
+        for d, r in zip(pairs, ref):
+            got = _fetch(c, d, cols, rows)
+            assert all(np.array_equal(a, b) for a, b in zip(got, r)), (cols, rows, n)
+        for d in pairs:
+            for k in d.values():
+                c.dev_free(k)
+    c.close(); ref_ctx.close()
