@@ -219,15 +219,20 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, con
   lds_f2* win3 = (lds_f2*)win;   // explicit LDS address space: ds_read_b64, never a flat access
   const f2v w00 = win3[o00], w10 = win3[o10], w01 = win3[o01], w11 = win3[o11];
   float2 t00 = make_float2(w00.x, w00.y), t10 = make_float2(w10.x, w10.y), t01 = make_float2(w01.x, w01.y), t11 = make_float2(w11.x, w11.y);
-  if (__builtin_expect(!inwin, 0)) {
-    const float2* p = g1 + (y0 * W + x0);
-    t00 = p[0]; t10 = p[1]; t01 = p[W]; t11 = p[W + 1];
+  // wave-uniform test first: the common "every lane inside the window" case costs a compare + one scalar branch, not an exec-mask
+  // save / restore around an empty block (two instructions of ~150 per step; a step is issue-bound, profiles/r03_sweep_step_isa.txt)
+  if (__builtin_expect(__any(!inwin), 0)) {
+    if (!inwin) {
+      const float2* p = g1 + (y0 * W + x0);
+      t00 = p[0]; t10 = p[1]; t01 = p[W]; t11 = p[W + 1];
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   // ---- B ----
   const float xR = __builtin_amdgcn_fractf(cx), yR = __builtin_amdgcn_fractf(cy);   // cx, cy >= 0: exactly cx - float(int(cx))
   const float dfx = bx - fdx, dfy = by - fdy;
-  const float s2 = dfx * dfx + dfy * dfy;
+  float s2 = dfx * dfx + dfy * dfy;
+  asm volatile("" : "+v"(s2));   // a finished scalar here: otherwise the SLP vectoriser packs this add with d2's below behind two register moves (3 instructions for 2)
   const float av = kVerticalRegularizationCoef * fabsf(fdy), ah = kHorizontalRegularizationCoef * fabsf(fdx);
   const f2p reg = div_core2(f2p{av, ah}, fW, rW);
   const float sm = sqrt_core(s2) * kSmoothnessCoef, rv = reg.x, rh = reg.y;
@@ -367,6 +372,13 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   };
   float2 prev = make_float2(0.f, 0.f);
   bool dead = false;
+  // The step counter's LDS address lives in a register for the whole band (the empty asm keeps it opaque, so the compiler cannot
+  // rematerialise it from an SGPR with a v_mov in every step -- a step is issue-bound, every instruction is ~0.65 % of it:
+  // profiles/r03_sweep_step_isa.txt).  (Measured and rejected: counting with an LDS atomic add of a register-resident 1 -- two
+  // instructions fewer, but the 64 lanes of the wave serialise on the one address: sweeps +17 %.)
+  typedef __attribute__((address_space(3))) int lds_int;
+  lds_int* cntp = (lds_int*)&sm.outHead[w];
+  asm volatile("" : "+v"(cntp));
 #ifdef PF_SWEEP_STATS
   int statHits = 0, statSpins = 0;
   long long statT0 = 0, statWait = 0, statR8 = 0, statC0 = 0;
@@ -540,7 +552,9 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       prev = fin;   // "no pixel" steps (gate < 0) hand on their zero record: never used as a neighbour (masked / outside the image)
       // ---- publish: result ring (all 8 lanes of a row store the same value to the same slot), then the step counter ----
       outChunk[j * kRows] = fin;
-      st_cnt(&sm.outHead[w], s + 1);
+      asm volatile("" ::: "memory");   // after the result (LDS operations of one wave execute in issue order)
+      __hip_atomic_store(cntp, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" : "+v"(cntp));
       ra = na; rb = nb; rc = nc;
     }
   }

@@ -116,7 +116,7 @@ def classify(line):
         rest = rest[:m.start()]
     ops = split_ops(rest)
     i = Ins(); i.text = t; i.mn = mn; i.lds = False
-    nodst = mn.startswith(("ds_write", "global_store", "buffer_store", "s_waitcnt", "s_nop", "s_branch", "s_cbranch", "s_sleep", "s_barrier", "s_setprio", "s_endpgm", "s_sethalt"))
+    nodst = mn.startswith(("ds_write", "ds_add", "ds_max", "ds_min", "ds_or", "global_store", "buffer_store", "s_waitcnt", "s_nop", "s_branch", "s_cbranch", "s_sleep", "s_barrier", "s_setprio", "s_endpgm", "s_sethalt"))
     i.dst, i.src = [], []
     if mn.startswith("s_cmp"):
         i.dst = ["scc"]; i.src = sum((regs_of(o) for o in ops), [])
@@ -137,7 +137,7 @@ def classify(line):
             i.dst = i.dst + ["exec"]
     if mn.startswith("ds_read"):
         i.kind = "ds_read"; i.lds = True
-    elif mn.startswith("ds_write"):
+    elif mn.startswith("ds_"):           # stores and LDS atomics without a returned value
         i.kind = "ds_write"; i.lds = True
     elif mn == "s_waitcnt":
         i.kind = "wait"
