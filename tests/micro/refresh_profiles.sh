@@ -11,7 +11,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p
 grep "^{\"metric\"" gpurun_out/prof_$R.log | tail -1 > gpurun_out/${R}_bench_line.json
 cp $(find gpurun_out/prof_$R -name '*kernel_stats.csv' | head -1) gpurun_out/${R}_bench_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcb_$c -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-profile > gpurun_out/pmcb_$c.log 2>&1
+  timeout 1200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcb_$c -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-profile > gpurun_out/pmcb_$c.log 2>&1
   echo "$c rc=$?"
 done
 python - <<PY
