@@ -1,0 +1,60 @@
+// Exact, cheaper forms of the IEEE square root and of the division by a constant, as the sweep kernels use them
+// (kernels_sweep2.hip).  Own header so that tools/exact_forms_check.hip tests exactly this code, exhaustively, on the GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+namespace pf {
+// ---- exact, cheaper forms of the two IEEE operations that dominate a lone wave's step ------------------
+// (measured on MI355X: correctly rounded sqrtf ~118 cycles, division ~78 cycles per dependent use)
+// sqrt: the core of LLVM's correctly rounded f32 sqrt (v_sqrt_f32 is within 1 ulp; test the two neighbours
+// with exact FMA residuals) without its denormal pre-scaling: valid for x == 0 or x >= 2^-96, finite.
+__device__ __forceinline__ float sqrt_core(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
+  const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+  s = (rm <= 0.0f) ? sm : s;
+  s = (rp > 0.0f) ? sp : s;
+  return s;
+}
+// a / c for a constant c with y = (float)(1.0 / (double)c), the correctly rounded reciprocal: ONE FMA refinement step
+// (Markstein).  q0 = RN(a*y) is within 1.5 ulp of a/c, so the residual r0 = a - q0*c is exact and
+// q0 + r0*y = a/c * (1 + d) with |d| <= 1.5 * 2^-24 ulp.  That rounds to RN(a/c) unless a/c lies that close to a midpoint
+// between two floats:
+//  * c = an image width (integer of k <= 21 bits): a/c - midpoint = (integer != 0) / (c * 2^(k+1)), i.e. at least
+//    2^-(k+1) ulp away -- never that close;
+//  * c = 0.001f (24 significant bits, the bound above does not help): checked bit-exact against IEEE division for
+//    EVERY float a with |a| in [2^-100, 2^100] (3.36e9 inputs), plus 4.8e9 random (a, c) with c = 2..12000:
+//    tests/micro/divtest.c, 0 mismatches.  a == 0 is exact.
+//    Both again, exhaustively and on the device, by tools/exact_forms_check (tests/test_gpu_exact_forms.py).
+// Below 2^-100 the residual underflows: the callers' range guard (emin) keeps every numerator above 2^-95.
+// a == -0 gives +0 where IEEE gives -0: no caller can pass it (the numerators are c*|x| and differences e1 - e0 of
+// energies that are sums of square roots, i.e. never -0)
+__device__ __forceinline__ float div_core(float a, float c, float y) {
+  const float q0 = a * y;
+  const float r0 = __builtin_fmaf(-q0, c, a);
+  return __builtin_fmaf(r0, y, q0);
+}
+// two quotients by the same constant at once (packed fp32 FMA)
+typedef float f2p __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2p div_core2(f2p a, float c, float y) {
+  const f2p cc = {c, c}, yy = {y, y};
+  const f2p q0 = a * yy;
+  const f2p r0 = __builtin_elementwise_fma(-q0, cc, a);
+  return __builtin_elementwise_fma(r0, yy, q0);
+}
+// Two correctly rounded square roots at once: the reciprocal-square-root form (v_rsq_f32 is within 1 ulp; Newton step on
+// (s, h = 1/(2s)) and a final exact-residual correction, all packed FMAs): 10 instructions for the pair instead of 16
+// for two sqrt_core.  x == 0 gives 0 (the 2^-126 added to the v_rsq operand changes no x >= 2^-102 and keeps rsq(0)
+// finite).  Verified on the MI355X against the correctly rounded sqrtf for EVERY float in [2^-96, 2^100] and 0
+// (tests/micro/sqrt_exhaust.hip, run by tests/test_gpu_exact_forms.py).
+__device__ __forceinline__ f2p sqrt_core2(f2p x) {
+  const f2p xt = x + f2p{0x1p-126f, 0x1p-126f};
+  const f2p r = {__builtin_amdgcn_rsqf(xt.x), __builtin_amdgcn_rsqf(xt.y)};
+  f2p s = x * r;
+  f2p h = r * f2p{0.5f, 0.5f};
+  const f2p e = __builtin_elementwise_fma(-h, s, f2p{0.5f, 0.5f});
+  h = __builtin_elementwise_fma(h, e, h);
+  s = __builtin_elementwise_fma(s, e, s);
+  const f2p d = __builtin_elementwise_fma(-s, s, x);
+  return __builtin_elementwise_fma(d, h, s);
+}
+}  // namespace pf

@@ -30,6 +30,7 @@
 
 #include "pf_common.hpp"
 #include "sweep_window.hpp"
+#include "exact_forms.hpp"
 
 namespace pf {
 
@@ -99,38 +100,6 @@ __device__ __forceinline__ float d_error2(const float2* __restrict__ g1, int W, 
          kVerticalRegularizationCoef * fabsf(fdy) / fW + kHorizontalRegularizationCoef * fabsf(fdx) / fW;
 }
 
-// ---- exact, cheaper forms of the two IEEE operations that dominate a lone wave's step ------------------
-// (measured on MI355X: correctly rounded sqrtf ~118 cycles, division ~78 cycles per dependent use)
-// sqrt: the core of LLVM's correctly rounded f32 sqrt (v_sqrt_f32 is within 1 ulp; test the two neighbours
-// with exact FMA residuals) without its denormal pre-scaling: valid for x == 0 or x >= 2^-96, finite.
-__device__ __forceinline__ float sqrt_core(float x) {
-  float s = __builtin_amdgcn_sqrtf(x);
-  const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
-  const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
-  s = (rm <= 0.0f) ? sm : s;
-  s = (rp > 0.0f) ? sp : s;
-  return s;
-}
-// a / c for a constant c with y = (float)(1.0 / (double)c): two FMA refinement steps (Markstein).  Verified
-// bit-exact against IEEE division on the CPU for every float a with |a| in [2^-100, 2^100] for c = 0.001f
-// (3.36e9 inputs) and for 4.8e9 random (a, c) with c = 2..12000 (tests/micro/divtest.c); a == 0 is exact.
-__device__ __forceinline__ float div_core(float a, float c, float y) {
-  const float q0 = a * y;
-  const float r0 = __builtin_fmaf(-q0, c, a);
-  const float q1 = __builtin_fmaf(r0, y, q0);
-  const float r1 = __builtin_fmaf(-q1, c, a);
-  return __builtin_fmaf(r1, y, q1);
-}
-// two quotients by the same constant at once (packed fp32 FMA)
-typedef float f2p __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2p div_core2(f2p a, float c, float y) {
-  const f2p cc = {c, c}, yy = {y, y};
-  const f2p q0 = a * yy;
-  const f2p r0 = __builtin_elementwise_fma(-q0, cc, a);
-  const f2p q1 = __builtin_elementwise_fma(r0, yy, q0);
-  const f2p r1 = __builtin_elementwise_fma(-q1, cc, a);
-  return __builtin_elementwise_fma(r1, yy, q1);
-}
 // all of v0..v3 (>= 0) are zero or inside [2^-95, 2^100]: the range where sqrt_core/div_core are exact
 __device__ __forceinline__ bool fast_range_ok(float v0, float v1, float v2, float v3) {
   const int e0 = __builtin_amdgcn_frexp_expf(v0), e1 = __builtin_amdgcn_frexp_expf(v1), e2 = __builtin_amdgcn_frexp_expf(v2),
@@ -191,10 +160,12 @@ __device__ __forceinline__ float dpp_shl0(float src) {
 // of their latency, (C) bilinear + data term.  sched_barrier keeps the compiler from sinking B below the wait.
 template <bool TR, bool FWD>
 __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, const float2* __restrict__ win, int ob, int W, int H, float wm2, float hm2,
-                                              float fW, float rW, float fx, float fy, float i0x, float i0y, float bx, float by, float fdx, float fdy,
+                                              float fW, float rW, f2p pos, float i0x, float i0y, float bx, float by, f2p fd,
                                               int& emin, float& vmax) {
-  // ---- A ----
-  const float matchX = fx + fdx, matchY = fy + fdy;
+  // ---- A ----  (pos = the pixel's (x, y), fd = the candidate flow: packed fp32 wherever both components take the same operation)
+  const float fdx = fd.x, fdy = fd.y;
+  const f2p match = pos + fd;
+  const float matchX = match.x, matchY = match.y;
   const float cx = __builtin_amdgcn_fmed3f(matchX, 0.0f, wm2);   // min(w-2, max(0, v)) incl. NaN -> 0 (med3 with a NaN input returns min3)
   const float cy = __builtin_amdgcn_fmed3f(matchY, 0.0f, hm2);
   const int x0 = int(cx), y0 = int(cy);
@@ -230,12 +201,15 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, con
   __builtin_amdgcn_sched_barrier(0);
   // ---- B ----
   const float xR = __builtin_amdgcn_fractf(cx), yR = __builtin_amdgcn_fractf(cy);   // cx, cy >= 0: exactly cx - float(int(cx))
-  const float dfx = bx - fdx, dfy = by - fdy;
-  float s2 = dfx * dfx + dfy * dfy;
+  const f2p df = f2p{bx, by} - fd;
+  const f2p df2 = df * df;
+  float s2 = df2.x + df2.y;
   asm volatile("" : "+v"(s2));   // a finished scalar here: otherwise the SLP vectoriser packs this add with d2's below behind two register moves (3 instructions for 2)
-  const float av = kVerticalRegularizationCoef * fabsf(fdy), ah = kHorizontalRegularizationCoef * fabsf(fdx);
+  float av = kVerticalRegularizationCoef * fabsf(fdy);
+  asm volatile("" : "+v"(av));   // keeps the two products scalar (|x| is a free source modifier there); packed, they need two v_and for the abs: 3 instructions for 2
+  const float ah = kHorizontalRegularizationCoef * fabsf(fdx);
   const f2p reg = div_core2(f2p{av, ah}, fW, rW);
-  const float sm = sqrt_core(s2) * kSmoothnessCoef, rv = reg.x, rh = reg.y;
+  const float rv = reg.x, rh = reg.y;
   emin = min(min(__builtin_amdgcn_frexp_expf(s2), __builtin_amdgcn_frexp_expf(av)), __builtin_amdgcn_frexp_expf(ah));   // 0 for a zero operand
   vmax = __builtin_fmaxf(__builtin_fmaxf(s2, av), ah);
   __builtin_amdgcn_sched_barrier(0);
@@ -251,10 +225,12 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, con
     const float a1 = f00, a2 = f10 - f00, a3 = f01 - f00, a4 = f00 + f11 - f10 - f01;
     i1y = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
   }
-  const float d2 = (i0x - i1x) * (i0x - i1x) + (i0y - i1y) * (i0y - i1y);
+  float d2 = (i0x - i1x) * (i0x - i1x) + (i0y - i1y) * (i0y - i1y);
+  asm volatile("" : "+v"(d2));   // a scalar add into the register next to s2 (not a packed add + a move of s2)
   emin = min(emin, __builtin_amdgcn_frexp_expf(d2));
   vmax = __builtin_fmaxf(vmax, d2);
-  return sqrt_core(d2) + sm + rv + rh;
+  const f2p sq = sqrt_core2(f2p{d2, s2});   // both square roots of the step as one packed sequence
+  return sq.x + sq.y * kSmoothnessCoef + rv + rh;
 }
 
 // The tail of a step for the lane that owns the pixel (lane 0 of its group of 8): gather the six values, select in the
@@ -271,17 +247,18 @@ __device__ __forceinline__ float2 select_step(float e, float eC, float exC, floa
   const bool pickT = okT && (eT < cur);
   cur = pickT ? eT : cur; ex = pickT ? exT : ex; ey = pickT ? eyT : ey;
   f.x = pickT ? T.x : f.x; f.y = pickT ? T.y : f.y;
-  const float dgx = ex - cur, dgy = ey - cur;
-  float gx, gy;
   if (FAST) {
-    const float ax = fabsf(dgx), ay = fabsf(dgy);
-    const f2p g2 = div_core2(f2p{dgx, dgy}, kGradEpsilon, rEps);
-    gx = g2.x; gy = g2.y;
+    // packed fp32 from here on (a step is issue-bound: one v_pk_* per pair of operations): (ex, ey) - cur, / eps, f - 0.5 * g
+    const f2p dg = f2p{ex, ey} - f2p{cur, cur};
+    const float ax = fabsf(dg.x), ay = fabsf(dg.y);
+    const f2p g2 = div_core2(dg, kGradEpsilon, rEps);
     emin = min(emin, min(__builtin_amdgcn_frexp_expf(ax), __builtin_amdgcn_frexp_expf(ay)));
     vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(ax, ay));
-  } else {
-    gx = dgx / kGradEpsilon; gy = dgy / kGradEpsilon;
+    const f2p r = f2p{f.x, f.y} - f2p{kGradientStepSize, kGradientStepSize} * g2;
+    return make_float2(r.x, r.y);
   }
+  const float dgx = ex - cur, dgy = ey - cur;
+  const float gx = dgx / kGradEpsilon, gy = dgy / kGradEpsilon;
   return make_float2(f.x - kGradientStepSize * gx, f.y - kGradientStepSize * gy);
 }
 
@@ -391,7 +368,10 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   const float fcross = float(forward ? ib : LBx - 1 - ib);
   const float fLast = float(LS - 1);
   float fpos = forward ? float(uLo - r) : float(LS - 1 - uLo + r);   // step s handles sweep-order column uLo + s - r
-  int avail = 0;                       // columns [0, avail) of the row above are known to be in the ring
+  // Does the next step have to wait for its top value?  Decided at the end of each step from the producer's counter read
+  // during the step, with a vector compare straight on the loaded register (v_cmp + branch on vcc: two instructions fewer
+  // per step than moving the counter to an SGPR and comparing there).
+  bool waitTop = true;
   unsigned long long tv = 0;           // raw top value for the current step (read during the previous one)
   // flow-control counters for the NEXT chunk, read one chunk ahead (they only grow, a stale value is conservative)
   int fcRec = 0, fcTail = 0, fcPub = 0, fcNext = 0;
@@ -450,19 +430,28 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 #endif
     // Ring positions of the chunk (nsteps is a whole number of chunks; every ring length is a multiple of the chunk, so a
     // chunk never wraps inside a ring): with the step loop unrolled, the per-step ring addresses are base + constant.
-    const float4* recChunk = &sm.rec[w][s0 % kRS][r][0];                    // record of step s0 + j: recChunk + j * kRows * 3
-    const float4* recNext = &sm.rec[w][(s0 + kChunk) % kRS][r][0];          // first record of the next chunk
-    float2* outChunk = &sm.out[w][s0 % kOS][r];                             // result slot of step s0 + j: outChunk + j * kRows
-    const unsigned long long* topChunk = (TOP == 1) ? top_slot(s0 + 1) : &sm.bnd[s0 & (kBS - 1)] + 1;   // top value of column s0 + j + 1
-    const unsigned long long* topNext = top_slot(s0 + kChunk);              // ... of the next chunk's first column
+    // They are LDS pointers held in VGPRs across the chunk (opaque to the compiler, which otherwise recomputes each of them
+    // from s in every step: 3 + 1 + 1 instructions of a step that is issue-bound).
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef float f2w __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) const f4v lds_f4;
+    typedef __attribute__((address_space(3))) f2w lds_wf2;
+    typedef __attribute__((address_space(3))) const unsigned long long lds_u64;
+    lds_f4* recChunk = (lds_f4*)&sm.rec[w][s0 % kRS][r][0];                 // record of step s0 + j: recChunk + j * kRows * 3
+    lds_f4* recNext = (lds_f4*)&sm.rec[w][(s0 + kChunk) % kRS][r][0];       // first record of the next chunk
+    lds_wf2* outChunk = (lds_wf2*)&sm.out[w][s0 % kOS][r];                  // result slot of step s0 + j: outChunk + j * kRows
+    lds_u64* topChunk = (lds_u64*)((TOP == 1) ? top_slot(s0 + 1) : &sm.bnd[s0 & (kBS - 1)] + 1);   // top value of column s0 + j + 1
+    lds_u64* topNext = (lds_u64*)top_slot(s0 + kChunk);                     // ... of the next chunk's first column
+    asm volatile("" : "+v"(recChunk), "+v"(recNext), "+v"(outChunk));
+    if (TOP != 0) asm volatile("" : "+v"(topChunk), "+v"(topNext));
 #pragma unroll PF_SWEEP_UNROLL
     for (int j = 0; j < kChunk; ++j) {
       const int s = s0 + j;
       // ---- top neighbour: row r-1's result of the previous step (DPP); row 0 of the band from the ring ----
       float2 up = prev;   // lanes the two DPP moves do not write (row 0 of the band) keep this: the ring value when there is one
       if (TOP != 0) {
-        if (__builtin_expect(s >= avail, 0)) {
-          if (s < LSv) {
+        if (__builtin_expect(waitTop, 0)) {
+          if (!dead && s < LSv) {
             // at the edge of the producer: wait for this column (across workgroups: and the next one, i.e. fall one more
             // column behind, so that the following steps find their top value already read despite the HBM hop's jitter).
             // No early exit from the hot loop: a timeout only marks the band dead (checked once per chunk).
@@ -472,9 +461,9 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
             ++statHits;
 #endif
             for (;;) {
-              avail = __builtin_amdgcn_readfirstlane(ld_cnt(topHead)) - kBias;
+              const int avail = __builtin_amdgcn_readfirstlane(ld_cnt(topHead)) - kBias;   // columns [0, avail) of the row above are in the ring
               if (avail >= need) break;
-              if (spin_expired(spins, sm) || (((spins & 255) == 0) && ld_cnt(&sm.abort))) { dead = true; avail = 0x7fffffff; break; }
+              if (spin_expired(spins, sm) || (((spins & 255) == 0) && ld_cnt(&sm.abort))) { dead = true; break; }
             }
 #ifdef PF_SWEEP_STATS
             statSpins += spins;
@@ -494,7 +483,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       up.y = dpp<0x142, 0xE, 0x3>(up.y, prev.y);
       // ---- the six proposal evaluations, one per lane ----
       // fpos = this pixel's image coordinate along the step axis (exact small integers in fp32), +-1 per step
-      const float fx = transposed ? fcross : fpos, fy = transposed ? fpos : fcross;
+      const f2p posv = transposed ? f2p{fcross, fpos} : f2p{fpos, fcross};
       const float2 C = make_float2(rb.x, rb.y);
       const float eC = rb.z, exC = rb.w, eyC = rc.x, gatev = rc.y;
       // previous pixel along the step axis = own result of the previous step; previous pixel across = DPP/ring.
@@ -504,8 +493,8 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       int hN = 0; unsigned long long tvN = tv;
       // next step's inputs (LDS): records (unconditional: past the chunk it reads a slot that is reloaded at the chunk
       // start anyway), producer counter, then the top value.  Issued behind the gather inside the evaluation below.
-      const float4* rpn = (j + 1 < kChunk) ? recChunk + (j + 1) * (kRows * 3) : recNext;
-      const unsigned long long* tpn = (j + 1 < kChunk) ? topChunk + j * ((TOP == 1) ? kRows : 1) : topNext;
+      lds_f4* rpn = (j + 1 < kChunk) ? recChunk + (j + 1) * (kRows * 3) : recNext;
+      lds_u64* tpn = (j + 1 < kChunk) ? topChunk + j * ((TOP == 1) ? kRows : 1) : topNext;
       // Sparse overlap (full-canvas inputs, CPU/StitchTool.cpp:17-33): when no pixel of this anti-diagonal is gated
       // the whole step is bookkeeping only (wave-uniform branch; an ungated pixel keeps its flow, PixFlow.hpp:317).
       if (!SPARSE || __any(gatev > 0.0f)) {
@@ -519,8 +508,10 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 #ifdef PF_SWEEP_STATS
       if (__any(!(__builtin_fmaxf(fabsf(cand.x + addx), fabsf(cand.y + addy)) <= float(kRad - 1)))) ++statOOW;
 #endif
-      float e = d_error_fast<TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, fx, fy, ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy, emin, vmax);
-      na = rpn[0]; nb = rpn[1]; nc = *reinterpret_cast<const float2*>(rpn + 2);
+      const f2p fdv = f2p{cand.x, cand.y} + f2p{addx, addy};
+      float e = d_error_fast<TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, posv, ra.x, ra.y, ra.z, ra.w, fdv, emin, vmax);
+      { const f4v q0 = rpn[0], q1 = rpn[1]; const f2w q2 = *(__attribute__((address_space(3))) const f2w*)(rpn + 2);
+        na = make_float4(q0.x, q0.y, q0.z, q0.w); nb = make_float4(q1.x, q1.y, q1.z, q1.w); nc = make_float2(q2.x, q2.y); }
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
       fin = select_step<true>(e, eC, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
       asm volatile("" : "+v"(fin.x), "+v"(fin.y));   // finish the fast result before the branch: the range test then runs beside the division, not before it
@@ -531,27 +522,27 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
         ++statRedo;
 #endif
         // an operand left the range where the fast forms are exact: the whole wave redoes the step with IEEE sqrt and division
-        e = d_error2(g1, W, wm2, hm2, fW, int(fx), int(fy), ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
+        e = d_error2(g1, W, wm2, hm2, fW, int(posv.x), int(posv.y), ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
         fin = select_step<false>(e, eC, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
       }
       if (!(gatev > 0.0f)) fin = C;
       fin.x = bcast8(fin.x); fin.y = bcast8(fin.y);
       } else {
-      na = rpn[0]; nb = rpn[1]; nc = *reinterpret_cast<const float2*>(rpn + 2);
+      { const f4v q0 = rpn[0], q1 = rpn[1]; const f2w q2 = *(__attribute__((address_space(3))) const f2w*)(rpn + 2);
+        na = make_float4(q0.x, q0.y, q0.z, q0.w); nb = make_float4(q1.x, q1.y, q1.z, q1.w); nc = make_float2(q2.x, q2.y); }
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
       }
       fpos += forward ? 1.0f : -1.0f;
       if (TOP != 0) {
         // Take the values read ahead BEFORE the stores below: LDS operations return in order, so a wait for them
         // at the top of the next step would also wait for this step's publishing stores.
-        avail = __builtin_amdgcn_readfirstlane(hN) - kBias;
-        unsigned tlo = unsigned(tvN), thi = unsigned(tvN >> 32);
-        asm volatile("" : "+v"(tlo), "+v"(thi));
-        tv = (unsigned long long)tlo | ((unsigned long long)thi << 32);
+        waitTop = __any(s + 1 + kBias >= hN);   // column s + 1 not yet there (every lane holds the same counter value)
+        asm volatile("" : "+v"(tvN));   // the register PAIR as one operand: two 32-bit operands cost two v_mov per step to split and rejoin it
+        tv = tvN;
       }
       prev = fin;   // "no pixel" steps (gate < 0) hand on their zero record: never used as a neighbour (masked / outside the image)
       // ---- publish: result ring (all 8 lanes of a row store the same value to the same slot), then the step counter ----
-      outChunk[j * kRows] = fin;
+      outChunk[j * kRows] = f2w{fin.x, fin.y};
       asm volatile("" ::: "memory");   // after the result (LDS operations of one wave execute in issue order)
       __hip_atomic_store(cntp, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       asm volatile("" : "+v"(cntp));

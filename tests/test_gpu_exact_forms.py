@@ -1,0 +1,26 @@
+"""The sweep's cheap exact forms (csrc/exact_forms.hpp: sqrt via v_rsq_f32 / v_sqrt_f32 + FMA corrections, division by a
+constant with one FMA refinement) checked EXHAUSTIVELY on the device against the correctly rounded operations: every float
+the sweep's range guard admits (zero, 2^-96 .. 2^100), ~2e9..4e9 inputs per form.  The hardware approximations behind them
+cannot be emulated on a CPU, so this is the proof that the fast path computes the reference's sqrtf and '/' bit for bit
+(CPU/PixFlow.hpp:258-277 errorFunction, :322-341 the gradient step)."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BIN = os.path.join(HERE, "..", "panorama-opticalflow_amd", "tools", "exact_forms_check")
+
+
+@pytest.mark.gpu
+def test_exact_forms_exhaustive():
+    assert os.path.exists(BIN), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[-1] == "mismatches 0"
+    sq = [ln for ln in lines if ln.startswith("sqrt_core")][0]
+    assert int(sq.split("tested")[1].split()[0]) > 1_600_000_000   # 196 binades x 2^23 mantissas + zero
+    dv = [ln for ln in lines if ln.startswith("div by kGradEpsilon")][0]
+    assert int(dv.split("tested")[1].split()[0]) > 3_200_000_000   # both signs
