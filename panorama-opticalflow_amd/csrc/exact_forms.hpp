@@ -3,6 +3,19 @@
 #pragma once
 #include <hip/hip_runtime.h>
 namespace pf {
+typedef float f2p __attribute__((ext_vector_type(2)));
+// ---- chains of packed fp32 instructions as ONE inline-asm block ----------------------------------------------
+// The compiler (ROCm 7.2 LLVM) separates every v_pk_*_f32 from an immediately dependent VALU instruction with an s_nop:
+// its "dst_sel forwarding hazard" test reads bit 3 of src0_modifiers, which is DST_OP_SEL for VOP3 but op_sel_hi[0] for
+// VOP3P -- set on every ordinary packed instruction (and it assumes the same of any asm statement).  The hardware hazard
+// is about partial (16-bit) register writes; a packed fp32 result is two whole registers, and
+// tests/micro/pk_hazard_probe.hip shows dependent packed chains give the same bits with and without the wait states
+// (1 wave alone .. 16 waves per SIMD).  The sweep's step is issue-bound (every slot ~0.7 % of it) and these chains are
+// serial, so they are issued as one asm block each: no wait states inside.  The one REAL hazard inside is kept by hand:
+// a VALU instruction that reads the result of a transcendental one (v_rsq_f32) needs one wait state.  The blocks'
+// results are read by ordinary compiler-generated VALU instructions (never directly by a DPP instruction, whose
+// 2-wait-state hazard after a VALU write the compiler cannot see through an asm statement).
+
 // ---- exact, cheaper forms of the two IEEE operations that dominate a lone wave's step ------------------
 // (measured on MI355X: correctly rounded sqrtf ~118 cycles, division ~78 cycles per dependent use)
 // sqrt: the core of LLVM's correctly rounded f32 sqrt (v_sqrt_f32 is within 1 ulp; test the two neighbours
@@ -34,7 +47,6 @@ __device__ __forceinline__ float div_core(float a, float c, float y) {
   return __builtin_fmaf(r0, y, q0);
 }
 // two quotients by the same constant at once (packed fp32 FMA)
-typedef float f2p __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2p div_core2(f2p a, float c, float y) {
   const f2p cc = {c, c}, yy = {y, y};
   const f2p q0 = a * yy;
@@ -46,15 +58,22 @@ __device__ __forceinline__ f2p div_core2(f2p a, float c, float y) {
 // for two sqrt_core.  x == 0 gives 0 (the 2^-126 added to the v_rsq operand changes no x >= 2^-102 and keeps rsq(0)
 // finite).  Verified on the MI355X against the correctly rounded sqrtf for EVERY float in [2^-96, 2^100] and 0
 // (tests/micro/sqrt_exhaust.hip, run by tests/test_gpu_exact_forms.py).
-__device__ __forceinline__ f2p sqrt_core2(f2p x) {
+// Also returns frexp_exp(x.x) (the callers' range guard wants it): it is the independent instruction that fills the wait
+// state a VALU instruction needs after the v_rsq_f32 whose result it reads.
+__device__ __forceinline__ f2p sqrt_core2(f2p x, int& exp_x0) {
   const f2p xt = x + f2p{0x1p-126f, 0x1p-126f};
   const f2p r = {__builtin_amdgcn_rsqf(xt.x), __builtin_amdgcn_rsqf(xt.y)};
-  f2p s = x * r;
-  f2p h = r * f2p{0.5f, 0.5f};
-  const f2p e = __builtin_elementwise_fma(-h, s, f2p{0.5f, 0.5f});
-  h = __builtin_elementwise_fma(h, e, h);
-  s = __builtin_elementwise_fma(s, e, s);
-  const f2p d = __builtin_elementwise_fma(-s, s, x);
-  return __builtin_elementwise_fma(d, h, s);
+  f2p s, h, e, out;
+  const float x0 = x.x;
+  asm("v_frexp_exp_i32_f32 %4, %7\n\t"                  // (r.y comes from the transcendental unit one slot ago)
+      "v_pk_mul_f32 %0, %5, %6\n\t"                     // s = x * r
+      "v_pk_mul_f32 %1, %6, 0.5 op_sel_hi:[1,0]\n\t"    // h = r / 2
+      "v_pk_fma_f32 %2, %1, %0, 0.5 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   // e = 0.5 - h * s
+      "v_pk_fma_f32 %1, %1, %2, %1\n\t"                 // h = h + h * e
+      "v_pk_fma_f32 %0, %0, %2, %0\n\t"                 // s = s + s * e
+      "v_pk_fma_f32 %2, %0, %0, %5 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   // d = x - s * s (exact)
+      "v_pk_fma_f32 %3, %2, %1, %0"                      // s + d * h, correctly rounded
+      : "=&v"(s), "=&v"(h), "=&v"(e), "=&v"(out), "=&v"(exp_x0) : "v"(x), "v"(r), "v"(x0));
+  return out;
 }
 }  // namespace pf

@@ -225,11 +225,14 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, con
     const float a1 = f00, a2 = f10 - f00, a3 = f01 - f00, a4 = f00 + f11 - f10 - f01;
     i1y = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
   }
-  float d2 = (i0x - i1x) * (i0x - i1x) + (i0y - i1y) * (i0y - i1y);
+  f2p di, di2;   // (i0 - i1)^2 per channel: one asm block, see exact_forms.hpp
+  asm("v_pk_add_f32 %0, %2, %3 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_mul_f32 %1, %0, %0" : "=&v"(di), "=&v"(di2) : "v"(f2p{i0x, i0y}), "v"(f2p{i1x, i1y}));
+  float d2 = di2.x + di2.y;
   asm volatile("" : "+v"(d2));   // a scalar add into the register next to s2 (not a packed add + a move of s2)
-  emin = min(emin, __builtin_amdgcn_frexp_expf(d2));
   vmax = __builtin_fmaxf(vmax, d2);
-  const f2p sq = sqrt_core2(f2p{d2, s2});   // both square roots of the step as one packed sequence
+  int ed2;
+  const f2p sq = sqrt_core2(f2p{d2, s2}, ed2);   // both square roots of the step as one packed sequence (+ d2's exponent for the guard)
+  emin = min(emin, ed2);
   return sq.x + sq.y * kSmoothnessCoef + rv + rh;
 }
 

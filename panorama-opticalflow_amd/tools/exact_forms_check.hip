@@ -35,9 +35,11 @@ __global__ void k_check(int mode, float c, float y, Report* rep) {
       const unsigned pb = bits == 0 ? 0x3f9e3779u : (bits ^ 0x002aaaaau);
       const float p = __uint_as_float(pb);
       const float want = sqrtf(x), wantp = sqrtf(p), want64 = (float)sqrt((double)x);
-      const pf::f2p a = pf::sqrt_core2(pf::f2p{x, p}), b = pf::sqrt_core2(pf::f2p{p, x});
+      int ea, eb;
+      const pf::f2p a = pf::sqrt_core2(pf::f2p{x, p}, ea), b = pf::sqrt_core2(pf::f2p{p, x}, eb);
       const float s1 = pf::sqrt_core(x);
-      const bool ok = __float_as_uint(want) == __float_as_uint(want64) && __float_as_uint(s1) == __float_as_uint(want) &&
+      const bool ok = ea == __builtin_amdgcn_frexp_expf(x) && eb == __builtin_amdgcn_frexp_expf(p) &&
+                      __float_as_uint(want) == __float_as_uint(want64) && __float_as_uint(s1) == __float_as_uint(want) &&
                       __float_as_uint(a.x) == __float_as_uint(want) && __float_as_uint(b.y) == __float_as_uint(want) &&
                       __float_as_uint(a.y) == __float_as_uint(wantp) && __float_as_uint(b.x) == __float_as_uint(wantp);
       ++tested;
