@@ -41,6 +41,7 @@ constexpr int kRS = 32;      // record ring (steps): the loader runs up to three
 constexpr int kLoadAhead = 3; // chunks per wave the loader fetches in one round when the ring has room
 constexpr int kOS = 32;      // result ring (steps)
 constexpr int kBS = 256;     // boundary ring (columns)
+constexpr float kKeepEnergy = -1.0f;   // below every real energy: E(C), E(C+dx), E(C+dy) of a pixel the sweep must not change
 constexpr int kChunk = 8;    // steps streamed per helper iteration and wave
 constexpr int kRad = 8;      // LDS window of the gathered plane: +-kRad texels around the band
 constexpr int kWA = kRows + 2 * kRad + 1;   // window extent across the band (25)
@@ -240,11 +241,11 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, con
 // reference's order (current, then L, then T, strict '<'), forward-difference gradient step.  FAST uses div_core and
 // extends the running range guard; !FAST is the IEEE sequence.
 template <bool FAST>
-__device__ __forceinline__ float2 select_step(float e, float eC, float exC, float eyC, float2 C, float2 L, float2 T, bool okL, bool okT, float rEps,
+__device__ __forceinline__ float2 select_step(float e, float eC, float eCL, float exC, float eyC, float2 C, float2 L, float2 T, bool okL, bool okT, float rEps,
                                               int& emin, float& vmax) {
   // gather the group's six values in its lane 0 (row_shl:n reads lane+n)
   const float eL = e, exL = dpp_shl0<1>(e), eyL = dpp_shl0<2>(e), eT = dpp_shl0<3>(e), exT = dpp_shl0<4>(e), eyT = dpp_shl0<5>(e);
-  const bool pickL = okL && (eL < eC);
+  const bool pickL = okL && (eL < eCL);   // eCL = eC, or below every energy where L does not exist (see the records)
   float cur = pickL ? eL : eC, ex = pickL ? exL : exC, ey = pickL ? eyL : eyC;
   float2 f; f.x = pickL ? L.x : C.x; f.y = pickL ? L.y : C.y;
   const bool pickT = okT && (eT < cur);
@@ -333,7 +334,9 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   const int r = lane >> 3, k = lane & 7;
   const int ib = band * kRows + r;           // index across the bands: row (normal) or column (transposed)
   const int LS = transposed ? H : W;         // extent along the step axis
-  const bool hasCross = ib > 0;              // the cross-lane neighbour (row/column before this one) exists
+  // the cross-lane neighbour (row/column before this one) exists: always, for a band that has a band before it (known at
+  // compile time there: the selection then needs no mask on that comparison -- one scalar instruction + one wait state per step)
+  const bool hasCross = (TOP != 0) || ib > 0;
   const float2* win = &sm.win[w][0][0];
   int ob = band * kRows - kRad;               // window origin across the bands
   asm volatile("" : "+s"(ob));                // opaque: otherwise the compiler splits it into (v - band*8) + 8, one more instruction on the address chain
@@ -367,10 +370,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   const long long statB = wall_clock64();
 #endif
   // image coordinates of this lane's pixel: across the bands (constant) and along the step axis (s - r in sweep order)
-  const int LBx = transposed ? W : H;
-  const float fcross = float(forward ? ib : LBx - 1 - ib);
   const float fLast = float(LS - 1);
-  float fpos = forward ? float(uLo - r) : float(LS - 1 - uLo + r);   // step s handles sweep-order column uLo + s - r
   // Does the next step have to wait for its top value?  Decided at the end of each step from the producer's counter read
   // during the step, with a vector compare straight on the loaded register (v_cmp + branch on vcc: two instructions fewer
   // per step than moving the counter to an SGPR and comparing there).
@@ -379,7 +379,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   // flow-control counters for the NEXT chunk, read one chunk ahead (they only grow, a stale value is conservative)
   int fcRec = 0, fcTail = 0, fcPub = 0, fcNext = 0;
   float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;   // this step's record (read one step ahead)
-  float2 rc = make_float2(0.f, 0.f);                          // only the first half of the record's third quad is used
+  float4 rc = ra;
   for (int s0 = 0; s0 < nsteps; s0 += kChunk) {
     // ---- once per 8 steps: records of the chunk present, result-ring slots of the chunk free ----
     if (dead) return false;
@@ -416,8 +416,8 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
         // The last step of the previous chunk read this chunk's first record ahead; that read was only good if the
         // record was already there, which the one-chunk-old counter just confirmed unless we had to wait.
         const float4* rp0 = &sm.rec[w][s0 % kRS][r][0];
-        ra = rp0[0]; rb = rp0[1]; rc = *reinterpret_cast<const float2*>(rp0 + 2);
-        asm volatile("" : "+v"(ra.x), "+v"(ra.y), "+v"(ra.z), "+v"(ra.w), "+v"(rb.x), "+v"(rb.y), "+v"(rb.z), "+v"(rb.w), "+v"(rc.x), "+v"(rc.y));
+        ra = rp0[0]; rb = rp0[1]; rc = rp0[2];
+        asm volatile("" : "+v"(ra.x), "+v"(ra.y), "+v"(ra.z), "+v"(ra.w), "+v"(rb.x), "+v"(rb.y), "+v"(rb.z), "+v"(rb.w), "+v"(rc.x), "+v"(rc.y), "+v"(rc.z), "+v"(rc.w));
       }
     }
     // read the counters again for the next chunk; the loads complete in the shadow of this chunk's steps
@@ -485,14 +485,16 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       up.x = dpp<0x142, 0xE, 0x3>(up.x, prev.x);             // row_bcast:15 -> lanes 0-7 of rows 1..3 (lane 15 of the row above)
       up.y = dpp<0x142, 0xE, 0x3>(up.y, prev.y);
       // ---- the six proposal evaluations, one per lane ----
-      // fpos = this pixel's image coordinate along the step axis (exact small integers in fp32), +-1 per step
-      const f2p posv = transposed ? f2p{fcross, fpos} : f2p{fpos, fcross};
+      // the pixel's image coordinates (exact small integers in fp32) come with its record
+      const f2p posv = f2p{rc.z, rc.w};
+      const float fpos = transposed ? rc.w : rc.z;   // along the step axis
       const float2 C = make_float2(rb.x, rb.y);
-      const float eC = rb.z, exC = rb.w, eyC = rc.x, gatev = rc.y;
+      const float eC = rb.z, exC = rb.w, eyC = rc.x, eCa = rc.y;
+      const bool gated = eC >= 0.0f;   // the pixel is updated (alpha0, alpha1 > 0.9): otherwise its record holds kKeepEnergy
       // previous pixel along the step axis = own result of the previous step; previous pixel across = DPP/ring.
       // Reference order is always "previous column, then previous row" (PixFlow.hpp:319-320 / :332-333).
       float2 fin = C;
-      float4 na, nb; float2 nc;
+      float4 na, nb, nc;
       int hN = 0; unsigned long long tvN = tv;
       // next step's inputs (LDS): records (unconditional: past the chunk it reads a slot that is reloaded at the chunk
       // start anyway), producer counter, then the top value.  Issued behind the gather inside the evaluation below.
@@ -500,9 +502,13 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       lds_u64* tpn = (j + 1 < kChunk) ? topChunk + j * ((TOP == 1) ? kRows : 1) : topNext;
       // Sparse overlap (full-canvas inputs, CPU/StitchTool.cpp:17-33): when no pixel of this anti-diagonal is gated
       // the whole step is bookkeeping only (wave-uniform branch; an ungated pixel keeps its flow, PixFlow.hpp:317).
-      if (!SPARSE || __any(gatev > 0.0f)) {
+      if (!SPARSE || __any(gated)) {
       // a missing neighbour is evaluated anyway (its slot holds a finite stale flow) and masked out of the selection
-      const bool hasAlong = forward ? (fpos > 0.0f) : (fpos < fLast);
+      // The proposal of the previous pixel ALONG the step axis is missing at the first pixel of a row.  When that proposal is
+      // L (not transposed) the record says so by itself: L is compared with eCa = kKeepEnergy there (no compare, no mask).
+      // Transposed, it is T, which is compared with a value computed in the step: masked as before.
+      const bool hasAlong = transposed ? (forward ? (fpos > 0.0f) : (fpos < fLast)) : true;
+      const float eCL = transposed ? eC : eCa;
       const float2 L = transposed ? up : prev;
       const float2 T = transposed ? prev : up;
       const bool okL = transposed ? hasCross : hasAlong, okT = transposed ? hasAlong : hasCross;
@@ -513,29 +519,28 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 #endif
       const f2p fdv = f2p{cand.x, cand.y} + f2p{addx, addy};
       float e = d_error_fast<TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, posv, ra.x, ra.y, ra.z, ra.w, fdv, emin, vmax);
-      { const f4v q0 = rpn[0], q1 = rpn[1]; const f2w q2 = *(__attribute__((address_space(3))) const f2w*)(rpn + 2);
-        na = make_float4(q0.x, q0.y, q0.z, q0.w); nb = make_float4(q1.x, q1.y, q1.z, q1.w); nc = make_float2(q2.x, q2.y); }
+      { const f4v q0 = rpn[0], q1 = rpn[1], q2 = rpn[2];
+        na = make_float4(q0.x, q0.y, q0.z, q0.w); nb = make_float4(q1.x, q1.y, q1.z, q1.w); nc = make_float4(q2.x, q2.y, q2.z, q2.w); }
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-      fin = select_step<true>(e, eC, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
+      fin = select_step<true>(e, eC, eCL, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
       asm volatile("" : "+v"(fin.x), "+v"(fin.y));   // finish the fast result before the branch: the range test then runs beside the division, not before it
       // Only pixels that will be updated count: the lanes of a pixel without data (gate <= 0) still run the arithmetic, and
       // there the inputs are blur tails of black borders (operands ~1e-40) -- their result is discarded two lines below.
-      if (__builtin_expect(__any((emin < -94 || !(vmax <= 0x1p100f)) && gatev > 0.0f), 0)) {
+      if (__builtin_expect(__any((emin < -94 || !(vmax <= 0x1p100f)) && gated), 0)) {
 #ifdef PF_SWEEP_STATS
         ++statRedo;
 #endif
         // an operand left the range where the fast forms are exact: the whole wave redoes the step with IEEE sqrt and division
         e = d_error2(g1, W, wm2, hm2, fW, int(posv.x), int(posv.y), ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
-        fin = select_step<false>(e, eC, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
+        fin = select_step<false>(e, eC, eCL, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
       }
-      if (!(gatev > 0.0f)) fin = C;
+      // (a pixel that is not updated keeps C through its record: kKeepEnergy, see d_make_record)
       fin.x = bcast8(fin.x); fin.y = bcast8(fin.y);
       } else {
-      { const f4v q0 = rpn[0], q1 = rpn[1]; const f2w q2 = *(__attribute__((address_space(3))) const f2w*)(rpn + 2);
-        na = make_float4(q0.x, q0.y, q0.z, q0.w); nb = make_float4(q1.x, q1.y, q1.z, q1.w); nc = make_float2(q2.x, q2.y); }
+      { const f4v q0 = rpn[0], q1 = rpn[1], q2 = rpn[2];
+        na = make_float4(q0.x, q0.y, q0.z, q0.w); nb = make_float4(q1.x, q1.y, q1.z, q1.w); nc = make_float4(q2.x, q2.y, q2.z, q2.w); }
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
       }
-      fpos += forward ? 1.0f : -1.0f;
       if (TOP != 0) {
         // Take the values read ahead BEFORE the stores below: LDS operations return in order, so a wait for them
         // at the top of the next step would also wait for this step's publishing stores.
@@ -573,13 +578,17 @@ __device__ __forceinline__ void d_make_record(size_t tid, size_t total, const fl
   const int s = int((tid / kRows) % nstepsPad);
   const int band = int(tid / (size_t(kRows) * nstepsPad));
   const int ia = uLo + s - r, ib = (bandLo + band) * kRows + r;
-  a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; c = make_float4(0.f, -1.0f, 0.f, 0.f);
+  // A pixel that is not updated (gate <= 0) carries E(C) = E(C+dx) = E(C+dy) = kKeepEnergy: every proposal's energy is >= 0
+  // (or NaN), so the selection keeps C, and the gradient step is C - 0.5 * ((E - E) / eps) = C bit for bit -- the sweep's
+  // step needs no "if not gated keep C" of its own (two v_cndmask per step).
+  a = make_float4(0.f, 0.f, 0.f, 0.f); b = make_float4(0.f, 0.f, kKeepEnergy, kKeepEnergy); c = make_float4(kKeepEnergy, kKeepEnergy, 0.f, 0.f);
   if (tid < total && s - r >= 0 && ia < uHi && ia < LS && ib < LB) {
     const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;   // position in sweep order
     const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
     const size_t idx = size_t(y) * W + x;
     const float2 f = flow[idx];
-    b.x = f.x; b.y = f.y; c.y = 0.0f;
+    b.x = f.x; b.y = f.y;
+    c.z = float(x); c.w = float(y);   // the pixel's image coordinates (exact small integers)
     if (gate[idx]) {
       const float2 g = g0[idx], bl = blurred[idx];
       const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
@@ -587,7 +596,7 @@ __device__ __forceinline__ void d_make_record(size_t tid, size_t total, const fl
       b.z = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x, f.y);
       b.w = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x + kGradEpsilon, f.y + 0.0f);
       c.x = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
-      c.y = 1.0f;
+      c.y = (ia > 0) ? b.z : kKeepEnergy;   // E(C) as the proposal from the previous pixel ALONG the step axis sees it: unbeatable at the first pixel of a row (there is none)
     }
   }
 }
@@ -595,8 +604,11 @@ __device__ __forceinline__ void d_make_record(size_t tid, size_t total, const fl
 // ------------------------------------------------------------------------------------------------
 // prepass: records in wavefront order.  rec[((band*nstepsPad + s)*8 + r)*3 + j] for the ACTIVE window of the sweep:
 // band counts from bandLo, step s handles sweep-order column uLo + s - r (columns [uLo, uHi)).
-//   j=0: (I0x, I0y, blurred.x, blurred.y)   j=1: (C.x, C.y, E(C), E(C+dx))   j=2: (E(C+dy), gate, 0, 0)
-//   gate: 1 = update (alpha0,alpha1 > 0.9), 0 = keep C, -1 = no pixel at this (step,row)
+//   j=0: (I0x, I0y, blurred.x, blurred.y)   j=1: (C.x, C.y, E(C), E(C+dx))   j=2: (E(C+dy), Ea, x, y)
+//   (x, y) = the pixel's image coordinates as floats; Ea = E(C), or kKeepEnergy at the first pixel of a row in sweep order
+//   (what the proposal of the previous pixel along the axis is compared with: no such pixel there, no mask needed).
+//   A pixel that is not updated (alpha <= 0.9: keep C) and a (step,row) slot without a pixel carry kKeepEnergy in all four
+//   energies; "updated" is E(C) >= 0.
 // When the window does not start at the first band, the row above it never changes during this sweep: its flow
 // is written as the granule row the first workgroup's poller reads (top0).
 // ------------------------------------------------------------------------------------------------
@@ -788,13 +800,13 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
       float2 wv[kLoadAhead][4]; int ws[kLoadAhead][4]; bool wok[kLoadAhead][4]; bool ld[kLoadAhead];
       float2 pv[4][4]; int ps[4][4]; bool pk[4][4];   // first round only: batches 0..3 (0 and 1 lie before the window: they exist when the window does not start at the image border)
       // fused prepass, phase 1: the inputs of up to kLoadAhead chunks are requested together (one round trip)
-      float2 qf[kLoadAhead], qg[kLoadAhead], qb[kLoadAhead]; int qgate[kLoadAhead], qx[kLoadAhead], qy[kLoadAhead]; bool qvalid[kLoadAhead];
+      float2 qf[kLoadAhead], qg[kLoadAhead], qb[kLoadAhead]; int qgate[kLoadAhead], qx[kLoadAhead], qy[kLoadAhead], ia_of[kLoadAhead]; bool qvalid[kLoadAhead];
 #pragma unroll
       for (int c = 0; c < kLoadAhead; ++c) {
         const int r0 = rh + c * kChunk;
         va[c] = z4; vb[c] = z4; vc[c] = z4;
         ld[c] = r0 < nsteps && (r0 + kChunk - oh <= kRS);
-        qf[c] = make_float2(0.f, 0.f); qg[c] = qf[c]; qb[c] = qf[c]; qgate[c] = 0; qx[c] = 0; qy[c] = 0; qvalid[c] = false;
+        qf[c] = make_float2(0.f, 0.f); qg[c] = qf[c]; qb[c] = qf[c]; qgate[c] = 0; qx[c] = 0; qy[c] = 0; ia_of[c] = 0; qvalid[c] = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { wv[c][k] = make_float2(0.f, 0.f); ws[c][k] = 0; wok[c][k] = false; }
         if (ld[c]) {
@@ -803,6 +815,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
             va[c] = src[lane]; vb[c] = src[lane + 64]; vc[c] = src[lane + 128];
           } else {
             const int sstep = r0 + lj, ia = uLo + sstep - lr;
+            ia_of[c] = ia;
             qvalid[c] = sstep - lr >= 0 && ia < uLo + LSv && ia < LS && lib < LB;
             const int cxs = TR ? lib : ia, cys = TR ? ia : lib;   // position in sweep order
             qx[c] = qvalid[c] ? (FWD ? cxs : W - 1 - cxs) : 0; qy[c] = qvalid[c] ? (FWD ? cys : H - 1 - cys) : 0;
@@ -831,8 +844,8 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
             const float e2 = d_error2g(g1, W, wm2, hm2, fW, rW, qx[c], qy[c], g.x, g.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
             float4* dst = &sm.rec[w][(rh + c * kChunk) % kRS][0][0] + lane * 3;   // slot (lane >> 3, lane & 7) = linear slot `lane`
             dst[0] = on ? make_float4(g.x, g.y, bl.x, bl.y) : z4;
-            dst[1] = make_float4(qvalid[c] ? f.x : 0.f, qvalid[c] ? f.y : 0.f, on ? e0 : 0.f, on ? e1 : 0.f);
-            dst[2] = make_float4(on ? e2 : 0.f, qvalid[c] ? (on ? 1.0f : 0.0f) : -1.0f, 0.f, 0.f);
+            dst[1] = make_float4(qvalid[c] ? f.x : 0.f, qvalid[c] ? f.y : 0.f, on ? e0 : kKeepEnergy, on ? e1 : kKeepEnergy);
+            dst[2] = make_float4(on ? e2 : kKeepEnergy, (on && ia_of[c] > 0) ? e0 : kKeepEnergy, float(qx[c]), float(qy[c]));
           }
         }
       }

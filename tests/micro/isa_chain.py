@@ -55,8 +55,10 @@ DS_CYC = {"ds_read_b32": 2, "ds_read_b64": 2, "ds_read_b128": 4, "ds_read2st64_b
 
 def compile_asm():
     out = "/tmp/isa_chain_sweep2.s"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-mllvm",
-                           "-amdgpu-sched-strategy=max-ilp", "-S", "--cuda-device-only", SRC, "-o", out], stderr=subprocess.DEVNULL)
+    # the flags of the Makefile (FLAGS + FLAGS_kernels_sweep2); ISA_FLAGS="..." replaces the scheduler flags for what-if runs
+    sched = os.environ.get("ISA_FLAGS", "-mllvm -amdgpu-sched-strategy=max-ilp").split()
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"] + sched +
+                          ["-S", "--cuda-device-only", SRC, "-o", out], stderr=subprocess.DEVNULL)
     return out
 
 
