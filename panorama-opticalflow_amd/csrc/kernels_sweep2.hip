@@ -46,6 +46,8 @@ constexpr int kChunk = 8;    // steps streamed per helper iteration and wave
 constexpr int kRad = 8;      // LDS window of the gathered plane: +-kRad texels around the band
 constexpr int kWA = kRows + 2 * kRad + 1;   // window extent across the band (25)
 constexpr int kWC = 64;      // window ring along the step axis (columns)
+constexpr int kWCp = kWC + 1; // row stride of the window: ring column 0 is stored a second time behind column 63, so that the
+                              // right-hand texel of a bilinear footprint is always the NEXT slot (no second ring wrap on the address chain)
 // Every wait is bounded by WALL-CLOCK time, not by a spin count: the deadline (kernel entry + a budget the host scales with
 // the launch: 2 s + 1000x the expected duration) sits in LDS and is only looked at every 1024 polls.  A band that is merely
 // slow -- several contexts oversubscribing the GPU, a predecessor workgroup not scheduled yet -- therefore never raises
@@ -160,7 +162,7 @@ __device__ __forceinline__ float dpp_shl0(float src) {
 // the texel reads, (B) every term that does not need the texels (smoothness, the two regularisers) in the shadow
 // of their latency, (C) bilinear + data term.  sched_barrier keeps the compiler from sinking B below the wait.
 template <bool TR, bool FWD>
-__device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, const float2* __restrict__ win, int ob, int W, int H, float wm2, float hm2,
+__device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __attribute__((address_space(3))) const float2* win, int ob, int W, int H, float wm2, float hm2,
                                               float fW, float rW, f2p pos, float i0x, float i0y, float bx, float by, f2p fd,
                                               int& emin, float& vmax) {
   // ---- A ----  (pos = the pixel's (x, y), fd = the candidate flow: packed fp32 wherever both components take the same operation)
@@ -175,20 +177,30 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, con
   // not on the clamped position: one max + one compare, off the address chain.  (NaN flows compare false -> HBM path.)
   const bool inwin = __builtin_fmaxf(fabsf(fdx), fabsf(fdy)) <= float(kRad - 1);
   // sweep-order coordinates of texel (x0,y0): u along the step axis, v across the bands
-  const int cxc = FWD ? x0 : W - 1 - x0, cyc = FWD ? y0 : H - 1 - y0;
-  const int u0 = TR ? cyc : cxc, v0 = TR ? cxc : cyc;
-  constexpr int sg = FWD ? 1 : -1;
+  // The 2x2 footprint in sweep order is (v0, v0 + sg) x (u0, u0 + sg), sg = +1 forward / -1 backward.  Addressed from its LOWER
+  // corner (vlo, ulo) it is two adjacent slots in two adjacent window rows -- the slot after ring column 63 holds column 0 again
+  // (kWCp) -- so one ring wrap and one address serve all four texels (immediate offsets 0, 1, kWCp, kWCp + 1).
+  const int cxl = FWD ? x0 : W - 2 - x0, cyl = FWD ? y0 : H - 2 - y0;
+  const int ulo = TR ? cyl : cxl, vlo = TR ? cxl : cyl;
   // out-of-window lanes are clamped to a valid window row (they read garbage that the HBM path below overwrites)
-  const int a0 = min(max(v0 - ob, FWD ? 0 : 1), FWD ? kWA - 2 : kWA - 1);
-  const int o00 = a0 * kWC + (u0 & (kWC - 1)), oal = a0 * kWC + ((u0 + sg) & (kWC - 1));   // +1 along the step axis (ring wrap)
-  const int o10 = TR ? o00 + sg * kWC : oal;          // texel (x0+1, y0)
-  const int o01 = TR ? oal : o00 + sg * kWC;          // texel (x0, y0+1)
-  const int o11 = oal + sg * kWC;                     // texel (x0+1, y0+1)
+  const int alo = min(max(vlo - ob, 0), kWA - 2);
+  auto q = [&](int dr, int dc) { return (FWD ? dr : 1 - dr) * kWCp + (FWD ? dc : 1 - dc); };   // texel (v0 + sg*dr, u0 + sg*dc), relative to the corner
+  const int o00 = q(0, 0);                            // texel (x0, y0)
+  const int o10 = TR ? q(1, 0) : q(0, 1);             // texel (x0+1, y0)
+  const int o01 = TR ? q(0, 1) : q(1, 0);             // texel (x0, y0+1)
+  const int o11 = q(1, 1);                            // texel (x0+1, y0+1)
   // LDS reads are unconditional (out-of-window lanes read a clamped slot and are overwritten below) so that the two
   // address spaces never meet in one pointer -- a merged pointer would turn every access into a slow flat_load.
   typedef float f2v __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) const f2v lds_f2;
-  lds_f2* win3 = (lds_f2*)win;   // explicit LDS address space: ds_read_b64, never a flat access
+  // explicit LDS address space: ds_read2_b64, never a flat access.  The corner's byte address as (ring column << 3) + window, then
+  // + row * stride in one 24-bit multiply-add: five instructions from (x0, y0) to the address.
+  unsigned ringCol = unsigned(ulo & (kWC - 1));
+  asm("" : "+v"(ringCol));   // (x & 63) << 3 + base as v_and + v_lshl_add, not the canonical v_lshl + v_and + v_add
+  const unsigned cornerCol = (ringCol << 3) + (unsigned)(size_t)win;
+  unsigned cornerAddr;   // = alo * row stride + cornerCol; written out because the compiler turns it into v_mul_u32_u24 + v_add3_u32 (one more)
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(cornerAddr) : "v"(alo), "s"(unsigned(kWCp * sizeof(float2))), "v"(cornerCol));
+  lds_f2* win3 = (lds_f2*)(size_t)cornerAddr;
   const f2v w00 = win3[o00], w10 = win3[o10], w01 = win3[o01], w11 = win3[o11];
   float2 t00 = make_float2(w00.x, w00.y), t10 = make_float2(w10.x, w10.y), t01 = make_float2(w01.x, w01.y), t11 = make_float2(w11.x, w11.y);
   // wave-uniform test first: the common "every lane inside the window" case costs a compare + one scalar branch, not an exec-mask
@@ -287,7 +299,7 @@ __device__ __forceinline__ float bcast8(float v) {
 struct Smem {
   float4 rec[kWaves][kRS][kRows][3];
   float2 out[kWaves][kOS][kRows];
-  float2 win[kWaves][kWA][kWC];           // (I1x,I1y) texels around each band, sweep-order coordinates, ring along the step axis
+  float2 win[kWaves][kWA][kWCp];          // (I1x,I1y) texels around each band, sweep-order coordinates, ring along the step axis (+ column 0 again)
   unsigned long long bnd[kBS];            // granules of the previous workgroup's last row (poller -> wave 0), valid below bndHead
   int recHead[kWaves];   // steps of records available to wave w        (stream helper -> compute)
   int outHead[kWaves];   // steps completed by wave w                    (compute -> helpers, next wave)
@@ -337,7 +349,11 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   // the cross-lane neighbour (row/column before this one) exists: always, for a band that has a band before it (known at
   // compile time there: the selection then needs no mask on that comparison -- one scalar instruction + one wait state per step)
   const bool hasCross = (TOP != 0) || ib > 0;
-  const float2* win = &sm.win[w][0][0];
+  // The band's window as an LDS address the compiler cannot take apart (an SGPR): with the struct offset visible it splits the
+  // four texel reads over two address registers instead of one address + immediate offsets.
+  typedef __attribute__((address_space(3))) const float2 lds_cf2;
+  lds_cf2* win = (lds_cf2*)&sm.win[w][0][0];
+  asm volatile("" : "+s"(win));
   int ob = band * kRows - kRad;               // window origin across the bands
   asm volatile("" : "+s"(ob));                // opaque: otherwise the compiler splits it into (v - band*8) + 8, one more instruction on the address chain
   const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
@@ -768,11 +784,17 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
     float2* winw = &sm.win[w][0][0];
     auto win_addr = [&](int b, int k, int& slot) -> const float2* {   // texel k of this lane in batch b
       const int u = uLo + 8 * b - 16 + tc[k], v = (bandLo + band0 + w) * kRows - kRad + ta[k];   // absolute sweep-order texel
-      slot = ta[k] * kWC + (u & (kWC - 1));
+      slot = ta[k] * kWCp + (u & (kWC - 1));
       if (!tvalid[k] || u < 0 || u >= LS || v < 0 || v >= LB) return nullptr;
       const int cxc = TR ? v : u, cyc = TR ? u : v;
       const int x = FWD ? cxc : W - 1 - cxc, y = FWD ? cyc : H - 1 - cyc;
       return g1 + (y * W + x);
+    };
+    // ring column 0 also goes to the slot behind column 63 (kWCp); tc/ta are loop invariant, a batch is 8 consecutive columns:
+    // texel k of this lane lands on ring column 0 in the batches with (uLo + 8b - 16 + tc[k]) % 64 == 0
+    auto win_store = [&](int slot, float2 v) {
+      winw[slot] = v;
+      if (slot % kWCp == 0) winw[slot + kWC] = v;
     };
     constexpr bool fused = MODE == 1;
     const float4* recw = fused ? nullptr : rec + size_t(band0 + w) * nstepsPad * (kRows * 3);
@@ -865,7 +887,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
         for (int b = 0; b < 4; ++b)
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-            if (pk[b][k]) winw[ps[b][k]] = pv[b][k];
+            if (pk[b][k]) win_store(ps[b][k], pv[b][k]);
         first = false;
       }
       bool progress = false;
@@ -875,7 +897,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
           float4* dst = &sm.rec[w][rh % kRS][0][0];
           if (!fused) { dst[lane] = va[c]; dst[lane + 64] = vb[c]; dst[lane + 128] = vc[c]; }
 #pragma unroll
-          for (int k = 0; k < 4; ++k) if (wok[c][k]) winw[ws[c][k]] = wv[c][k];
+          for (int k = 0; k < 4; ++k) if (wok[c][k]) win_store(ws[c][k], wv[c][k]);
           rh += kChunk;
           st_cnt(&sm.recHead[w], rh);
           progress = true;
