@@ -285,13 +285,13 @@ __global__ __launch_bounds__(kRXThreads) void k_sweep_relax(const float2* __rest
           const float2 C = sm.cC[q], g = sm.cG[q], bl = sm.cB[q];
           const float2 L = okL ? unpack2(u > 0 ? sm.P[q - 1] : sm.haloL[v]) : C;
           const float2 T = okT ? unpack2(v > 0 ? sm.P[q - kT] : sm.haloT[u]) : C;
-          const float2 base = k < 3 ? L : T;
-          const int kk = k < 3 ? k : k - 3;
+          const float2 base = k < 4 ? L : T;   // lane roles of select_step: 0-2 the L proposal (+0, +dx, +dy), 4-6 the T proposal
+          const int kk = k & 3;
           const float fx = base.x + (kk == 1 ? kGradEpsilon : 0.0f), fy = base.y + (kk == 2 ? kGradEpsilon : 0.0f);
           float e = 0.0f;
-          if (act && k < 6) e = d_error_rx(g1, sm.win, wx0, wy0, W, wm2, hm2, fW, rW, FWD ? cu : W - 1 - cu, FWD ? cv : H - 1 - cv, g.x, g.y, bl.x, bl.y, fx, fy);
+          if (act && kk < 3) e = d_error_rx(g1, sm.win, wx0, wy0, W, wm2, hm2, fW, rW, FWD ? cu : W - 1 - cu, FWD ? cv : H - 1 - cv, g.x, g.y, bl.x, bl.y, fx, fy);
           int emin = 0; float vmax = 0.0f;
-          const float2 o = select_step<false>(e, sm.cE[0][q], sm.cE[0][q], sm.cE[1][q], sm.cE[2][q], C, L, T, okL, okT, 0.0f, emin, vmax);
+          const float2 o = select_step<false, false>(e, sm.cE[0][q], sm.cE[0][q], sm.cE[1][q], sm.cE[2][q], C, L, T, okL, okT, 0.0f, emin, vmax);
           if (act && k == 0) {
             atomicAnd(&sm.bits[pc][q >> 5], ~(1u << (q & 31)));
             const unsigned long long nv = pack2(o);

@@ -252,11 +252,13 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
 // The tail of a step for the lane that owns the pixel (lane 0 of its group of 8): gather the six values, select in the
 // reference's order (current, then L, then T, strict '<'), forward-difference gradient step.  FAST uses div_core and
 // extends the running range guard; !FAST is the IEEE sequence.
-template <bool FAST>
+template <bool FAST, bool TR>
 __device__ __forceinline__ float2 select_step(float e, float eC, float eCL, float exC, float eyC, float2 C, float2 L, float2 T, bool okL, bool okT, float rEps,
                                               int& emin, float& vmax) {
-  // gather the group's six values in its lane 0 (row_shl:n reads lane+n)
-  const float eL = e, exL = dpp_shl0<1>(e), eyL = dpp_shl0<2>(e), eT = dpp_shl0<3>(e), exT = dpp_shl0<4>(e), eyT = dpp_shl0<5>(e);
+  // gather the group's six values in its lane 0 (row_shl:n reads lane+n): lanes 0-2 hold the along-axis proposal's three
+  // energies, lanes 4-6 the across proposal's; L is the along one unless the sweep is transposed
+  const float eA = e, exA = dpp_shl0<1>(e), eyA = dpp_shl0<2>(e), eX = dpp_shl0<4>(e), exX = dpp_shl0<5>(e), eyX = dpp_shl0<6>(e);
+  const float eL = TR ? eX : eA, exL = TR ? exX : exA, eyL = TR ? eyX : eyA, eT = TR ? eA : eX, exT = TR ? exA : exX, eyT = TR ? eyA : eyX;
   const bool pickL = okL && (eL < eCL);   // eCL = eC, or below every energy where L does not exist (see the records)
   float cur = pickL ? eL : eC, ex = pickL ? exL : exC, ey = pickL ? eyL : eyC;
   float2 f; f.x = pickL ? L.x : C.x; f.y = pickL ? L.y : C.y;
@@ -300,6 +302,7 @@ struct Smem {
   float4 rec[kWaves][kRS][kRows][3];
   float2 out[kWaves][kOS][kRows];
   float2 win[kWaves][kWA][kWCp];          // (I1x,I1y) texels around each band, sweep-order coordinates, ring along the step axis (+ column 0 again)
+  float2 scratch[kWaves][128];            // where lanes 1-7 of a group "store" in the publishing step (lane + 8 * step-in-chunk)
   unsigned long long bnd[kBS];            // granules of the previous workgroup's last row (poller -> wave 0), valid below bndHead
   int recHead[kWaves];   // steps of records available to wave w        (stream helper -> compute)
   int outHead[kWaves];   // steps completed by wave w                    (compute -> helpers, next wave)
@@ -357,8 +360,11 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   int ob = band * kRows - kRad;               // window origin across the bands
   asm volatile("" : "+s"(ob));                // opaque: otherwise the compiler splits it into (v - band*8) + 8, one more instruction on the address chain
   const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
-  const bool candIsT = (k >= 3);
-  const int kk = k % 3;
+  // Lane roles inside a pixel's group of 8: lanes 0-2 evaluate the proposal of the previous pixel ALONG the step axis (this
+  // row's own last result) at +0, +dx, +dy; lanes 4-6 the proposal of the pixel ACROSS (the row above); lanes 3 and 7 repeat
+  // lanes 0 and 4.  Quads, because DPP bank masks select quads: each lane's proposal arrives by DPP straight from the lane
+  // that computed it (lane 0 of a group), no select.
+  const int kk = k & 3;
   const float addx = (kk == 1) ? kGradEpsilon : 0.0f, addy = (kk == 2) ? kGradEpsilon : 0.0f;
   const bool lastPub = publishes && (w == kWaves - 1);
   const bool hasNext = (w + 1 < nact);
@@ -458,7 +464,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
     typedef __attribute__((address_space(3))) const unsigned long long lds_u64;
     lds_f4* recChunk = (lds_f4*)&sm.rec[w][s0 % kRS][r][0];                 // record of step s0 + j: recChunk + j * kRows * 3
     lds_f4* recNext = (lds_f4*)&sm.rec[w][(s0 + kChunk) % kRS][r][0];       // first record of the next chunk
-    lds_wf2* outChunk = (lds_wf2*)&sm.out[w][s0 % kOS][r];                  // result slot of step s0 + j: outChunk + j * kRows
+    lds_wf2* outChunk = (lds_wf2*)((k == 0) ? &sm.out[w][s0 % kOS][r] : &sm.scratch[w][lane]);   // result slot of step s0 + j: outChunk + j * kRows (lanes 1-7 of a group hold no result: scratch)
     lds_u64* topChunk = (lds_u64*)((TOP == 1) ? top_slot(s0 + 1) : &sm.bnd[s0 & (kBS - 1)] + 1);   // top value of column s0 + j + 1
     lds_u64* topNext = (lds_u64*)top_slot(s0 + kChunk);                     // ... of the next chunk's first column
     asm volatile("" : "+v"(recChunk), "+v"(recNext), "+v"(outChunk));
@@ -466,8 +472,10 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 #pragma unroll PF_SWEEP_UNROLL
     for (int j = 0; j < kChunk; ++j) {
       const int s = s0 + j;
-      // ---- top neighbour: row r-1's result of the previous step (DPP); row 0 of the band from the ring ----
-      float2 up = prev;   // lanes the two DPP moves do not write (row 0 of the band) keep this: the ring value when there is one
+      // ---- this lane's proposal: lanes 0-3 of a group <- the group's own last result (its lane 0), lanes 4-7 <- the result of
+      // the row above (lane 0 of the group before; row 0 of the band: the ring value).  prev is valid in lane 0 of a group only. ----
+      // lanes no DPP move writes (lanes 4-7 of the band's row 0) keep this: the ring value (there is one unless this is the first band)
+      float2 cnd = prev;
       if (TOP != 0) {
         if (__builtin_expect(waitTop, 0)) {
           if (!dead && s < LSv) {
@@ -494,12 +502,28 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
             tv = (unsigned long long)tlo | ((unsigned long long)thi << 32);
           }
         }
-        up = unpack2(tv);
+        cnd = unpack2(tv);
       }
-      up.x = dpp<0x118, 0xF, 0xC>(up.x, prev.x);             // row_shr:8 into lanes 8-15 of each row of 16
-      up.y = dpp<0x118, 0xF, 0xC>(up.y, prev.y);
-      up.x = dpp<0x142, 0xE, 0x3>(up.x, prev.x);             // row_bcast:15 -> lanes 0-7 of rows 1..3 (lane 15 of the row above)
-      up.y = dpp<0x142, 0xE, 0x3>(up.y, prev.y);
+      // Every move reads prev itself (one DPP hop from the lane that computed it; only the hop into the next row of 16 lanes
+      // needs a second one): the chain prev -> proposal is 1-2 dependent DPP moves, not 4 and a select.
+      if (TOP != 0) {
+        cnd.x = dpp<0x150, 0xF, 0x9>(cnd.x, prev.x);         // row_newbcast:0 -> lanes 0-3 (own) and 12-15 (the row above of the odd group)
+        cnd.y = dpp<0x150, 0xF, 0x9>(cnd.y, prev.y);
+      } else {
+        // first band: no ring value.  Lanes 4-7 of row 0 take the row's own last result as well (masked out of the selection, but
+        // evaluated: prev is only meaningful in lane 0 of a group, a wild value would send the wave through the out-of-window path
+        // in every step); with every lane written by one of the moves there is no previous value to set up.
+        cnd.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(prev.x), 0x150, 0xF, 0xB, false));
+        cnd.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(prev.y), 0x150, 0xF, 0xB, false));
+      }
+      float2 t15;
+      // row_newbcast:8 -> lane 15 (lanes 12-15; the other lanes are not used): the odd group's result, for the next row of 16
+      t15.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(prev.x), 0x158, 0xF, 0x8, true));
+      t15.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(prev.y), 0x158, 0xF, 0x8, true));
+      cnd.x = dpp<0x158, 0xF, 0x4>(cnd.x, prev.x);           // row_newbcast:8 -> lanes 8-11 (own, odd group)
+      cnd.y = dpp<0x158, 0xF, 0x4>(cnd.y, prev.y);
+      cnd.x = dpp<0x142, 0xE, 0x2>(cnd.x, t15.x);            // row_bcast:15 -> lanes 4-7 of rows 1..3 (lane 15 of the row of 16 above)
+      cnd.y = dpp<0x142, 0xE, 0x2>(cnd.y, t15.y);
       // ---- the six proposal evaluations, one per lane ----
       // the pixel's image coordinates (exact small integers in fp32) come with its record
       const f2p posv = f2p{rc.z, rc.w};
@@ -525,10 +549,13 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       // Transposed, it is T, which is compared with a value computed in the step: masked as before.
       const bool hasAlong = transposed ? (forward ? (fpos > 0.0f) : (fpos < fLast)) : true;
       const float eCL = transposed ? eC : eCa;
-      const float2 L = transposed ? up : prev;
-      const float2 T = transposed ? prev : up;
+      // the two proposals' flows for the selection in lane 0: its own, and the across one from lane 4 (off the critical chain)
+      const float2 along = cnd;
+      const float2 across = make_float2(dpp_shl0<4>(cnd.x), dpp_shl0<4>(cnd.y));
+      const float2 L = transposed ? across : along;
+      const float2 T = transposed ? along : across;
       const bool okL = transposed ? hasCross : hasAlong, okT = transposed ? hasAlong : hasCross;
-      const float2 cand = candIsT ? T : L;
+      const float2 cand = cnd;
       int emin; float vmax;
 #ifdef PF_SWEEP_STATS
       if (__any(!(__builtin_fmaxf(fabsf(cand.x + addx), fabsf(cand.y + addy)) <= float(kRad - 1)))) ++statOOW;
@@ -538,7 +565,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       { const f4v q0 = rpn[0], q1 = rpn[1], q2 = rpn[2];
         na = make_float4(q0.x, q0.y, q0.z, q0.w); nb = make_float4(q1.x, q1.y, q1.z, q1.w); nc = make_float4(q2.x, q2.y, q2.z, q2.w); }
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-      fin = select_step<true>(e, eC, eCL, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
+      fin = select_step<true, TR>(e, eC, eCL, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
       asm volatile("" : "+v"(fin.x), "+v"(fin.y));   // finish the fast result before the branch: the range test then runs beside the division, not before it
       // Only pixels that will be updated count: the lanes of a pixel without data (gate <= 0) still run the arithmetic, and
       // there the inputs are blur tails of black borders (operands ~1e-40) -- their result is discarded two lines below.
@@ -548,10 +575,9 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 #endif
         // an operand left the range where the fast forms are exact: the whole wave redoes the step with IEEE sqrt and division
         e = d_error2(g1, W, wm2, hm2, fW, int(posv.x), int(posv.y), ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
-        fin = select_step<false>(e, eC, eCL, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
+        fin = select_step<false, TR>(e, eC, eCL, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
       }
       // (a pixel that is not updated keeps C through its record: kKeepEnergy, see d_make_record)
-      fin.x = bcast8(fin.x); fin.y = bcast8(fin.y);
       } else {
       { const f4v q0 = rpn[0], q1 = rpn[1], q2 = rpn[2];
         na = make_float4(q0.x, q0.y, q0.z, q0.w); nb = make_float4(q1.x, q1.y, q1.z, q1.w); nc = make_float4(q2.x, q2.y, q2.z, q2.w); }
@@ -564,8 +590,8 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
         asm volatile("" : "+v"(tvN));   // the register PAIR as one operand: two 32-bit operands cost two v_mov per step to split and rejoin it
         tv = tvN;
       }
-      prev = fin;   // "no pixel" steps (gate < 0) hand on their zero record: never used as a neighbour (masked / outside the image)
-      // ---- publish: result ring (all 8 lanes of a row store the same value to the same slot), then the step counter ----
+      prev = fin;   // valid in lane 0 of each group.  "no pixel" steps hand on their zero record: never used as a neighbour (masked / outside the image)
+      // ---- publish: result ring (lane 0 of a group stores to the slot, the other lanes to a scratch slot of their own), then the step counter ----
       outChunk[j * kRows] = f2w{fin.x, fin.y};
       asm volatile("" ::: "memory");   // after the result (LDS operations of one wave execute in issue order)
       __hip_atomic_store(cntp, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -3,7 +3,7 @@
 
   1. compiles csrc/kernels_sweep2.hip to gfx950 assembly with the product's flags (or takes --asm FILE),
   2. cuts the three steady-state loops of compute_band<TOP = 0 / 1 / 2> out of k_sweep2<TR=0, FWD=1, SPARSE=0, MODE=0> (each is the
-     8-step unrolled chunk; a step starts at its first `row_shr:8` DPP move = the hand-over of the previous step's result),
+     8-step unrolled chunk; a step starts at its first `row_newbcast:0` DPP move = the hand-over of the previous step's result),
   3. builds the register dependency graph of the not-taken (steady-state) path and prices it two ways:
        * recurrence  = the loop-carried dependency cycle alone: longest latency-weighted path through two copies of the chunk
                        minus the path through one, / 8 steps -- what an infinitely wide machine would need per step;
@@ -281,7 +281,7 @@ def main():
     k0 = next(n for n, l in enumerate(lines) if l.startswith(KERNEL))
     k1 = next(n for n in range(k0 + 1, len(lines)) if lines[n].strip().startswith("s_endpgm"))
     body = lines[k0:k1]
-    marks = [n for n, l in enumerate(body) if "row_shr:8" in l]
+    marks = [n for n, l in enumerate(body) if "row_newbcast:0" in l]
     marks = marks[::2]                       # two moves (x, y) per step
     loops = [marks[i:i + 8] for i in range(0, len(marks) - 7, 8)]
     lone = analyse(body, loops, lat, issue, a.clock_ghz)
@@ -308,7 +308,7 @@ def main():
                 "guide's 2-cycle wave64 VALU rate (MI355X_MICROARCH.md: SIMD-32) needs two or more waves per SIMD.  So a step costs its instruction\n"
                 "COUNT x the lone-wave issue interval; the loop-carried dependency cycle (`recurrence`) is about half of that and is not the limit.\n\n")
         f.write("Three instances of the loop exist in the kernel (compute_band<TOP>: first band of a sweep / band inside a workgroup / first band of a\n"
-                "workgroup); each is the 8-step unrolled chunk (a step starts at its first `row_shr:8` DPP move).\n\n")
+                "workgroup); each is the 8-step unrolled chunk (a step starts at its first `row_newbcast:0` DPP move).\n\n")
         for (e, _, _), (g, _, _) in zip(lone, guide):
             f.write("  loop %d: %.1f instructions per step (%.1f vector, %.1f LDS, %.1f scalar/control)%s\n"
                     "      lone-wave pricing : issue slots alone %4.0f cycles | recurrence %4.0f | ONE wave in order %4.0f cycles = %.4f us @ %.1f GHz\n"
@@ -352,7 +352,7 @@ def main():
         step_no = 0
         nstar = nwait = 0
         for k, i in enumerate(ins):
-            if "row_shr:8" in i.text and (k == 0 or "row_shr:8" not in ins[k - 1].text):
+            if "row_newbcast:0" in i.text and (k == 0 or "row_newbcast:0" not in ins[k - 1].text):
                 step_no += 1
                 f.write("  ---- step %d of the chunk ----\n" % step_no)
             start, why = tl[(5, k)]

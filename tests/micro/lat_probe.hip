@@ -15,7 +15,7 @@
 enum Mode {
   ADD_DEP, ADD_IND4, MUL_ADD_DEP, PK_ADD_DEP, PK_FMA_DEP, PK_MUL_DEP, PK_ADD_IND4, SQRT_DEP, SQRT_ADD_DEP, CMP64_CND_DEP, CMPVCC_CND_DEP, DPP_SHR8_DEP, DPP_BCAST_DEP,
   DPP_QUAD_DEP, DPP_SHL1_DEP, DPP_IND4, MED3_DEP, CVT_I32_DEP, FRACT_DEP, FREXP_DEP, LSHL_ADD_DEP, MIN3I_DEP, RFL_SALU_DEP, RFL_CMP_BRANCH, DS_B32_DEP, DS_B64_DEP, DS_B128_DEP,
-  DS_R2ST64_DEP, DS_WRITE_READ, DS_2XR2ST64_WAIT, SAVEEXEC_PAIR, NMODES
+  DS_R2ST64_DEP, DS_WRITE_READ, DS_2XR2ST64_WAIT, SAVEEXEC_PAIR, DPP_NEWBCAST_DEP, DPP_NEWBCAST_IND4, DS_WRITE64_SAME8, DS_WRITE64_DISTINCT, NMODES
 };
 static const char* kNames[NMODES] = {
     "v_add_f32 dependent", "v_add_f32 4 independent chains (per instr)", "v_mul_f32 + v_add_f32 dependent (per instr)", "v_pk_add_f32 dependent", "v_pk_fma_f32 dependent",
@@ -25,7 +25,8 @@ static const char* kNames[NMODES] = {
     "v_fract_f32 dependent", "v_frexp_exp_i32_f32 + v_cvt_f32_i32 (per pair)", "v_lshl_add_u32 dependent", "v_min3_i32 dependent", "v_readfirstlane -> v_mov from SGPR (per pair)",
     "v_readfirstlane -> s_cmp -> s_cbranch (not taken) -> v_add (per group)", "ds_read_b32 address-dependent chain", "ds_read_b64 address-dependent chain", "ds_read_b128 address-dependent chain",
     "ds_read2st64_b64 address-dependent chain", "ds_write_b64 + ds_write_b32 + ds_read_b32 of it + wait (per group)", "2 x ds_read2st64_b64 + s_waitcnt lgkmcnt(0) + use (per group)",
-    "s_and_saveexec_b64 + s_or_b64 exec pair + v_add (per group)"};
+    "s_and_saveexec_b64 + s_or_b64 exec pair + v_add (per group)", "v_mov_b32_dpp row_newbcast:0 dependent", "v_mov_b32_dpp row_newbcast 4 independent (per instr)",
+    "ds_write_b64, 8 distinct addresses (8 lanes each) (per instr)", "ds_write_b64, 64 distinct addresses (per instr)"};
 
 template <int MODE>
 __global__ void k(float* out, long long* res, int n) {
@@ -59,6 +60,12 @@ __global__ void k(float* out, long long* res, int n) {
     if (MODE == DPP_IND4) { REP8(asm volatile("s_nop 1\n v_mov_b32_dpp %0, %4 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32_dpp %1, %4 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
                                           "v_mov_b32_dpp %2, %4 row_shl:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32_dpp %3, %4 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1"
                                           : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(h));) }
+    if (MODE == DPP_NEWBCAST_DEP) { REP32(asm volatile("s_nop 1\n v_mov_b32_dpp %0, %0 row_newbcast:0 row_mask:0xf bank_mask:0x9" : "+v"(a));) }
+    if (MODE == DPP_NEWBCAST_IND4) { REP8(asm volatile("s_nop 1\n v_mov_b32_dpp %0, %4 row_newbcast:0 row_mask:0xf bank_mask:0x9\n v_mov_b32_dpp %1, %4 row_newbcast:8 row_mask:0xf bank_mask:0x4\n"
+                                          "v_mov_b32_dpp %2, %4 row_newbcast:8 row_mask:0xf bank_mask:0x8\n v_mov_b32_dpp %3, %4 row_newbcast:0 row_mask:0xf bank_mask:0x9"
+                                          : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(h));) }
+    if (MODE == DS_WRITE64_SAME8) { const unsigned ad = (threadIdx.x >> 3) * 8u; REP32(asm volatile("ds_write_b64 %0, %1 offset:1024" :: "v"(ad), "v"(pa) : "memory");) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    if (MODE == DS_WRITE64_DISTINCT) { const unsigned ad = threadIdx.x * 8u; REP32(asm volatile("ds_write_b64 %0, %1 offset:1024" :: "v"(ad), "v"(pa) : "memory");) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     if (MODE == MED3_DEP) { REP32(asm volatile("v_med3_f32 %0, %0, %1, 0" : "+v"(a) : "v"(b));) }
     if (MODE == CVT_I32_DEP) { REP32(asm volatile("v_cvt_i32_f32 %1, %0\n v_cvt_f32_i32 %0, %1" : "+v"(a), "+v"(ia));) }
     if (MODE == FRACT_DEP) { REP32(asm volatile("v_fract_f32 %0, %0" : "+v"(a));) }
@@ -83,7 +90,7 @@ __global__ void k(float* out, long long* res, int n) {
   if (threadIdx.x == 0) { res[0] = t1 - t0; res[1] = w1 - w0; }
 }
 
-static const int kPerIter[NMODES] = {32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32};
+static const int kPerIter[NMODES] = {32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32};
 
 template <int MODE>
 void run(float* out, long long* res) {
