@@ -272,7 +272,11 @@ __device__ __forceinline__ float2 select_step(float e, float eC, float eCL, floa
     const f2p g2 = div_core2(dg, kGradEpsilon, rEps);
     emin = min(emin, min(__builtin_amdgcn_frexp_expf(ax), __builtin_amdgcn_frexp_expf(ay)));
     vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(ax, ay));
-    const f2p r = f2p{f.x, f.y} - f2p{kGradientStepSize, kGradientStepSize} * g2;
+    // f - 0.5 * g as ONE fused multiply-add: the product with a power of two is exact (|g| >= 2^-84 or 0 inside the guard's
+    // range, so no underflow), hence the single rounding of the FMA is the rounding of the reference's subtraction -- bit for
+    // bit, signs of zero included (g = +0: f + (-0) = f) -- and one instruction less on the step's dependency chain.
+    static_assert(kGradientStepSize == 0.5f, "the exactness argument needs a power of two");
+    const f2p r = __builtin_elementwise_fma(g2, f2p{-kGradientStepSize, -kGradientStepSize}, f2p{f.x, f.y});
     return make_float2(r.x, r.y);
   }
   const float dgx = ex - cur, dgy = ey - cur;
