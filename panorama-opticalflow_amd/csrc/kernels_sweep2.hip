@@ -67,8 +67,8 @@ constexpr int kWCp = kWC + 1; // row stride of the window: ring column 0 is stor
 #ifndef PF_PUB_SLEEP
 #define PF_PUB_SLEEP 1    // publisher wave: s_sleep between two looks at the last band's step counter
 #endif
-#ifndef PF_POLL_GAP
-#define PF_POLL_GAP 2     // poller wave: s_sleep (x64 cycles) between two polls of the previous workgroup's granules; six polls are in flight
+#ifndef PF_POLL_SLEEP
+#define PF_POLL_SLEEP 1   // poller wave: s_sleep between two polls of the previous workgroup's granules
 #endif
 #define PF_STR2(x) #x
 #define PF_STR(x) PF_STR2(x)   // ~0.2 s of polling: a stuck band raises ctrl[1] instead of hanging the GPU
@@ -1017,82 +1017,35 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
     const unsigned long long* bnd_in = boundary + size_t(wg) * LSv;
     const bool topFromPlane = MODE != 0 && wg == 0;   // (wg == 0 only gets here with a static top row)
     int bh = 0, idle = 0;
-    if (!topFromPlane) {
-      // Several polls in flight.  One poll = one agent-scope load of 64 consecutive granules.  With a single poll outstanding a
-      // granule is seen, on average, 1.5 load round trips after it became visible (the poll in flight when it lands misses it),
-      // and the producer moves 2-3 columns per round trip: the first band of a workgroup ran ~7 steps behind the last band of
-      // the workgroup above on top of the 8 steps of skew.  kPolls loads issued kPollGap apart and retired in order bring that
-      // down to one round trip + the gap.  Every load keeps the window base it was issued with (a multiple of 32 at or below the
-      // first missing column at that time), so a retired load may deliver nothing new, some columns, or -- when other loads got
-      // ahead of it by more than its window -- nothing it still has to say.
-      // (global address space spelled out: through a generic pointer these would be FLAT loads, which count as LDS operations
-      // too -- every s_waitcnt for the LDS counter read below would then wait for all polls in flight)
-      typedef __attribute__((address_space(1))) const unsigned long long gmem_u64;
-      gmem_u64* bnd_g = (gmem_u64*)bnd_in;
-      constexpr int kPolls = 6, kRounds = 6;
-      unsigned long long g[kPolls];
-      int base[kPolls];
-      auto issue = [&](int i) {
-        base[i] = bh & ~31;
-        // unconditional (lanes past the end re-read the last granule; their value is ignored): a load under a branch would make
-        // the number of loads in flight path-dependent and the compiler wait for all of them (vmcnt(0)) instead of the oldest
-        const int col = min(base[i] + lane, LSv - 1);
-        g[i] = __hip_atomic_load(bnd_g + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_sleep(PF_POLL_GAP);
-      };
-      auto retire = [&](int i) -> bool {
-        const int b0 = base[i];
-        const unsigned long long v = g[i];
-        const bool ready = (v != kNotReady) || (b0 + lane >= LSv);
-        const unsigned long long m = __ballot(ready);
-        const int off = bh - b0;                                  // first column still missing, as a lane of this load
-        if (off >= 64) return false;
-        const unsigned long long run = ~(m >> off);               // zero bits = ready columns from `off` on
-        int n = run ? __builtin_ctzll(run) : 64;
-        n = (n > 64 - off) ? 64 - off : n;
-        const int room = kBS - (bh - ld_cnt(&sm.outHead[0]));     // ring slots wave 0 has already consumed
-        n = n > room ? room : n;
-        if (n <= 0) return false;
-        if (lane >= off && lane < off + n && b0 + lane < LSv) sm.bnd[(b0 + lane) % kBS] = v;
-        bh += n;
-        st_cnt(&sm.bndHead, bh);
-        return true;
-      };
-      // The loads of one pass of this loop are issued and retired in straight-line code (the compiler then waits for exactly the
-      // oldest one: s_waitcnt vmcnt(kPolls - 1); across a loop back-edge it would wait for all of them): kPolls in flight through
-      // kRounds x kPolls polls, then the pipeline drains once.
-      while (bh < LSv) {
-        bool progress = false;
-#pragma unroll
-        for (int i = 0; i < kPolls; ++i) issue(i);
-#pragma unroll
-        for (int r = 0; r < kRounds; ++r) {
-#pragma unroll
-          for (int i = 0; i < kPolls; ++i) { progress |= retire(i); issue(i); }
-        }
-#pragma unroll
-        for (int i = 0; i < kPolls; ++i) progress |= retire(i);
-        if (progress) idle = 0;
-        else if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-      }
-      return;
-    }
-    // fused prepass (lab build), first workgroup: the row above the window never changes during this sweep -- read it from the flow plane itself
     while (bh < LSv) {
       const int oh0 = ld_cnt(&sm.outHead[0]);
       if (bh + 64 - oh0 <= kBS) {
+        unsigned long long g = kNotReady;
         if (bh + lane < LSv) {
-          const int ia = uLo + bh + lane, ib = bandLo * kRows - 1;
-          const int cxs = TR ? ib : ia, cys = TR ? ia : ib;
-          const int x = FWD ? cxs : W - 1 - cxs, y = FWD ? cys : H - 1 - cys;
-          sm.bnd[(bh + lane) % kBS] = pack2(flow[y * W + x]);
+          if (topFromPlane) {
+            // fused prepass: the row above the window never changes during this sweep -- read it from the flow plane itself
+            const int ia = uLo + bh + lane, ib = bandLo * kRows - 1;
+            const int cxs = TR ? ib : ia, cys = TR ? ia : ib;
+            const int x = FWD ? cxs : W - 1 - cxs, y = FWD ? cys : H - 1 - cys;
+            g = pack2(flow[y * W + x]);
+          } else {
+            g = __hip_atomic_load(bnd_in + bh + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
-        bh += 64;
-        st_cnt(&sm.bndHead, bh < LSv ? bh : LSv);
-        idle = 0;
-        continue;
+        const bool ready = (g != kNotReady) || (bh + lane >= LSv);
+        const unsigned long long m = __ballot(ready);
+        const int n = (m == ~0ull) ? 64 : __builtin_ctzll(~m);
+        if (n > 0) {
+          if (lane < n && bh + lane < LSv) sm.bnd[(bh + lane) % kBS] = g;
+          bh += n;
+          st_cnt(&sm.bndHead, bh);
+          idle = 0;
+          continue;
+        }
+        __builtin_amdgcn_s_sleep(PF_POLL_SLEEP);
+      } else {
+        __builtin_amdgcn_s_sleep(8);
       }
-      __builtin_amdgcn_s_sleep(8);
       if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
   }
