@@ -249,39 +249,47 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   return sq.x + sq.y * kSmoothnessCoef + rv + rh;
 }
 
-// The tail of a step for the lane that owns the pixel (lane 0 of its group of 8): gather the six values, select in the
-// reference's order (current, then L, then T, strict '<'), forward-difference gradient step.  FAST uses div_core and
-// extends the running range guard; !FAST is the IEEE sequence.
+// The tail of a step.  Every proposal takes its OWN gradient step, in its own lane, before anybody knows which one wins: lane 0
+// of a group holds the along-axis proposal's E, lanes 1 and 2 its E(+dx), E(+dy) (lanes 4, 5, 6: the across proposal's), so two
+// DPP moves give lanes 0 and 4 their finite differences, and ONE pass through the division / update -- the same instructions
+// for all lanes -- produces both candidates' results from the proposal flow each lane already holds.  The current flow's own
+// step, rC = C - 0.5 * grad E(C) / eps, does not depend on the neighbours: it comes with the record (prepass).  Selection in
+// the reference's order (current, then L, then T, strict '<') then only has to pick one of three finished results in lane 0.
+// (Before: gather all six energies in lane 0, select (E, E+dx, E+dy, flow) in two stages of five v_cndmask, then one gradient
+// step: two DPP moves and five v_cndmask more per step, all on the dependency chain.)
+// FAST uses div_core and extends the running range guard; !FAST is the IEEE sequence.
 template <bool FAST, bool TR>
-__device__ __forceinline__ float2 select_step(float e, float eC, float eCL, float exC, float eyC, float2 C, float2 L, float2 T, bool okL, bool okT, float rEps,
-                                              int& emin, float& vmax) {
-  // gather the group's six values in its lane 0 (row_shl:n reads lane+n): lanes 0-2 hold the along-axis proposal's three
-  // energies, lanes 4-6 the across proposal's; L is the along one unless the sweep is transposed
-  const float eA = e, exA = dpp_shl0<1>(e), eyA = dpp_shl0<2>(e), eX = dpp_shl0<4>(e), exX = dpp_shl0<5>(e), eyX = dpp_shl0<6>(e);
-  const float eL = TR ? eX : eA, exL = TR ? exX : exA, eyL = TR ? eyX : eyA, eT = TR ? eA : eX, exT = TR ? exA : exX, eyT = TR ? eyA : eyX;
-  const bool pickL = okL && (eL < eCL);   // eCL = eC, or below every energy where L does not exist (see the records)
-  float cur = pickL ? eL : eC, ex = pickL ? exL : exC, ey = pickL ? eyL : eyC;
-  float2 f; f.x = pickL ? L.x : C.x; f.y = pickL ? L.y : C.y;
-  const bool pickT = okT && (eT < cur);
-  cur = pickT ? eT : cur; ex = pickT ? exT : ex; ey = pickT ? eyT : ey;
-  f.x = pickT ? T.x : f.x; f.y = pickT ? T.y : f.y;
+__device__ __forceinline__ float2 select_step(float e, float eC, float eCL, float2 rC, float2 cnd, bool okL, bool okT, float rEps, int& emin, float& vmax) {
+  const float g1 = dpp_shl0<1>(e), g2 = dpp_shl0<2>(e);   // row_shl:n reads lane+n
+  float2 rp;                                               // this lane's proposal after its gradient step (meaningful in lanes 0 and 4)
   if (FAST) {
-    // packed fp32 from here on (a step is issue-bound: one v_pk_* per pair of operations): (ex, ey) - cur, / eps, f - 0.5 * g
-    const f2p dg = f2p{ex, ey} - f2p{cur, cur};
+    // packed fp32 (a step is issue-bound: one v_pk_* per pair of operations): (E+dx, E+dy) - E, / eps, flow - 0.5 * g
+    const f2p dg = f2p{g1, g2} - f2p{e, e};
     const float ax = fabsf(dg.x), ay = fabsf(dg.y);
-    const f2p g2 = div_core2(dg, kGradEpsilon, rEps);
+    const f2p gq = div_core2(dg, kGradEpsilon, rEps);
     emin = min(emin, min(__builtin_amdgcn_frexp_expf(ax), __builtin_amdgcn_frexp_expf(ay)));
     vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(ax, ay));
-    // f - 0.5 * g as ONE fused multiply-add: the product with a power of two is exact (|g| >= 2^-84 or 0 inside the guard's
+    // flow - 0.5 * g as ONE fused multiply-add: the product with a power of two is exact (|g| >= 2^-84 or 0 inside the guard's
     // range, so no underflow), hence the single rounding of the FMA is the rounding of the reference's subtraction -- bit for
     // bit, signs of zero included (g = +0: f + (-0) = f) -- and one instruction less on the step's dependency chain.
     static_assert(kGradientStepSize == 0.5f, "the exactness argument needs a power of two");
-    const f2p r = __builtin_elementwise_fma(g2, f2p{-kGradientStepSize, -kGradientStepSize}, f2p{f.x, f.y});
-    return make_float2(r.x, r.y);
+    const f2p r = __builtin_elementwise_fma(gq, f2p{-kGradientStepSize, -kGradientStepSize}, f2p{cnd.x, cnd.y});
+    rp = make_float2(r.x, r.y);
+  } else {
+    const float gx = (g1 - e) / kGradEpsilon, gy = (g2 - e) / kGradEpsilon;
+    rp = make_float2(cnd.x - kGradientStepSize * gx, cnd.y - kGradientStepSize * gy);
   }
-  const float dgx = ex - cur, dgy = ey - cur;
-  const float gx = dgx / kGradEpsilon, gy = dgy / kGradEpsilon;
-  return make_float2(f.x - kGradientStepSize * gx, f.y - kGradientStepSize * gy);
+  // lane 0: the across proposal's energy and result from lane 4; L is the along-axis proposal unless the sweep is transposed
+  const float eX = dpp_shl0<4>(e);
+  const float2 rX = make_float2(dpp_shl0<4>(rp.x), dpp_shl0<4>(rp.y));
+  const float eL = TR ? eX : e, eT = TR ? e : eX;
+  const float2 rL = TR ? rX : rp, rT = TR ? rp : rX;
+  const bool pickL = okL && (eL < eCL);   // eCL = eC, or below every energy where L does not exist (see the records)
+  const float cur = pickL ? eL : eC;
+  const bool pickT = okT && (eT < cur);
+  float2 f; f.x = pickL ? rL.x : rC.x; f.y = pickL ? rL.y : rC.y;
+  f.x = pickT ? rT.x : f.x; f.y = pickT ? rT.y : f.y;
+  return f;
 }
 
 __device__ __forceinline__ unsigned long long pack2(float2 f) {
@@ -405,7 +413,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   // flow-control counters for the NEXT chunk, read one chunk ahead (they only grow, a stale value is conservative)
   int fcRec = 0, fcTail = 0, fcPub = 0, fcNext = 0;
   float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;   // this step's record (read one step ahead)
-  float4 rc = ra;
+  float2 rc = make_float2(0.f, 0.f);                          // only the first half of the record's third quad is used
   for (int s0 = 0; s0 < nsteps; s0 += kChunk) {
     // ---- once per 8 steps: records of the chunk present, result-ring slots of the chunk free ----
     if (dead) return false;
@@ -442,8 +450,8 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
         // The last step of the previous chunk read this chunk's first record ahead; that read was only good if the
         // record was already there, which the one-chunk-old counter just confirmed unless we had to wait.
         const float4* rp0 = &sm.rec[w][s0 % kRS][r][0];
-        ra = rp0[0]; rb = rp0[1]; rc = rp0[2];
-        asm volatile("" : "+v"(ra.x), "+v"(ra.y), "+v"(ra.z), "+v"(ra.w), "+v"(rb.x), "+v"(rb.y), "+v"(rb.z), "+v"(rb.w), "+v"(rc.x), "+v"(rc.y), "+v"(rc.z), "+v"(rc.w));
+        ra = rp0[0]; rb = rp0[1]; rc = *reinterpret_cast<const float2*>(rp0 + 2);
+        asm volatile("" : "+v"(ra.x), "+v"(ra.y), "+v"(ra.z), "+v"(ra.w), "+v"(rb.x), "+v"(rb.y), "+v"(rb.z), "+v"(rb.w), "+v"(rc.x), "+v"(rc.y));
       }
     }
     // read the counters again for the next chunk; the loads complete in the shadow of this chunk's steps
@@ -530,15 +538,15 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       cnd.y = dpp<0x142, 0xE, 0x2>(cnd.y, t15.y);
       // ---- the six proposal evaluations, one per lane ----
       // the pixel's image coordinates (exact small integers in fp32) come with its record
-      const f2p posv = f2p{rc.z, rc.w};
-      const float fpos = transposed ? rc.w : rc.z;   // along the step axis
-      const float2 C = make_float2(rb.x, rb.y);
-      const float eC = rb.z, exC = rb.w, eyC = rc.x, eCa = rc.y;
+      const f2p posv = f2p{rc.x, rc.y};
+      const float fpos = transposed ? rc.y : rc.x;   // along the step axis
+      const float eC = rb.x, eCa = rb.w;
+      const float2 rC = make_float2(rb.y, rb.z);   // the current flow C after its own gradient step (prepass); C itself where the pixel is not updated
       const bool gated = eC >= 0.0f;   // the pixel is updated (alpha0, alpha1 > 0.9): otherwise its record holds kKeepEnergy
       // previous pixel along the step axis = own result of the previous step; previous pixel across = DPP/ring.
       // Reference order is always "previous column, then previous row" (PixFlow.hpp:319-320 / :332-333).
-      float2 fin = C;
-      float4 na, nb, nc;
+      float2 fin = rC;   // (a step in which no pixel of the wave is updated: rC = C everywhere)
+      float4 na, nb; float2 nc;
       int hN = 0; unsigned long long tvN = tv;
       // next step's inputs (LDS): records (unconditional: past the chunk it reads a slot that is reloaded at the chunk
       // start anyway), producer counter, then the top value.  Issued behind the gather inside the evaluation below.
@@ -553,11 +561,6 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       // Transposed, it is T, which is compared with a value computed in the step: masked as before.
       const bool hasAlong = transposed ? (forward ? (fpos > 0.0f) : (fpos < fLast)) : true;
       const float eCL = transposed ? eC : eCa;
-      // the two proposals' flows for the selection in lane 0: its own, and the across one from lane 4 (off the critical chain)
-      const float2 along = cnd;
-      const float2 across = make_float2(dpp_shl0<4>(cnd.x), dpp_shl0<4>(cnd.y));
-      const float2 L = transposed ? across : along;
-      const float2 T = transposed ? along : across;
       const bool okL = transposed ? hasCross : hasAlong, okT = transposed ? hasAlong : hasCross;
       const float2 cand = cnd;
       int emin; float vmax;
@@ -566,10 +569,10 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 #endif
       const f2p fdv = f2p{cand.x, cand.y} + f2p{addx, addy};
       float e = d_error_fast<TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, posv, ra.x, ra.y, ra.z, ra.w, fdv, emin, vmax);
-      { const f4v q0 = rpn[0], q1 = rpn[1], q2 = rpn[2];
-        na = make_float4(q0.x, q0.y, q0.z, q0.w); nb = make_float4(q1.x, q1.y, q1.z, q1.w); nc = make_float4(q2.x, q2.y, q2.z, q2.w); }
+      { const f4v q0 = rpn[0], q1 = rpn[1]; const f2w q2 = *(__attribute__((address_space(3))) const f2w*)(rpn + 2);
+        na = make_float4(q0.x, q0.y, q0.z, q0.w); nb = make_float4(q1.x, q1.y, q1.z, q1.w); nc = make_float2(q2.x, q2.y); }
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-      fin = select_step<true, TR>(e, eC, eCL, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
+      fin = select_step<true, TR>(e, eC, eCL, rC, cnd, okL, okT, rEps, emin, vmax);
       asm volatile("" : "+v"(fin.x), "+v"(fin.y));   // finish the fast result before the branch: the range test then runs beside the division, not before it
       // Only pixels that will be updated count: the lanes of a pixel without data (gate <= 0) still run the arithmetic, and
       // there the inputs are blur tails of black borders (operands ~1e-40) -- their result is discarded two lines below.
@@ -579,12 +582,12 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 #endif
         // an operand left the range where the fast forms are exact: the whole wave redoes the step with IEEE sqrt and division
         e = d_error2(g1, W, wm2, hm2, fW, int(posv.x), int(posv.y), ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
-        fin = select_step<false, TR>(e, eC, eCL, exC, eyC, C, L, T, okL, okT, rEps, emin, vmax);
+        fin = select_step<false, TR>(e, eC, eCL, rC, cnd, okL, okT, rEps, emin, vmax);
       }
       // (a pixel that is not updated keeps C through its record: kKeepEnergy, see d_make_record)
       } else {
-      { const f4v q0 = rpn[0], q1 = rpn[1], q2 = rpn[2];
-        na = make_float4(q0.x, q0.y, q0.z, q0.w); nb = make_float4(q1.x, q1.y, q1.z, q1.w); nc = make_float4(q2.x, q2.y, q2.z, q2.w); }
+      { const f4v q0 = rpn[0], q1 = rpn[1]; const f2w q2 = *(__attribute__((address_space(3))) const f2w*)(rpn + 2);
+        na = make_float4(q0.x, q0.y, q0.z, q0.w); nb = make_float4(q1.x, q1.y, q1.z, q1.w); nc = make_float2(q2.x, q2.y); }
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
       }
       if (TOP != 0) {
@@ -613,6 +616,12 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   return !dead;
 }
 
+// The current flow's own gradient step (PixFlow.hpp:322-341 with the pixel's own energies), IEEE operations in the reference's order.
+__device__ __forceinline__ float2 own_gradient_step(float2 f, float e0, float ex, float ey) {
+  const float gx = (ex - e0) / kGradEpsilon, gy = (ey - e0) / kGradEpsilon;
+  return make_float2(f.x - kGradientStepSize * gx, f.y - kGradientStepSize * gy);
+}
+
 // One record of the prepass (slot = linear index in wavefront order, see k_sweep_prep): shared by the prepass kernel and by
 // the prepass blocks that ride inside the sweep launch (k_sweep2, MODE 2).
 __device__ __forceinline__ void d_make_record(size_t tid, size_t total, const float2* __restrict__ g0, const float2* __restrict__ g1,
@@ -624,25 +633,26 @@ __device__ __forceinline__ void d_make_record(size_t tid, size_t total, const fl
   const int s = int((tid / kRows) % nstepsPad);
   const int band = int(tid / (size_t(kRows) * nstepsPad));
   const int ia = uLo + s - r, ib = (bandLo + band) * kRows + r;
-  // A pixel that is not updated (gate <= 0) carries E(C) = E(C+dx) = E(C+dy) = kKeepEnergy: every proposal's energy is >= 0
-  // (or NaN), so the selection keeps C, and the gradient step is C - 0.5 * ((E - E) / eps) = C bit for bit -- the sweep's
-  // step needs no "if not gated keep C" of its own (two v_cndmask per step).
-  a = make_float4(0.f, 0.f, 0.f, 0.f); b = make_float4(0.f, 0.f, kKeepEnergy, kKeepEnergy); c = make_float4(kKeepEnergy, kKeepEnergy, 0.f, 0.f);
+  // A pixel that is not updated (gate <= 0) carries E(C) = kKeepEnergy and rC = C: every proposal's energy is >= 0 (or NaN), so
+  // the selection keeps rC = C -- the sweep's step needs no "if not gated keep C" of its own (two v_cndmask per step).
+  a = make_float4(0.f, 0.f, 0.f, 0.f); b = make_float4(kKeepEnergy, 0.f, 0.f, kKeepEnergy); c = a;
   if (tid < total && s - r >= 0 && ia < uHi && ia < LS && ib < LB) {
     const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;   // position in sweep order
     const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
     const size_t idx = size_t(y) * W + x;
     const float2 f = flow[idx];
-    b.x = f.x; b.y = f.y;
-    c.z = float(x); c.w = float(y);   // the pixel's image coordinates (exact small integers)
+    b.y = f.x; b.z = f.y;             // rC = C unless the pixel is updated (below)
+    c.x = float(x); c.y = float(y);   // the pixel's image coordinates (exact small integers)
     if (gate[idx]) {
       const float2 g = g0[idx], bl = blurred[idx];
       const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
       a = make_float4(g.x, g.y, bl.x, bl.y);
-      b.z = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x, f.y);
-      b.w = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x + kGradEpsilon, f.y + 0.0f);
-      c.x = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
-      c.y = (ia > 0) ? b.z : kKeepEnergy;   // E(C) as the proposal from the previous pixel ALONG the step axis sees it: unbeatable at the first pixel of a row (there is none)
+      const float e0 = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x, f.y);
+      const float e1 = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x + kGradEpsilon, f.y + 0.0f);
+      const float e2 = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
+      const float2 rc0 = own_gradient_step(f, e0, e1, e2);
+      b.x = e0; b.y = rc0.x; b.z = rc0.y;
+      b.w = (ia > 0) ? e0 : kKeepEnergy;   // E(C) as the proposal from the previous pixel ALONG the step axis sees it: unbeatable at the first pixel of a row (there is none)
     }
   }
 }
@@ -650,11 +660,13 @@ __device__ __forceinline__ void d_make_record(size_t tid, size_t total, const fl
 // ------------------------------------------------------------------------------------------------
 // prepass: records in wavefront order.  rec[((band*nstepsPad + s)*8 + r)*3 + j] for the ACTIVE window of the sweep:
 // band counts from bandLo, step s handles sweep-order column uLo + s - r (columns [uLo, uHi)).
-//   j=0: (I0x, I0y, blurred.x, blurred.y)   j=1: (C.x, C.y, E(C), E(C+dx))   j=2: (E(C+dy), Ea, x, y)
+//   j=0: (I0x, I0y, blurred.x, blurred.y)   j=1: (E(C), rC.x, rC.y, Ea)   j=2: (x, y, -, -)     (the step reads 16 + 16 + 8 bytes)
+//   rC = C after its own gradient step, C - 0.5 * ((E(C+dx), E(C+dy)) - E(C)) / eps (IEEE operations: what the sweep's exact fast
+//   forms reproduce bit for bit for the two proposals) -- the result of the pixel if neither proposal beats E(C);
 //   (x, y) = the pixel's image coordinates as floats; Ea = E(C), or kKeepEnergy at the first pixel of a row in sweep order
 //   (what the proposal of the previous pixel along the axis is compared with: no such pixel there, no mask needed).
-//   A pixel that is not updated (alpha <= 0.9: keep C) and a (step,row) slot without a pixel carry kKeepEnergy in all four
-//   energies; "updated" is E(C) >= 0.
+//   A pixel that is not updated (alpha <= 0.9: keep C) and a (step,row) slot without a pixel carry kKeepEnergy in both
+//   energies and rC = C; "updated" is E(C) >= 0.
 // When the window does not start at the first band, the row above it never changes during this sweep: its flow
 // is written as the granule row the first workgroup's poller reads (top0).
 // ------------------------------------------------------------------------------------------------
@@ -896,8 +908,10 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
             const float e2 = d_error2g(g1, W, wm2, hm2, fW, rW, qx[c], qy[c], g.x, g.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
             float4* dst = &sm.rec[w][(rh + c * kChunk) % kRS][0][0] + lane * 3;   // slot (lane >> 3, lane & 7) = linear slot `lane`
             dst[0] = on ? make_float4(g.x, g.y, bl.x, bl.y) : z4;
-            dst[1] = make_float4(qvalid[c] ? f.x : 0.f, qvalid[c] ? f.y : 0.f, on ? e0 : kKeepEnergy, on ? e1 : kKeepEnergy);
-            dst[2] = make_float4(on ? e2 : kKeepEnergy, (on && ia_of[c] > 0) ? e0 : kKeepEnergy, float(qx[c]), float(qy[c]));
+            const float2 fv = make_float2(qvalid[c] ? f.x : 0.f, qvalid[c] ? f.y : 0.f);
+            const float2 rc0 = on ? own_gradient_step(f, e0, e1, e2) : fv;
+            dst[1] = make_float4(on ? e0 : kKeepEnergy, rc0.x, rc0.y, (on && ia_of[c] > 0) ? e0 : kKeepEnergy);
+            dst[2] = make_float4(float(qx[c]), float(qy[c]), 0.f, 0.f);
           }
         }
       }
