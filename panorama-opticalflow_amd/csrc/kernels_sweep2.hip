@@ -2,14 +2,15 @@
 //
 // The sweep is dependency-latency bound (W+H-1 anti-diagonal steps per sweep), so the design minimises
 // the time of ONE step instead of bytes moved:
-//   * 8 lanes per pixel.  Everything about a pixel that does not depend on its neighbours -- E(C),
-//     E(C+dx), E(C+dy) for its own incoming flow C -- is computed by a fully parallel prepass
+//   * 8 lanes per pixel.  Everything about a pixel that does not depend on its neighbours -- E(C) and
+//     the gradient step its own incoming flow C would take, rC -- is computed by a fully parallel prepass
 //     (k_sweep_prep) which also packs the static per-pixel inputs into 48-byte records laid out in the
 //     order the wavefront consumes them.  In the sequential kernel six lanes evaluate
 //     E(L), E(L+dx), E(L+dy), E(T), E(T+dx), E(T+dy) for the two proposals (L = previous column,
-//     T = previous row) AT THE SAME TIME: one gather round per step instead of five dependent ones.
-//     Selection follows the reference order (current, then L, then T, strict '<'), the finite-difference
-//     gradient of the winner is already there.  Same arithmetic, same order => bit-identical.
+//     T = previous row) AT THE SAME TIME: one gather round per step instead of five dependent ones --
+//     and each proposal takes its own gradient step in its own lane (the same instructions for all lanes)
+//     before the selection, which follows the reference order (current, then L, then T, strict '<') and
+//     only picks one of three finished results.  Same arithmetic, same order => bit-identical.
 //   * one compute wave = a band of 8 rows (lane = 8*row + role).  Four compute waves (one per SIMD)
 //     + seven helper waves (four loaders, publisher, poller, drainer) form a workgroup = 32 rows.  Rows inside a
 //     wave hand their result to the next row by DPP moves; waves inside a workgroup through the LDS result
@@ -20,9 +21,11 @@
 //     waves stream records and window texels HBM->LDS ahead of the wavefront, drain results LDS->HBM,
 //     publish the granules and poll the previous workgroup's granules, so the long-latency traffic sits in
 //     THEIR in-order memory queues, not in the compute waves'.
-//   * a lone wave issues one instruction every ~6 cycles here, so the step time is the instruction count:
-//     ~170 instructions per step (packed fp32 math, one range guard per step, no per-step address
-//     arithmetic that a loop-carried register or an immediate can replace, no LDS-order stalls).
+//   * a lone wave issues one instruction every ~5.5 cycles here, so the step time is the instruction count
+//     (and, among equals, the length of the loop-carried chain): ~118 instructions per step (packed fp32
+//     math, exact cheap forms of sqrt and division -- exact_forms.hpp --, one range guard per step, no
+//     per-step address arithmetic that a loop-carried register or an immediate can replace, no LDS-order
+//     stalls).  DESIGN.md 3.4 has the history (154 -> 118) and profiles/r03_sweep_step_isa.txt the listing.
 // Workgroups take their band index from an atomic ticket (a band only waits for bands already
 // running), every spin is bounded and raises ctrl[1] instead of hanging.
 #include <hip/hip_ext.h>
@@ -304,12 +307,6 @@ template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
 __device__ __forceinline__ float dpp(float old, float src) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, BANK_MASK, false));
 }
-// value of lane (8*g) broadcast to the 8 lanes of group g
-__device__ __forceinline__ float bcast8(float v) {
-  const float q = dpp<0x00>(v, v);          // quad_perm [0,0,0,0]: lanes 0-3 <- lane 0, lanes 4-7 <- lane 4
-  return dpp<0x114, 0xF, 0xA>(q, q);        // row_shr:4 into banks 1,3 (lanes 4-7, 12-15): <- lanes 0-3, 8-11
-}
-
 struct Smem {
   float4 rec[kWaves][kRS][kRows][3];
   float2 out[kWaves][kOS][kRows];
