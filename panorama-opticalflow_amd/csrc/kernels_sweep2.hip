@@ -566,8 +566,14 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
 #endif
       const f2p fdv = f2p{cand.x, cand.y} + f2p{addx, addy};
       float e = d_error_fast<TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, posv, ra.x, ra.y, ra.z, ra.w, fdv, emin, vmax);
-      { const f4v q0 = rpn[0], q1 = rpn[1]; const f2w q2 = *(__attribute__((address_space(3))) const f2w*)(rpn + 2);
-        na = make_float4(q0.x, q0.y, q0.z, q0.w); nb = make_float4(q1.x, q1.y, q1.z, q1.w); nc = make_float2(q2.x, q2.y); }
+      { // Only what the step uses is loaded: a loaded register nothing reads is handed out again by the register allocator at once,
+        // and the hardware must then wait for the load in flight before the new value may be written (s_waitcnt right behind the
+        // loads, ~50 cycles per step).  Transposed sweeps do not use Ea, the fourth float of the second quad.
+        typedef float f3v __attribute__((ext_vector_type(3)));
+        const f4v q0 = rpn[0]; const f2w q2 = *(__attribute__((address_space(3))) const f2w*)(rpn + 2);
+        na = make_float4(q0.x, q0.y, q0.z, q0.w); nc = make_float2(q2.x, q2.y);
+        if (transposed) { const f3v q1 = *(__attribute__((address_space(3))) const f3v*)(rpn + 1); nb = make_float4(q1.x, q1.y, q1.z, 0.f); }
+        else { const f4v q1 = rpn[1]; nb = make_float4(q1.x, q1.y, q1.z, q1.w); } }
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
       fin = select_step<true, TR>(e, eC, eCL, rC, cnd, okL, okT, rEps, emin, vmax);
       asm volatile("" : "+v"(fin.x), "+v"(fin.y));   // finish the fast result before the branch: the range test then runs beside the division, not before it
@@ -583,8 +589,14 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       }
       // (a pixel that is not updated keeps C through its record: kKeepEnergy, see d_make_record)
       } else {
-      { const f4v q0 = rpn[0], q1 = rpn[1]; const f2w q2 = *(__attribute__((address_space(3))) const f2w*)(rpn + 2);
-        na = make_float4(q0.x, q0.y, q0.z, q0.w); nb = make_float4(q1.x, q1.y, q1.z, q1.w); nc = make_float2(q2.x, q2.y); }
+      { // Only what the step uses is loaded: a loaded register nothing reads is handed out again by the register allocator at once,
+        // and the hardware must then wait for the load in flight before the new value may be written (s_waitcnt right behind the
+        // loads, ~50 cycles per step).  Transposed sweeps do not use Ea, the fourth float of the second quad.
+        typedef float f3v __attribute__((ext_vector_type(3)));
+        const f4v q0 = rpn[0]; const f2w q2 = *(__attribute__((address_space(3))) const f2w*)(rpn + 2);
+        na = make_float4(q0.x, q0.y, q0.z, q0.w); nc = make_float2(q2.x, q2.y);
+        if (transposed) { const f3v q1 = *(__attribute__((address_space(3))) const f3v*)(rpn + 1); nb = make_float4(q1.x, q1.y, q1.z, 0.f); }
+        else { const f4v q1 = rpn[1]; nb = make_float4(q1.x, q1.y, q1.z, q1.w); } }
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
       }
       if (TOP != 0) {
