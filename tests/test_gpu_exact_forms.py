@@ -24,3 +24,19 @@ def test_exact_forms_exhaustive():
     assert int(sq.split("tested")[1].split()[0]) > 1_600_000_000   # 196 binades x 2^23 mantissas + zero
     dv = [ln for ln in lines if ln.startswith("div by kGradEpsilon")][0]
     assert int(dv.split("tested")[1].split()[0]) > 3_200_000_000   # both signs
+
+
+PROBE = os.path.join(HERE, "..", "panorama-opticalflow_amd", "tools", "pk_hazard_probe")
+
+
+@pytest.mark.gpu
+def test_packed_fp32_chains_need_no_wait_states():
+    """csrc/exact_forms.hpp issues dependent v_pk_*_f32 instructions back to back (inside asm blocks), without the s_nop the compiler
+    puts between them (its dst_sel hazard test misreads op_sel_hi of VOP3P as DST_OP_SEL).  The probe runs the same dependent chains with
+    and without wait states -- one wave alone up to 16 waves per SIMD -- and must get identical bits."""
+    assert os.path.exists(PROBE), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    r = subprocess.run([PROBE], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical with and without s_nop" in r.stdout
+    assert "differing results 0" in r.stdout
