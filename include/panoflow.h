@@ -54,7 +54,7 @@ typedef struct pf_config {
   int struct_size;
   int device, max_cols, max_rows;   /* as pf_create */
   int stagger_levels;       /* direction R->L starts this many coarse levels behind L->R (-1: 2, or 4 for >= 5 Mpix half-res) */
-  long fuse_small_level_px; /* levels up to this many pixels fold the upsample / second median into the neighbouring Gaussian
+  int64_t fuse_small_level_px; /* levels up to this many pixels fold the upsample / second median into the neighbouring Gaussian
                                launches (-1: 0 for a lone pair, 262144 for the lanes of the throughput mode) */
   int fine_gradient_blocks; /* width of the launch that computes the gradients of the 4 finest levels beside the coarse sweeps (64) */
   int pyramid_chaining;     /* 1: small pyramid levels are built two or three per launch, 0: one launch per level (1) */
@@ -62,6 +62,14 @@ typedef struct pf_config {
   int sparse_sweep;         /* -1: pick the sweep variant that skips ungated anti-diagonals from the gate density, 0 / 1: force (-1) */
   int batch_pairs;          /* throughput mode (pf_novel_view_batch_dev): pairs that go through ONE set of launches (1..8; in_flight =
                                lanes x batch_pairs).  -1: in_flight itself up to 8 (one lane), half of it (two lanes) beyond */
+  int sweep_wide;           /* workgroup shape of the sweep launches: 0 = latency form (4 bands of 8 rows per workgroup, ONE compute wave per SIMD:
+                               the shortest step, what a lone pair wants), 1 = wide form (8 bands, two compute waves per SIMD: ~2x the steps per CU
+                               and second, what a batch that oversubscribes the chip wants), -1 = wide for the launches of a batch that ask for
+                               more latency-form workgroups than sweep_wide_threshold (-1).  Same bits either way. */
+  int sweep_wide_threshold; /* sweep_wide = -1: workgroups (pairs x 2 directions x workgroups per sweep) above which a launch goes wide (768 = three
+                               rounds of the chip: measured +2 % on 8 dense 9000x4000 pairs, -3.5 % on 2000x4000 strips at 560) */
+  int full_width_batch_gradients; /* 1: in a batched solve the finest levels' gradients are one full-width launch (nothing to hide them
+                               behind: the batch keeps every CU busy anyway), 0: the narrow launch of a lone pair (1) */
   /* Cross-check implementations -- only in libpanoflow_exp.so (the -DPF_EXPERIMENTS build used by the test-suite);
    * libpanoflow.so rejects anything but the defaults with PF_ERR_ARG. */
   int sweep_impl;           /* 2: wavefront sweep (k_sweep_prep + k_sweep2); 1: the independent 64-rows-per-wave kernel; 3: LDS-tile relaxation */

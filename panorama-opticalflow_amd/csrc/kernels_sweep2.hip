@@ -39,16 +39,37 @@ namespace pf {
 
 namespace {
 constexpr int kRows = 8;     // rows per compute wave
-constexpr int kWaves = 4;    // compute waves per workgroup, one per SIMD (two per SIMD measured slower)
-constexpr int kRS = 32;      // record ring (steps): the loader runs up to three chunks ahead
-constexpr int kLoadAhead = 3; // chunks per wave the loader fetches in one round when the ring has room
-constexpr int kOS = 32;      // result ring (steps)
 constexpr int kBS = 256;     // boundary ring (columns)
 constexpr float kKeepEnergy = -1.0f;   // below every real energy: E(C), E(C+dx), E(C+dy) of a pixel the sweep must not change
 constexpr int kChunk = 8;    // steps streamed per helper iteration and wave
 constexpr int kRad = 8;      // LDS window of the gathered plane: +-kRad texels around the band
-constexpr int kWA = kRows + 2 * kRad + 1;   // window extent across the band (25)
 constexpr int kWC = 64;      // window ring along the step axis (columns)
+// Two workgroup shapes of the SAME step (compute_band is one function; every test holds both to the same bits):
+//  * SwLatency -- ONE pair: 4 compute waves (one per SIMD: alone on its SIMD a wave is offered an issue slot every ~5.5 cycles,
+//    and the step's dependency chain cannot use a second wave) + 4 loaders + publisher + poller + drainer = 704 threads, 113 KB of
+//    LDS: one workgroup owns a CU.  Everything is sized for the latency of one band chain (32-step rings, the loader three
+//    chunks ahead, one private gather window per band).
+//  * SwWide -- a BATCH of pairs (throughput mode): more sweep workgroups are asked for than the chip has CUs, so what counts is
+//    steps per CU and second, and a SIMD whose lone compute wave leaves ~3/5 of its issue slots empty is the waste.  8 compute
+//    waves (two per SIMD, 64 rows per workgroup) share the same seven helper roles: 960 threads, 4 waves per SIMD (128 VGPRs),
+//    126 KB of LDS -- two adjacent bands share one 33-row gather window and one loader, rings are 16 steps.
+template <int NW, int BPW>
+struct SwGeom {
+  static constexpr int kWaves = NW;              // compute waves (bands) per workgroup
+  static constexpr int kBPW = BPW;               // adjacent bands that share one gather window and one loader wave
+  static constexpr int kLoaders = NW / BPW;
+  static constexpr int kRS = BPW == 1 ? 32 : 24; // record ring (steps)
+  static constexpr int kRQ = BPW == 1 ? 3 : 2;   // float4 quads per record in the LDS ring: the 48-byte record as it is in memory, or -- wide form, where
+                                                 // LDS is what limits the rings -- its first two quads, the (x, y) of the third in a ring of its own (40 bytes)
+  static constexpr int kLoadAhead = BPW == 1 ? 3 : 1;   // chunks per band the loader fetches in one round when the ring has room
+  static constexpr int kOS = 32;                 // result ring (steps)
+  static constexpr int kWA = BPW * kRows + 2 * kRad + 1;   // window extent across the band(s): 25 / 33
+  static constexpr int kWavesTotal = NW + kLoaders + 3;    // + publisher, poller, drainer
+  static constexpr int kThreads = 64 * kWavesTotal;
+  static constexpr int kScratch = BPW == 1 ? NW : 1;       // scratch areas for the non-publishing lanes (write-only: may be shared)
+};
+using SwLatency = SwGeom<4, 1>;
+using SwWide = SwGeom<8, 2>;
 constexpr int kWCp = kWC + 1; // row stride of the window: ring column 0 is stored a second time behind column 63, so that the
                               // right-hand texel of a bilinear footprint is always the NEXT slot (no second ring wrap on the address chain)
 // Every wait is bounded by WALL-CLOCK time, not by a spin count: the deadline (kernel entry + a budget the host scales with
@@ -164,7 +185,7 @@ __device__ __forceinline__ float dpp_shl0(float src) {
 // within +-(kRad-1) texels of the pixel, otherwise from HBM.  Scheduled in three phases: (A) addresses + issue of
 // the texel reads, (B) every term that does not need the texels (smoothness, the two regularisers) in the shadow
 // of their latency, (C) bilinear + data term.  sched_barrier keeps the compiler from sinking B below the wait.
-template <bool TR, bool FWD>
+template <bool TR, bool FWD, int kWA>
 __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __attribute__((address_space(3))) const float2* win, int ob, int W, int H, float wm2, float hm2,
                                               float fW, float rW, f2p pos, float i0x, float i0y, float bx, float by, f2p fd,
                                               int& emin, float& vmax) {
@@ -307,15 +328,17 @@ template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
 __device__ __forceinline__ float dpp(float old, float src) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, BANK_MASK, false));
 }
-struct Smem {
-  float4 rec[kWaves][kRS][kRows][3];
-  float2 out[kWaves][kOS][kRows];
-  float2 win[kWaves][kWA][kWCp];          // (I1x,I1y) texels around each band, sweep-order coordinates, ring along the step axis (+ column 0 again)
-  float2 scratch[kWaves][128];            // where lanes 1-7 of a group "store" in the publishing step (lane + 8 * step-in-chunk)
+template <class G>
+struct SmemT {
+  float4 rec[G::kWaves][G::kRS][kRows][G::kRQ];
+  float2 recxy[G::kRQ == 3 ? 1 : G::kWaves][G::kRQ == 3 ? 1 : G::kRS][kRows];   // wide form: the records' (x, y)
+  float2 out[G::kWaves][G::kOS][kRows];
+  float2 win[G::kLoaders][G::kWA][kWCp];  // (I1x,I1y) texels around each band (pair of bands), sweep-order coordinates, ring along the step axis (+ column 0 again)
+  float2 scratch[G::kScratch][128];       // where lanes 1-7 of a group "store" in the publishing step (lane + 8 * step-in-chunk)
   unsigned long long bnd[kBS];            // granules of the previous workgroup's last row (poller -> wave 0), valid below bndHead
-  int recHead[kWaves];   // steps of records available to wave w        (stream helper -> compute)
-  int outHead[kWaves];   // steps completed by wave w                    (compute -> helpers, next wave)
-  int outTail[kWaves];   // steps of wave w written to the flow plane    (stream helper -> compute)
+  int recHead[G::kWaves];   // steps of records available to wave w        (stream helper -> compute)
+  int outHead[G::kWaves];   // steps completed by wave w                    (compute -> helpers, next wave)
+  int outTail[G::kWaves];   // steps of wave w written to the flow plane    (stream helper -> compute)
   int pubTail;           // steps of the last wave published as granules (granule helper -> compute)
   int bndHead;           // boundary columns available to wave 0        (granule helper -> compute)
   int abort;
@@ -325,7 +348,8 @@ struct Smem {
   long long statEntry;
 };
 
-__device__ __forceinline__ bool spin_expired(int& spins, const Smem& sm) {
+template <class SM>
+__device__ __forceinline__ bool spin_expired(int& spins, const SM& sm) {
   if ((++spins & 1023) != 0) return false;
   return (long long)wall_clock64() > *(const volatile long long*)&sm.deadline;
 }
@@ -350,9 +374,10 @@ __device__ __forceinline__ void st_cnt(int* p, int v) {
 // Hand-off protocol: the producer writes its result, then its step counter; the consumer reads the counter,
 // then the value (one wave's LDS operations execute in issue order), one step ahead of use.  The counter is
 // wave-uniform, so the per-step "is my top neighbour there" test is two scalar instructions.
-template <int TOP, bool TR, bool FWD, bool SPARSE>
-__device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict__ g1, int W, int H, int nsteps, int w, int band,
+template <class G, int TOP, bool TR, bool FWD, bool SPARSE>
+__device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restrict__ g1, int W, int H, int nsteps, int w, int band,
                                              int nact, bool publishes, float rW, float rEps, int uLo, int LSv) {
+  constexpr int kWaves = G::kWaves, kRS = G::kRS, kOS = G::kOS, kWA = G::kWA;
   constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0;
   const int lane = threadIdx.x & 63;
   const int r = lane >> 3, k = lane & 7;
@@ -364,9 +389,9 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
   // The band's window as an LDS address the compiler cannot take apart (an SGPR): with the struct offset visible it splits the
   // four texel reads over two address registers instead of one address + immediate offsets.
   typedef __attribute__((address_space(3))) const float2 lds_cf2;
-  lds_cf2* win = (lds_cf2*)&sm.win[w][0][0];
+  lds_cf2* win = (lds_cf2*)&sm.win[w / G::kBPW][0][0];   // (wide form: the window this band shares with its neighbour)
   asm volatile("" : "+s"(win));
-  int ob = band * kRows - kRad;               // window origin across the bands
+  int ob = (band - w % G::kBPW) * kRows - kRad;   // window origin across the bands (the workgroup's first band is a multiple of kBPW)
   asm volatile("" : "+s"(ob));                // opaque: otherwise the compiler splits it into (v - band*8) + 8, one more instruction on the address chain
   const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
   // Lane roles inside a pixel's group of 8: lanes 0-2 evaluate the proposal of the previous pixel ALONG the step axis (this
@@ -447,7 +472,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
         // The last step of the previous chunk read this chunk's first record ahead; that read was only good if the
         // record was already there, which the one-chunk-old counter just confirmed unless we had to wait.
         const float4* rp0 = &sm.rec[w][s0 % kRS][r][0];
-        ra = rp0[0]; rb = rp0[1]; rc = *reinterpret_cast<const float2*>(rp0 + 2);
+        ra = rp0[0]; rb = rp0[1]; rc = (G::kRQ == 3) ? *reinterpret_cast<const float2*>(rp0 + 2) : sm.recxy[G::kRQ == 3 ? 0 : w][G::kRQ == 3 ? 0 : s0 % kRS][r];
         asm volatile("" : "+v"(ra.x), "+v"(ra.y), "+v"(ra.z), "+v"(ra.w), "+v"(rb.x), "+v"(rb.y), "+v"(rb.z), "+v"(rb.w), "+v"(rc.x), "+v"(rc.y));
       }
     }
@@ -471,9 +496,13 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
     typedef __attribute__((address_space(3))) const f4v lds_f4;
     typedef __attribute__((address_space(3))) f2w lds_wf2;
     typedef __attribute__((address_space(3))) const unsigned long long lds_u64;
-    lds_f4* recChunk = (lds_f4*)&sm.rec[w][s0 % kRS][r][0];                 // record of step s0 + j: recChunk + j * kRows * 3
+    lds_f4* recChunk = (lds_f4*)&sm.rec[w][s0 % kRS][r][0];                 // record of step s0 + j: recChunk + j * kRows * kRQ
     lds_f4* recNext = (lds_f4*)&sm.rec[w][(s0 + kChunk) % kRS][r][0];       // first record of the next chunk
-    lds_wf2* outChunk = (lds_wf2*)((k == 0) ? &sm.out[w][s0 % kOS][r] : &sm.scratch[w][lane]);   // result slot of step s0 + j: outChunk + j * kRows (lanes 1-7 of a group hold no result: scratch)
+    typedef __attribute__((address_space(3))) const f2w lds_cf2w;
+    lds_cf2w* xyChunk = (lds_cf2w*)&sm.recxy[G::kRQ == 3 ? 0 : w][G::kRQ == 3 ? 0 : s0 % kRS][r];              // wide form: (x, y) of step s0 + j: xyChunk + j * kRows
+    lds_cf2w* xyNext = (lds_cf2w*)&sm.recxy[G::kRQ == 3 ? 0 : w][G::kRQ == 3 ? 0 : (s0 + kChunk) % kRS][r];
+    if (G::kRQ != 3) asm volatile("" : "+v"(xyChunk), "+v"(xyNext));
+    lds_wf2* outChunk = (lds_wf2*)((k == 0) ? &sm.out[w][s0 % kOS][r] : &sm.scratch[G::kScratch == 1 ? 0 : w][lane]);   // result slot of step s0 + j: outChunk + j * kRows (lanes 1-7 of a group hold no result: scratch)
     lds_u64* topChunk = (lds_u64*)((TOP == 1) ? top_slot(s0 + 1) : &sm.bnd[s0 & (kBS - 1)] + 1);   // top value of column s0 + j + 1
     lds_u64* topNext = (lds_u64*)top_slot(s0 + kChunk);                     // ... of the next chunk's first column
     asm volatile("" : "+v"(recChunk), "+v"(recNext), "+v"(outChunk));
@@ -547,7 +576,8 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       int hN = 0; unsigned long long tvN = tv;
       // next step's inputs (LDS): records (unconditional: past the chunk it reads a slot that is reloaded at the chunk
       // start anyway), producer counter, then the top value.  Issued behind the gather inside the evaluation below.
-      lds_f4* rpn = (j + 1 < kChunk) ? recChunk + (j + 1) * (kRows * 3) : recNext;
+      lds_f4* rpn = (j + 1 < kChunk) ? recChunk + (j + 1) * (kRows * G::kRQ) : recNext;
+      lds_cf2w* xyn = (G::kRQ == 3) ? (lds_cf2w*)(rpn + 2) : ((j + 1 < kChunk) ? xyChunk + (j + 1) * kRows : xyNext);
       lds_u64* tpn = (j + 1 < kChunk) ? topChunk + j * ((TOP == 1) ? kRows : 1) : topNext;
       // Sparse overlap (full-canvas inputs, CPU/StitchTool.cpp:17-33): when no pixel of this anti-diagonal is gated
       // the whole step is bookkeeping only (wave-uniform branch; an ungated pixel keeps its flow, PixFlow.hpp:317).
@@ -565,12 +595,12 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
       if (__any(!(__builtin_fmaxf(fabsf(cand.x + addx), fabsf(cand.y + addy)) <= float(kRad - 1)))) ++statOOW;
 #endif
       const f2p fdv = f2p{cand.x, cand.y} + f2p{addx, addy};
-      float e = d_error_fast<TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, posv, ra.x, ra.y, ra.z, ra.w, fdv, emin, vmax);
+      float e = d_error_fast<TR, FWD, kWA>(g1, win, ob, W, H, wm2, hm2, fW, rW, posv, ra.x, ra.y, ra.z, ra.w, fdv, emin, vmax);
       { // Only what the step uses is loaded: a loaded register nothing reads is handed out again by the register allocator at once,
         // and the hardware must then wait for the load in flight before the new value may be written (s_waitcnt right behind the
         // loads, ~50 cycles per step).  Transposed sweeps do not use Ea, the fourth float of the second quad.
         typedef float f3v __attribute__((ext_vector_type(3)));
-        const f4v q0 = rpn[0]; const f2w q2 = *(__attribute__((address_space(3))) const f2w*)(rpn + 2);
+        const f4v q0 = rpn[0]; const f2w q2 = *xyn;
         na = make_float4(q0.x, q0.y, q0.z, q0.w); nc = make_float2(q2.x, q2.y);
         if (transposed) { const f3v q1 = *(__attribute__((address_space(3))) const f3v*)(rpn + 1); nb = make_float4(q1.x, q1.y, q1.z, 0.f); }
         else { const f4v q1 = rpn[1]; nb = make_float4(q1.x, q1.y, q1.z, q1.w); } }
@@ -593,7 +623,7 @@ __device__ __forceinline__ bool compute_band(Smem& sm, const float2* __restrict_
         // and the hardware must then wait for the load in flight before the new value may be written (s_waitcnt right behind the
         // loads, ~50 cycles per step).  Transposed sweeps do not use Ea, the fourth float of the second quad.
         typedef float f3v __attribute__((ext_vector_type(3)));
-        const f4v q0 = rpn[0]; const f2w q2 = *(__attribute__((address_space(3))) const f2w*)(rpn + 2);
+        const f4v q0 = rpn[0]; const f2w q2 = *xyn;
         na = make_float4(q0.x, q0.y, q0.z, q0.w); nc = make_float2(q2.x, q2.y);
         if (transposed) { const f3v q1 = *(__attribute__((address_space(3))) const f3v*)(rpn + 1); nb = make_float4(q1.x, q1.y, q1.z, 0.f); }
         else { const f4v q1 = rpn[1]; nb = make_float4(q1.x, q1.y, q1.z, q1.w); } }
@@ -711,18 +741,151 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
   }
 }
 
+
 // ------------------------------------------------------------------------------------------------
-// 704 threads: waves 0-3 compute (one band of 8 rows each), waves 4-7 load records and window texels (one per
+// Loader wave of the WIDE form (SwWide): serves the PAIR of adjacent bands A = 2l, B = 2l + 1 of its workgroup -- their record
+// streams (one ring each) and the ONE gather window they share (33 = 8 + 8 + 2 * 8 + 1 texel rows, the same 64-column ring
+// along the step axis).  Window batch b = the 8 texel columns [8b-16, 8b-8) (relative to uLo) x 33 rows; a band working on
+// chunk j (steps 8j .. 8j+7) reads batches j .. j+4.  The window follows the LEADING band A: batch j + 4 is loaded together
+// with A's chunk j (batches 0..3 in the first round), which overwrites batch j - 4.  Hence two rules beyond the rings' room:
+//   * A's chunk j is loaded only when B has finished every step of its chunks <= j - 4 (B still reads batch j - 4 otherwise),
+//     i.e. outHead[B] >= 8j - 24.  B runs 8-9 steps behind A by construction and A's records are at most 16 steps ahead of A,
+//     so in steady state outHead[B] ~ 8j - 17: the rule never binds unless B is held up.
+//   * B's chunk j is published only after A's chunk j (its batches <= j + 4 are then in the window).
+// No deadlock: A blocked by the first rule holds records up to step 8j - 1, B needs A's results up to its own step + 8 only.
+// One chunk per band and round (16-step rings: two chunks): a round is one HBM round trip for both bands.
+// ------------------------------------------------------------------------------------------------
+template <class G, bool TR, bool FWD>
+__device__ __forceinline__ void sweep_loader_pair(SmemT<G>& sm, const float4* __restrict__ rec, const float2* __restrict__ g1, int* __restrict__ ctrl, int W, int H,
+                                                  int nsteps, int nstepsPad, int l, int nact, int band0, int bandLo, int uLo, int LSv) {
+  static_assert(G::kBPW == 2, "pair loader");
+  constexpr int kRS = G::kRS, kWA = G::kWA;
+  constexpr int kKT = (8 * kWA + 63) / 64;   // window texels per lane and batch (5)
+  const int lane = threadIdx.x & 63;
+  const int wA = 2 * l, wB = 2 * l + 1;
+  if (wA >= nact) return;
+  const bool hasB = wB < nact;
+  const int LS = TR ? H : W, LB = TR ? W : H;
+  int tc[kKT], ta[kKT]; bool tvalid[kKT];
+#pragma unroll
+  for (int k = 0; k < kKT; ++k) {
+    const int t = lane + 64 * k;
+    tc[k] = TR ? t / kWA : (t & 7); ta[k] = TR ? t % kWA : (t >> 3); tvalid[k] = t < 8 * kWA;
+  }
+  float2* winw = &sm.win[l][0][0];
+  const int v0 = (bandLo + band0 + wA) * kRows - kRad;   // window origin across the bands
+  auto win_addr = [&](int b, int k, int& slot) -> const float2* {   // texel k of this lane in batch b
+    const int u = uLo + 8 * b - 16 + tc[k], v = v0 + ta[k];   // absolute sweep-order texel
+    slot = ta[k] * kWCp + (u & (kWC - 1));
+    if (!tvalid[k] || u < 0 || u >= LS || v < 0 || v >= LB) return nullptr;
+    const int cxc = TR ? v : u, cyc = TR ? u : v;
+    const int x = FWD ? cxc : W - 1 - cxc, y = FWD ? cyc : H - 1 - cyc;
+    return g1 + (y * W + x);
+  };
+  auto win_store = [&](int slot, float2 v) {   // ring column 0 also goes to the slot behind column 63 (kWCp)
+    winw[slot] = v;
+    if (slot % kWCp == 0) winw[slot + kWC] = v;
+  };
+  const float4* recA = rec + size_t(band0 + wA) * nstepsPad * (kRows * 3);
+  const float4* recB = recA + size_t(nstepsPad) * (kRows * 3);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // a chunk's records arrive as 192 float4 (64 records x 3 quads, lane i holds quads i, i + 64, i + 128); in the LDS ring quads 0 and 1
+  // of record n go to rec[..][n][q], the first half of quad 2 to recxy[..][n]
+  int dn[3], dq[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { const int i = lane + 64 * k; dn[k] = i / 3; dq[k] = i % 3; }
+  auto rec_store = [&](int wv_, int ring, const float4& q0_, const float4& q1_, const float4& q2_) {
+    float4* d4 = &sm.rec[wv_][ring][0][0];
+    float2* d2 = &sm.recxy[wv_][ring][0];
+    const float4 v[3] = {q0_, q1_, q2_};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (dq[k] < 2) d4[dn[k] * 2 + dq[k]] = v[k];
+      else d2[dn[k]] = make_float2(v[k].x, v[k].y);
+    }
+  };
+  int rhA = 0, rhB = 0, idle = 0;
+  bool first = true;
+  for (;;) {
+    const int ohA = first ? 0 : ld_cnt(&sm.outHead[wA]);
+    const int ohB = (first || !hasB) ? 0 : ld_cnt(&sm.outHead[wB]);
+    const bool ldA = rhA < nsteps && (rhA + kChunk - ohA <= kRS) && (!hasB || ohB >= rhA - 24);
+    const int rhA2 = rhA + (ldA ? kChunk : 0);
+    const bool ldB = hasB && rhB < nsteps && (rhB + kChunk - ohB <= kRS) && (rhB + kChunk <= rhA2);
+    float4 a0 = z4, a1 = z4, a2 = z4, b0 = z4, b1 = z4, b2 = z4;
+    float2 wv[kKT]; int ws[kKT]; bool wok[kKT];
+#pragma unroll
+    for (int k = 0; k < kKT; ++k) { wv[k] = make_float2(0.f, 0.f); ws[k] = 0; wok[k] = false; }
+    if (ldA) {
+      const float4* src = recA + size_t(rhA) * (kRows * 3);
+      a0 = src[lane]; a1 = src[lane + 64]; a2 = src[lane + 128];
+      const int b = rhA / kChunk + 4;
+#pragma unroll
+      for (int k = 0; k < kKT; ++k) {
+        const float2* q = win_addr(b, k, ws[k]);
+        wok[k] = q != nullptr;
+        if (wok[k]) wv[k] = *q;
+      }
+    }
+    if (ldB) {
+      const float4* src = recB + size_t(rhB) * (kRows * 3);
+      b0 = src[lane]; b1 = src[lane + 64]; b2 = src[lane + 128];
+    }
+    if (first) {   // batches 0..3 (0 and 1 lie before the window: they exist when the window does not start at the image border)
+      float2 pv[4][kKT]; int ps[4][kKT]; bool pk[4][kKT];
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int k = 0; k < kKT; ++k) {
+          pv[b][k] = make_float2(0.f, 0.f);
+          const float2* q = win_addr(b, k, ps[b][k]);
+          pk[b][k] = q != nullptr;
+          if (pk[b][k]) pv[b][k] = *q;
+        }
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int k = 0; k < kKT; ++k) if (pk[b][k]) win_store(ps[b][k], pv[b][k]);
+      first = false;
+    }
+    bool progress = false;
+    if (ldA) {
+      rec_store(wA, rhA % kRS, a0, a1, a2);
+#pragma unroll
+      for (int k = 0; k < kKT; ++k) if (wok[k]) win_store(ws[k], wv[k]);
+      rhA += kChunk;
+      st_cnt(&sm.recHead[wA], rhA);
+      progress = true;
+    }
+    if (ldB) {
+      rec_store(wB, rhB % kRS, b0, b1, b2);
+      rhB += kChunk;
+      st_cnt(&sm.recHead[wB], rhB);
+      progress = true;
+    }
+    if (rhA >= nsteps && (!hasB || rhB >= nsteps)) break;
+    if (progress) idle = 0;
+    else {
+      __builtin_amdgcn_s_sleep(4);
+      if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SwLatency, 704 threads: waves 0-3 compute (one band of 8 rows each), waves 4-7 load records and window texels (one per
 // compute wave), wave 8 publishes the workgroup's last row as granules, wave 9 polls the previous workgroup's
 // granules, wave 10 drains results.  Waves land on SIMD (wave % 4): every compute wave shares its SIMD with its
 // own loader; three waves per SIMD cap the kernel at 168 VGPRs.
+// SwWide, 960 threads: waves 0-7 compute (two per SIMD), waves 8-11 load for a PAIR of adjacent bands each (their records,
+// and the one 33-row window the two share), waves 12 / 13 / 14 publish, poll, drain: four waves per SIMD, 128 VGPRs.
 // ------------------------------------------------------------------------------------------------
 // MODE 0: records come from k_sweep_prep (launched in front).  MODE 1: the loader waves compute them (experiment, slower).
 // MODE 2: the prepass rides INSIDE this launch -- blocks [nwgSweep, gridDim.x) compute the records in wavefront order (sweep
 // workgroup 0's first) and hand them over with the write-through + counter + acquire protocol of cdna_hip_programming.md G16/R1;
 // the first bands start a few microseconds after the launch instead of after a whole prepass kernel.
-template <bool TR, bool FWD, bool SPARSE, int MODE>
-__global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
+template <class G, bool TR, bool FWD, bool SPARSE, int MODE>
+__global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
                                                 unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H,
                                                 int nstepsPad, int nbands, float rW, float rEps, int uLo, int LSv, int bandLo, long long budgetTicks,
                                                 const float2* __restrict__ g0, const float2* __restrict__ blurred, const uint8_t* __restrict__ gate,
@@ -732,6 +895,9 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
     PF_BOFF(rec, bo); PF_BOFF(g1, bo); PF_BOFF(flow, bo); PF_BOFF(boundary, bo); PF_BOFF(ctrl, bo); PF_BOFF(g0, bo); PF_BOFF(blurred, bo); PF_BOFF(gate, bo);
     if (prepcnt != nullptr) PF_BOFF(prepcnt, bo);
   }
+  constexpr int kWaves = G::kWaves, kRS = G::kRS, kOS = G::kOS, kWA = G::kWA, kLoadAhead = G::kLoadAhead, kLoaders = G::kLoaders;
+  static_assert(MODE == 0 || G::kBPW == 1, "the experimental record paths exist in the latency form only");
+  using Smem = SmemT<G>;
   if (MODE == 2 && int(blockIdx.x) >= nwgSweep) {
     // ======================= prepass block (MODE 2): 704 records, written through to memory, then counted in =======================
     const int slotsPerWG = kWaves * nstepsPad * kRows;
@@ -803,9 +969,9 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
     const int top = (wave > 0) ? 1 : ((wg > 0 || staticTop) ? 2 : 0);   // where row 0's top neighbour comes from
     const int band = bandLo + band0 + wave;                               // absolute band index
     bool ok;
-    if (top == 1) ok = compute_band<1, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
-    else if (top == 2) ok = compute_band<2, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
-    else ok = compute_band<0, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
+    if (top == 1) ok = compute_band<G, 1, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
+    else if (top == 2) ok = compute_band<G, 2, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
+    else ok = compute_band<G, 0, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
     if (!ok) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #ifdef PF_SWEEP_STATS
     if (lane == 0) { atomicAdd(&ctrl[2], atomicExch(&sm.statHits, 0)); atomicAdd(&ctrl[3], atomicExch(&sm.statSpins, 0)); }
@@ -816,7 +982,13 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
   // helper waves: below the compute waves (3), above another kernel's waves that share this CU -- since the two directions run
   // out of phase, the other direction's Gaussians / medians / prepass sit on the sweep's SIMDs (strip -0.12 ms, 9000x4000 pair -0.4 ms)
   __builtin_amdgcn_s_setprio(1);
-  if (wave >= kWaves && wave < 2 * kWaves) {
+  if constexpr (G::kBPW == 2) {
+    if (wave >= kWaves && wave < kWaves + kLoaders) {
+      sweep_loader_pair<G, TR, FWD>(sm, rec, g1, ctrl, W, H, nsteps, nstepsPad, wave - kWaves, nact, band0, bandLo, uLo, LSv);
+      return;
+    }
+  }
+  if constexpr (G::kBPW == 1) if (wave >= kWaves && wave < 2 * kWaves) {
     // ======================= loader of compute wave w: records + gather window HBM -> LDS, up to kRS steps ahead =======================
     // Window batch b = the 8 texel columns (along the step axis) [8b-16, 8b-8) x kWA texels across the band.
     // A compute wave working on chunk j (steps 8j..8j+7) reads columns [8j-15, 8j+16], i.e. batches j..j+4,
@@ -966,7 +1138,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
     return;
   }
 
-  if (wave == 2 * kWaves + 2) {
+  if (wave == kWaves + kLoaders + 2) {
     // ======================= drainer: results LDS ring -> flow plane (stores only: never waits on HBM) =======================
     int idle = 0;
     for (;;) {
@@ -1006,7 +1178,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
     return;
   }
 
-  if (wave == 2 * kWaves) {
+  if (wave == kWaves + kLoaders) {
     // ======================= publisher: last row of the workgroup -> granules in HBM (tight loop, never waits on HBM) =======================
     if (!publishes) return;
     unsigned long long* bnd_out = boundary + size_t(wg + 1) * LSv;   // granule row 0 belongs to the static row above the window
@@ -1036,7 +1208,7 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
 
   // ======================= poller: previous workgroup's granules HBM -> LDS ring =======================
   {
-    if ((wg == 0 && !staticTop) || wave != 2 * kWaves + 1) return;
+    if ((wg == 0 && !staticTop) || wave != kWaves + kLoaders + 1) return;
     const unsigned long long* bnd_in = boundary + size_t(wg) * LSv;
     const bool topFromPlane = MODE != 0 && wg == 0;   // (wg == 0 only gets here with a static top row)
     int bh = 0, idle = 0;
@@ -1077,7 +1249,8 @@ __global__ __launch_bounds__(64 * (2 * kWaves + 3)) void k_sweep2(const float4* 
 // ---- host side ----
 // Bands run across the SHORTER side of the active window (fewer band-to-band hand-offs on the critical path):
 // normal = bands of 8 rows stepping along x; transposed = bands of 8 columns stepping along y.
-static inline int wgs_for(int LB) { const int nbands = (LB + kRows - 1) / kRows; return (nbands + kWaves - 1) / kWaves; }
+// (buffers are sized for either workgroup shape: the latency form has the most workgroups, the wide form pads the bands to a multiple of 8)
+static inline int wgs_for(int LB, int waves = SwLatency::kWaves) { const int nbands = (LB + kRows - 1) / kRows; return (nbands + waves - 1) / waves; }
 static inline int steps_pad(int LS) { return ((LS + kRows - 1) + kChunk - 1) / kChunk * kChunk; }
 int sweep2_num_wgs(int H) { return wgs_for(H); }
 int sweep2_num_wgs_max(int W, int H) { const int a = wgs_for(W), b = wgs_for(H); return a > b ? a : b; }
@@ -1095,10 +1268,12 @@ size_t sweep_boundary_elems(int W, int H) {   // hand-off granules a sweep launc
   return v;
 }
 size_t sweep2_rec_bytes(int W, int H) {
-  const size_t a = size_t(wgs_for(H)) * kWaves * steps_pad(W), b = size_t(wgs_for(W)) * kWaves * steps_pad(H);
+  const size_t a = size_t(wgs_for(H, SwWide::kWaves)) * SwWide::kWaves * steps_pad(W), b = size_t(wgs_for(W, SwWide::kWaves)) * SwWide::kWaves * steps_pad(H);
   return (a > b ? a : b) * kRows * 48;
 }
-bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
+template <class G>
+static bool launch_sweep2_form(hipStream_t st, const SweepArgs& a, float* rec) {
+  constexpr int kWaves = G::kWaves;
   // active window: bounding box of the gated pixels (pixels outside it are not updated by this sweep and keep their flow)
   const SweepWindow win = make_sweep_window(a.W, a.H, a.forward, a.ax0, a.ay0, a.ax1, a.ay1, kRows, kWaves, kChunk);
   if (win.empty) return false;   // nothing to update: the sweep is the identity
@@ -1108,12 +1283,12 @@ bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
   const size_t prepThreads = total > size_t(LSv) ? total : size_t(LSv);
   const float rW = (float)(1.0 / (double)(float)a.W), rEps = (float)(1.0 / (double)kGradEpsilon);
   // How the records reach the sweep.  0 (the product): k_sweep_prep in front of the sweep.  Two measured and rejected alternatives
-  // exist in the lab build only (-DPF_EXPERIMENTS, SweepArgs::prep_mode), both bit-identical: 1 = the loader waves compute them (no
-  // record traffic through HBM, but 8 % slower: profiles/r02_fused_prepass_ab.txt); 2 = prepass blocks inside the sweep launch with
-  // a write-through + counter + acquire hand-off (the first bands start microseconds after the launch, yet the launch as a whole
-  // is not shorter: same file).
+  // exist in the lab build only (-DPF_EXPERIMENTS, SweepArgs::prep_mode; latency form only), both bit-identical: 1 = the loader waves
+  // compute them (no record traffic through HBM, but 8 % slower: profiles/r02_fused_prepass_ab.txt); 2 = prepass blocks inside the
+  // sweep launch with a write-through + counter + acquire hand-off (the first bands start microseconds after the launch, yet the
+  // launch as a whole is not shorter: same file).
 #ifdef PF_EXPERIMENTS
-  const int mode = (a.prep_mode == 2 && (a.prepcnt == nullptr || total * 48 >= (size_t(1) << 31))) ? 0 : a.prep_mode;
+  const int mode = (G::kBPW != 1 || (a.prep_mode == 2 && (a.prepcnt == nullptr || total * 48 >= (size_t(1) << 31)))) ? 0 : a.prep_mode;
 #else
   constexpr int mode = 0;
 #endif
@@ -1124,14 +1299,14 @@ bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
   hipEvent_t evs = mode == 0 ? nullptr : a.ev_start;   // without a prepass kernel the sweep launch carries both events
   // wall-clock budget of every wait inside the launch, in 100 MHz ticks: 2 s + 1000 x the expected duration (~0.5 us per step)
   const long long budget = 200000000ll + 1000ll * 50ll * (long long)(nstepsPad + 9 * nbands);
-  const unsigned nthreads = 64 * (2 * kWaves + 3);
+  const unsigned nthreads = G::kThreads;
   const dim3 grid(mode == 2 ? nwg + (unsigned)((total + nthreads - 1) / nthreads) : nwg, 1, a.bt.n), block(nthreads);
   const float4* r4 = mode == 1 ? nullptr : reinterpret_cast<const float4*>(rec);
-#define PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, MDV) hipExtLaunchKernelGGL((k_sweep2<TRV, FWV, SPV, MDV>), grid, block, 0, st, evs, a.ev_stop, 0, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.g0, a.blurred, a.gate, nwg, a.prepcnt, a.bt.stride)
+#define PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, MDV) hipExtLaunchKernelGGL((k_sweep2<G, TRV, FWV, SPV, MDV>), grid, block, 0, st, evs, a.ev_stop, 0, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.g0, a.blurred, a.gate, nwg, a.prepcnt, a.bt.stride)
 #ifdef PF_EXPERIMENTS
-#define PF_LAUNCH_SWEEP2__(TRV, FWV, SPV) do { if (mode == 2) PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 2); else if (mode == 1) PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 1); else PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 0); } while (0)
+#define PF_LAUNCH_SWEEP2__(TRV, FWV, SPV) do { if constexpr (G::kBPW == 1) { if (mode == 2) { PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 2); break; } if (mode == 1) { PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 1); break; } } PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 0); } while (0)
 #else
-#define PF_LAUNCH_SWEEP2__(TRV, FWV, SPV) PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 0)   /* the product library ships the 8 MODE-0 variants only */
+#define PF_LAUNCH_SWEEP2__(TRV, FWV, SPV) PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 0)   /* the product library ships the MODE-0 variants only: 8 per workgroup shape */
 #endif
 #define PF_LAUNCH_SWEEP2(TRV, FWV) do { if (a.sparse) PF_LAUNCH_SWEEP2__(TRV, FWV, true); else PF_LAUNCH_SWEEP2__(TRV, FWV, false); } while (0)
   if (tr) { if (a.forward) PF_LAUNCH_SWEEP2(true, true); else PF_LAUNCH_SWEEP2(true, false); }
@@ -1140,6 +1315,17 @@ bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
   return true;
 #undef PF_LAUNCH_SWEEP2_
 #undef PF_LAUNCH_SWEEP2
+}
+// Which workgroup shape: the wide form (two compute waves per SIMD) when the launch asks for more workgroups than the chip can
+// hold at once -- a batch of pairs at the large levels -- and the latency form otherwise (a.wide: 0 / 1 forced, -1 = by size).
+// `concurrent` = sweep launches that run beside this one (the other direction's): the host's estimate, 2 for a bidirectional solve.
+bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
+  int wide = a.wide;
+  if (wide < 0) {
+    const SweepWindow win = make_sweep_window(a.W, a.H, a.forward, a.ax0, a.ay0, a.ax1, a.ay1, kRows, SwLatency::kWaves, kChunk);
+    wide = (!win.empty && long(win.nwg) * a.bt.n * 2 > long(a.wide_threshold_wgs)) ? 1 : 0;
+  }
+  return wide ? launch_sweep2_form<SwWide>(st, a, rec) : launch_sweep2_form<SwLatency>(st, a, rec);
 }
 
 #ifdef PF_EXPERIMENTS

@@ -188,7 +188,7 @@ int check_dims(pf_ctx* c, int cols, int rows, int pad) {
 
 // Levels up to this many pixels trade launches for longer kernels (upsample inside the next Gaussian, second median inside the
 // diffusion): 0 for a lone pair, set by the throughput mode for its lanes; pf_config::fuse_small_level_px overrides both.
-long fuse_small_px(const pf_ctx* c) { return c->cfg.fuse_small_level_px >= 0 ? c->cfg.fuse_small_level_px : c->fuse_ups_px; }
+int64_t fuse_small_px(const pf_ctx* c) { return c->cfg.fuse_small_level_px >= 0 ? c->cfg.fuse_small_level_px : c->fuse_ups_px; }
 
 // the product library ships ONE sweep (k_sweep_prep + k_sweep2); the lab build (-DPF_EXPERIMENTS, libpanoflow_exp.so) adds the
 // cross-check implementations the test-suite holds it against
@@ -216,6 +216,9 @@ void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, cons
   sa.g0 = reinterpret_cast<const float2*>(g0); sa.g1 = reinterpret_cast<const float2*>(g1);
   sa.blurred = reinterpret_cast<const float2*>(b.blurred); sa.gate = gate; sa.W = w; sa.H = h; sa.sparse = sparse;
   if (box) { sa.ax0 = box[0]; sa.ay0 = box[1]; sa.ax1 = box[2] + 1; sa.ay1 = box[3] + 1; }   // empty (max < min): the sweeps are the identity
+  // workgroup shape (pf_config::sweep_wide): a lone pair never oversubscribes the chip (126 workgroups at 9000x4000) and keeps the latency form
+  sa.wide = c->cfg.sweep_wide < 0 ? (bt.n > 1 ? -1 : 0) : c->cfg.sweep_wide;
+  sa.wide_threshold_wgs = c->cfg.sweep_wide_threshold;
   // Timing a sweep (profile mode 1 or 2) attaches the two events to the launches themselves (hipExtLaunchKernel) instead of
   // recording markers around them.  Same-box A/B, ms per step: no timing 27.38, markers 27.65, attached events 27.60 -- bench.py's
   // roofline needs per-launch HIP events inside its timed region, so ~0.2 ms of every timed step is the measurement itself.
@@ -469,7 +472,9 @@ int solve_n(pf_ctx* c, int nb, const uint8_t* const* d_img0, const uint8_t* cons
   // Fine levels in two launches behind the coarse ones: levels [split2, split) at full width (needed first, a quarter of the fine
   // pixels), then the finest levels [0, split2) as a NARROW launch -- it runs beside the sweeps of ~30 coarser levels and is not
   // needed for milliseconds; at full width it took every wave slot of the chip and slowed the first sweeps several times over.
-  const int fineBlocks = c->cfg.fine_gradient_blocks;
+  // (a batch keeps every CU busy anyway -- there is nothing to hide a narrow launch behind, and at 64 blocks per image it would run
+  // for the whole solve: full width, pf_config::full_width_batch_gradients)
+  const int fineBlocks = (nb > 1 && c->cfg.full_width_batch_gradients) ? 0 : c->cfg.fine_gradient_blocks;
   const int split2 = split > 4 ? 4 : 0;
   if (have_table && split > 0) { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], table, g.off[split2], g.off[split], c->g3_05, 0, bt); }
   HIPCHK(c, hipEventRecord(c->ev_fine, sm));
@@ -675,6 +680,7 @@ void pf_config_init(pf_config* cfg) {
   cfg->struct_size = (int)sizeof *cfg;
   cfg->stagger_levels = -1; cfg->fuse_small_level_px = -1; cfg->fine_gradient_blocks = 64; cfg->pyramid_chaining = 1;
   cfg->sweep_window = 1; cfg->sparse_sweep = -1; cfg->sweep_impl = 2; cfg->record_path = 0; cfg->batch_pairs = -1;
+  cfg->sweep_wide = -1; cfg->sweep_wide_threshold = 768; cfg->full_width_batch_gradients = 1;
 }
 
 pf_ctx* pf_create(int device, int max_cols, int max_rows) {
@@ -747,7 +753,8 @@ pf_ctx* pf_create_cfg(const pf_config* user) {
   auto env_int = [](const char* name, int& v) { if (const char* e = getenv(name)) v = atoi(e); };
   env_int("PANOFLOW_SWEEP", cfg.sweep_impl); env_int("PANOFLOW_PREP", cfg.record_path); env_int("PANOFLOW_STAGGER", cfg.stagger_levels);
   env_int("PANOFLOW_PYR_CHAIN", cfg.pyramid_chaining); env_int("PANOFLOW_FINE_GRAD_BLOCKS", cfg.fine_gradient_blocks);
-  env_int("PANOFLOW_SPARSE", cfg.sparse_sweep);
+  env_int("PANOFLOW_SPARSE", cfg.sparse_sweep); env_int("PANOFLOW_WIDE", cfg.sweep_wide); env_int("PANOFLOW_WIDE_THRESHOLD", cfg.sweep_wide_threshold);
+  env_int("PANOFLOW_BATCH_GRAD_FULL", cfg.full_width_batch_gradients);
   if (getenv("PANOFLOW_NO_WINDOW")) cfg.sweep_window = 0;
   if (const char* e = getenv("PANOFLOW_FUSE_UPS_PX")) cfg.fuse_small_level_px = atol(e);
   if (cfg.sweep_impl != 1 && cfg.sweep_impl != 3) cfg.sweep_impl = 2;
@@ -759,7 +766,8 @@ pf_ctx* pf_create_cfg(const pf_config* user) {
   }
 #endif
   if (cfg.batch_pairs == 0 || cfg.batch_pairs < -1 || cfg.batch_pairs > kMaxBatch) { fail(nullptr, PF_ERR_ARG, "pf_create_cfg: batch_pairs must be -1 or 1..%d", kMaxBatch); return nullptr; }
-  if (cfg.fine_gradient_blocks < 1 || cfg.stagger_levels < -1 || cfg.fuse_small_level_px < -1 || cfg.sparse_sweep < -1 || cfg.sparse_sweep > 1) {
+  if (cfg.fine_gradient_blocks < 1 || cfg.stagger_levels < -1 || cfg.fuse_small_level_px < -1 || cfg.sparse_sweep < -1 || cfg.sparse_sweep > 1 ||
+      cfg.sweep_wide < -1 || cfg.sweep_wide > 1 || cfg.sweep_wide_threshold < 0) {
     fail(nullptr, PF_ERR_ARG, "pf_create_cfg: knob out of range");
     return nullptr;
   }
@@ -1358,6 +1366,7 @@ int pf_stage_sweep(pf_ctx* c, const float* g0, const float* g1, const float* blu
   HIPCHK(c, hipMemsetAsync(pcnt, 0, 2 * size_t(sweep2_num_wgs_max(w, h)) * sizeof(int), sm));
   SweepArgs sa; sa.prepcnt = pcnt; sa.g0 = (const float2*)dg0; sa.g1 = (const float2*)dg1; sa.blurred = (const float2*)dbl; sa.gate = gate; sa.flow = (float2*)df;
   sa.boundary = bnd; sa.ctrl = ctrl; sa.W = w; sa.H = h; sa.forward = forward; sa.sparse = (w * h) % 2;   // stage test: exercise both variants
+  sa.wide = c->cfg.sweep_wide == 1 ? 1 : 0;   // the workgroup shape the context was created for (auto = latency form: one pair)
   {
     std::vector<int> box; LevelTable t; t.n = 1; t.w[0] = w; t.h[0] = h; t.off[0] = 0;
     if (int e = gate_boxes_to_host(c, sm, gate, t, n, box)) return e;

@@ -138,6 +138,9 @@ struct SweepArgs {
   Batch bt;               // v2 sweep: bt.n same-size pairs in one launch (every pointer above is pair 0's; pair z's lies z * bt.stride bytes on)
   int prep_mode = 0;      // lab build only (-DPF_EXPERIMENTS): 1 / 2 = the two rejected record paths (pf_config::record_path)
   int ax0 = 0, ay0 = 0, ax1 = 1 << 30, ay1 = 1 << 30;   // bounding box [ax0,ax1) x [ay0,ay1) of the gated pixels (default: everything); v2 sweep only
+  int wide = 0;           // v2 sweep workgroup shape: 0 = latency form (4 bands per workgroup, one compute wave per SIMD), 1 = wide form (8 bands,
+                          // two compute waves per SIMD: throughput of a batch), -1 = wide when the launch oversubscribes the chip
+  int wide_threshold_wgs = 768;   // wide = -1: "oversubscribed" means more latency-form workgroups (x pairs x 2 directions) than this
 };
 size_t sweep_boundary_elems(int W, int H);   // hand-off granules needed per sweep launch (covers every sweep kernel of this build)
 size_t sweep1_boundary_elems(int W, int H);                     // lab build only (-DPF_EXPERIMENTS)

@@ -10,7 +10,11 @@ and stores what tests/test_gpu_fullsize.py::test_dense_canvas_pair_vs_oracle_fix
     combineNovelViews, CPU/OpticalFlow.cpp:30-145) -- the HIP path must reproduce all three BIT FOR BIT,
   * a stride-16 subsample of the three outputs (to say WHERE a mismatch is, should there ever be one).
 
-Run:  python tests/golden/make_dense_golden.py [cols rows [alg]]   (writes tests/golden/dense_<cols>x<rows>.npz)
+Run:  python tests/golden/make_dense_golden.py [cols rows [alg [seed]]]   (writes tests/golden/dense_<cols>x<rows>.npz)
+
+With a seed other than 1234 (config 5's other pairs: rank r of an N-GPU run solves seed 1234 + r) the fixture holds the
+SHA-256 strings only and is written to dense_<cols>x<rows>_s<seed>.npz (a few hundred bytes): enough for every rank of a
+multi-GPU bench / pano_batch run to validate its own pair.
 """
 import hashlib
 import importlib.util
@@ -44,10 +48,11 @@ def sha(a):
 def main():
     cols, rows = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (9000, 4000)
     max_pct = {"pixflow_low": 0, "pixflow_search_20": 20}[sys.argv[3] if len(sys.argv) > 3 else "pixflow_low"]
+    seed = int(sys.argv[4]) if len(sys.argv) > 4 else SEED
     orc.build()
     synth = load_synth()
     t0 = time.time()
-    L, R, blend = synth.make_pair_np(cols, rows, SEED)
+    L, R, blend = synth.make_pair_np(cols, rows, seed)
     print("inputs generated in %.0f s" % (time.time() - t0), flush=True)
     res = [None, None]
 
@@ -59,12 +64,13 @@ def main():
     th = [threading.Thread(target=run, args=(d,)) for d in (0, 1)]
     [t.start() for t in th]; [t.join() for t in th]
     out = orc.combine_novel_views(L, R, res[0], res[1], blend)
-    fix = {"cols": cols, "rows": rows, "seed": SEED, "max_pct": max_pct, "stride": STRIDE,
+    fix = {"cols": cols, "rows": rows, "seed": seed, "max_pct": max_pct, "stride": STRIDE,
            "sha_inputs": np.array([sha(L), sha(R), sha(blend)]),
-           "sha_outputs": np.array([sha(res[0]), sha(res[1]), sha(out)]),
-           "flow_l2r_sub": res[0][::STRIDE, ::STRIDE].copy(), "flow_r2l_sub": res[1][::STRIDE, ::STRIDE].copy(),
-           "out_sub": out[::STRIDE, ::STRIDE].copy()}
-    path = os.path.join(HERE, "dense_%dx%d.npz" % (cols, rows))
+           "sha_outputs": np.array([sha(res[0]), sha(res[1]), sha(out)])}
+    if seed == SEED:
+        fix.update({"flow_l2r_sub": res[0][::STRIDE, ::STRIDE].copy(), "flow_r2l_sub": res[1][::STRIDE, ::STRIDE].copy(),
+                    "out_sub": out[::STRIDE, ::STRIDE].copy()})
+    path = os.path.join(HERE, "dense_%dx%d%s.npz" % (cols, rows, "" if seed == SEED else "_s%d" % seed))
     np.savez_compressed(path, **fix)
     print("wrote %s (%.1f MB) in %.0f s; max |flow| = %.2f px" % (path, os.path.getsize(path) / 1e6, time.time() - t0,
                                                                   float(max(np.abs(res[0]).max(), np.abs(res[1]).max()))))

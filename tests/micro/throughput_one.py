@@ -8,7 +8,7 @@ pf = load_pkg_module("pyabi"); synth = load_pkg_module("synth")
 infl = int(sys.argv[1])
 cols, rows = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (2000, 4000)
 dev = torch.device("cuda", 0)
-nb = 24
+nb = int(os.environ.get("TP_PAIRS", "24"))
 pairs = [synth.make_pair(cols, rows, 7000 + i, dev) for i in range(nb)]
 outs = [torch.empty((rows, cols, 4), dtype=torch.uint8, device=dev) for _ in range(nb)]
 torch.cuda.synchronize()
@@ -16,6 +16,9 @@ bp = int(os.environ.get("TP_BATCH", "-1"))
 knobs = {"batch_pairs": bp}
 if os.environ.get("TP_STAGGER"): knobs["stagger_levels"] = int(os.environ["TP_STAGGER"])
 if os.environ.get("TP_FUSE"): knobs["fuse_small_level_px"] = int(os.environ["TP_FUSE"])
+if os.environ.get("TP_WIDE"): knobs["sweep_wide"] = int(os.environ["TP_WIDE"])
+if os.environ.get("TP_WIDE_THR"): knobs["sweep_wide_threshold"] = int(os.environ["TP_WIDE_THR"])
+if os.environ.get("TP_GRAD_FULL"): knobs["full_width_batch_gradients"] = int(os.environ["TP_GRAD_FULL"])
 c = pf.Context(0, cols, rows, **knobs)
 call = lambda: c.novel_view_batch_dev([p[0].data_ptr() for p in pairs], [p[1].data_ptr() for p in pairs], cols, rows, 0,
                                       [p[2].data_ptr() for p in pairs], [o.data_ptr() for o in outs], None, None, in_flight=infl)

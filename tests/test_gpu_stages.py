@@ -8,9 +8,11 @@ pytestmark = pytest.mark.gpu
 rng = np.random.default_rng(11)
 
 
-@pytest.fixture(scope="module")
-def ctx(pf):
-    c = pf.Context(0)
+@pytest.fixture(scope="module", params=["latency", "wide"])
+def ctx(pf, request):
+    """Every stage test runs with both workgroup shapes of the sweep (pf_config::sweep_wide): the latency form a lone pair uses
+    and the wide form (8 bands per workgroup, two compute waves per SIMD, pair-shared gather windows) of the throughput mode."""
+    c = pf.Context(0, sweep_wide=1 if request.param == "wide" else 0)
     yield c
     c.close()
 

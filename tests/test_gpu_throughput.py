@@ -23,14 +23,17 @@ def _fetch(c, d, cols, rows):
             c.download(np.empty((rows, cols, 2), np.float32), d["f1"]))
 
 
-@pytest.mark.parametrize("in_flight,batch_pairs", [(4, -1), (6, -1), (6, 1), (5, 5), (7, 2), (8, 8)])
-def test_batch_entry_point_equals_single_calls(pf, synth, in_flight, batch_pairs):
+@pytest.mark.parametrize("in_flight,batch_pairs,wide", [(4, -1, -1), (6, -1, -1), (6, 1, -1), (5, 5, -1), (7, 2, -1), (8, 8, -1), (8, 8, 1), (5, 5, 1), (6, 3, 1)])
+def test_batch_entry_point_equals_single_calls(pf, synth, in_flight, batch_pairs, wide):
     """pf_novel_view_batch_dev = lanes x batches: pairs of a batch share every kernel launch (blockIdx.z = pair, slab buffers, one
     sweep window = the union of the pairs' windows), lanes run side by side.  Whatever the split -- also with a ragged last batch,
-    with flows the caller does not want, and with pairs whose gates differ -- the results are the bits of single calls."""
+    with flows the caller does not want, and with pairs whose gates differ -- the results are the bits of single calls.
+    wide = 1: every sweep launch of the batch in the wide workgroup shape (pf_config::sweep_wide; by default only launches that
+    oversubscribe the chip use it), held against single calls in the latency shape."""
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     cols, rows, n = 1000, 1400, 7
-    c = pf.Context(0, batch_pairs=batch_pairs)
+    c = pf.Context(0, batch_pairs=batch_pairs, sweep_wide=wide)
+    ref_ctx = pf.Context(0, sweep_wide=0)
     pairs = [_dev_pair(pf, c, synth, cols, rows, 100 + i) for i in range(n)]
     # pair 2: an extra hole in the alpha of both images -> a different gate / bounding box than its batch mates
     L2, R2, _ = synth.make_pair_np(cols, rows, 102)
@@ -38,8 +41,9 @@ def test_batch_entry_point_equals_single_calls(pf, synth, in_flight, batch_pairs
     c.upload(pairs[2]["L"], L2); c.upload(pairs[2]["R"], R2)
     ref = []
     for d in pairs:
-        c.novel_view_dev(d["L"], d["R"], cols, rows, 20, d["b"], d["o"], d["f0"], d["f1"])
-        ref.append(_fetch(c, d, cols, rows))
+        ref_ctx.novel_view_dev(d["L"], d["R"], cols, rows, 20, d["b"], d["o"], d["f0"], d["f1"])
+        ref.append(_fetch(ref_ctx, d, cols, rows))
+    ref_ctx.close()
     for rep in range(2):
         for d in pairs:   # scrub the outputs so a stale result cannot pass
             c.upload(d["o"], np.zeros((rows, cols, 4), np.uint8)); c.upload(d["f0"], np.zeros((rows, cols, 2), np.float32))
