@@ -243,40 +243,33 @@ void launch_count_gate(hipStream_t st, const uint8_t* gate, int n, unsigned* cou
 
 // ------------------------------------------------------------------------------------------------
 // K7 medianBlur(5) on float2, per channel, BORDER_REPLICATE, out of place (PixFlow.hpp:325,338).
-// Exact selection by "forgetful selection": keep a pool of n/2+2 candidates, drop its min and max,
-// add the next element; the survivor of the last 3 is the median.  All in registers.
+// A median is a pure selection: the element of rank 13 of the window, whatever finds it.  Two horizontally adjacent outputs per
+// thread: their 5x5 windows share four columns (20 values), and an element of that shared set can only be the median of either
+// window if its rank inside the set is 8..13.  The selection network is GENERATED (tools/gen_median_net.py -> median_net.inl):
+// columns sorted with v_min3 / v_med3 / v_max3 (12 instructions per column), Batcher odd-even merges of the sorted columns, ranks
+// 8..13 of the shared twenty merged with each output's own fifth column, and everything the two medians do not depend on pruned
+// by a liveness pass -- 180 instructions per channel for the two outputs (rounds 1-3: hand-written "forgetful selection", ~345),
+// verified exhaustively with the 0-1 principle (2^30 inputs; tests/test_median_net.py).  All in registers.
 // ------------------------------------------------------------------------------------------------
-#define PF_CE(a, b) { const float lo_ = __builtin_fminf(a, b); const float hi_ = __builtin_fmaxf(a, b); a = lo_; b = hi_; }
-template <int N>
-__device__ __forceinline__ void d_minmax(float* v) {  // afterwards v[0] = min, v[N-1] = max of v[0..N-1]
+// (Measured and rejected: the five operations as inline-asm instructions, to shed the 60 v_max x, x, x with which the compiler
+// canonicalises the values loaded from memory before an fminf / fmaxf -- the hazard recogniser then puts an s_nop behind every asm
+// statement whose result is read next, 66 of them: 571 instead of 524 instructions per thread.)
+__device__ __forceinline__ float d_min3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }   // v_min3_f32
+__device__ __forceinline__ float d_max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }   // v_max3_f32
+#include "median_net.inl"
+// medians of the two horizontally adjacent outputs whose 6 x 5 neighbourhood is col[0..5][0..4] (output 0: columns 0-4, output 1: 1-5)
+__device__ __forceinline__ void d_median_pair(const float2 (&col)[6][5], float2& m0, float2& m1) {
+  float in[30], a, b;
 #pragma unroll
-  for (int i = 0; i + 1 < N; i += 2) PF_CE(v[i], v[i + 1]);
+  for (int i = 0; i < 6; ++i)
 #pragma unroll
-  for (int i = 2; i < N; i += 2) PF_CE(v[0], v[i]);
+    for (int j = 0; j < 5; ++j) in[i * 5 + j] = col[i][j].x;
+  d_median_pair_net(in, a, b); m0.x = a; m1.x = b;
 #pragma unroll
-  for (int i = 1; i < N - 1; i += 2) PF_CE(v[i], v[N - 1]);
-}
-// Two horizontally adjacent outputs per thread.  Their 5x5 windows share four columns (20 values): an element of that shared
-// set can only be the median (rank 13 of 25) of either window if its rank inside the set is 8..13 -- it has at least rank-1
-// and at most rank-1+5 values below it -- so the 7 smallest and 7 largest shared values are dropped ONCE (forgetful
-// selection), and each output then selects the median of 11 = 6 survivors + its own fifth column.  Pure selection: the value
-// is the one any exact median returns; ~80 compare-exchanges per output and channel instead of ~130.
-__device__ __forceinline__ void d_mid6of20(float* v) {   // afterwards v[1..6] hold the elements of rank 8..13 of v[0..19]
-  d_minmax<14>(v); v[0] = v[14];
-  d_minmax<13>(v); v[0] = v[15];
-  d_minmax<12>(v); v[0] = v[16];
-  d_minmax<11>(v); v[0] = v[17];
-  d_minmax<10>(v); v[0] = v[18];
-  d_minmax<9>(v); v[0] = v[19];
-  d_minmax<8>(v);
-}
-__device__ __forceinline__ float d_median11(float* v) {  // median of v[0..10]
-  d_minmax<7>(v); v[0] = v[7];
-  d_minmax<6>(v); v[0] = v[8];
-  d_minmax<5>(v); v[0] = v[9];
-  d_minmax<4>(v); v[0] = v[10];
-  d_minmax<3>(v);
-  return v[1];
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) in[i * 5 + j] = col[i][j].y;
+  d_median_pair_net(in, a, b); m0.y = a; m1.y = b;
 }
 // One output pixel of medianBlur(5), with exactly the operations k_median5 performs for it (that kernel computes outputs xp = x & ~1
 // and xp + 1 together; which four columns are shared depends on the parity of x) -- used by the Gaussian that takes the median
@@ -290,23 +283,9 @@ __device__ __forceinline__ float2 d_median5_px(const float2* __restrict__ src, i
 #pragma unroll
     for (int i = 0; i < 6; ++i) col[i][j] = r[d_replicate(xp + i - 2, w)];
   }
-  float m[2];
-#pragma unroll
-  for (int ch = 0; ch < 2; ++ch) {
-    float s[20];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 5; ++j) s[i * 5 + j] = ch ? col[i + 1][j].y : col[i + 1][j].x;
-    d_mid6of20(s);
-    float t[11];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) t[k] = s[k + 1];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) { const float2 e = o ? col[5][j] : col[0][j]; t[6 + j] = ch ? e.y : e.x; }
-    m[ch] = d_median11(t);
-  }
-  return make_float2(m[0], m[1]);
+  float2 m0, m1;
+  d_median_pair(col, m0, m1);
+  return o ? m1 : m0;
 }
 
 // one output pixel of the inter-level upsample (K9 below: resize INTER_CUBIC on float2, then *= 1/0.9f); shared by
@@ -555,31 +534,14 @@ __global__ __launch_bounds__(256) void k_median5(const float2* __restrict__ src,
 #pragma unroll
     for (int i = 0; i < 6; ++i) col[i][j] = r[d_replicate(xp + i - 2, w)];
   }
-  float m[2][2];
-#pragma unroll
-  for (int ch = 0; ch < 2; ++ch) {
-    float s[20];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 5; ++j) s[i * 5 + j] = ch ? col[i + 1][j].y : col[i + 1][j].x;
-    d_mid6of20(s);
-#pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      float t[11];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) t[k] = s[k + 1];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) t[6 + j] = ch ? col[o ? 5 : 0][j].y : col[o ? 5 : 0][j].x;
-      m[o][ch] = d_median11(t);
-    }
-  }
-  dst[size_t(y) * w + xp] = make_float2(m[0][0], m[0][1]);
-  if (xp + 1 < w) dst[size_t(y) * w + xp + 1] = make_float2(m[1][0], m[1][1]);
+  float2 m0, m1;
+  d_median_pair(col, m0, m1);
+  dst[size_t(y) * w + xp] = m0;
+  if (xp + 1 < w) dst[size_t(y) * w + xp + 1] = m1;
 }
 // A block of 1024 threads owns a 128 x 16 output tile.  The tile + its 2-pixel halo (replicate border) is staged in LDS once -- 1.29
 // global loads per output instead of 15 through L1 -- and every thread then selects 2 horizontally adjacent outputs of one row
-// from LDS (16-byte reads: the six columns of an output pair are three float4).  Same selection network (d_mid6of20 / d_median11).
+// from LDS (16-byte reads: the six columns of an output pair are three float4).  Same generated selection network (d_median_pair).
 // Measured per launch beside the other direction's kernels (tests/micro/kern_by_grid.sh): 4950x2000 123 vs 139 us, 4455x1800 112 vs
 // 124, equal at ~2.3 Mpix, slower below (a block's single HBM round trip + barrier in front of the network): levels >= kMedTiledMinPx.
 constexpr int kMedX = 128, kMedY = 16, kMedSX = kMedX + 4, kMedSY = kMedY + 4, kMedT = 64 * kMedY;
@@ -612,29 +574,12 @@ __global__ __launch_bounds__(kMedT) void k_median5_tiled(const float2* __restric
 #pragma unroll
     for (int i = 0; i < 3; ++i) { const float4 v = rp[i]; col[2 * i][j] = make_float2(v.x, v.y); col[2 * i + 1][j] = make_float2(v.z, v.w); }
   }
-  float m[2][2];
-#pragma unroll
-  for (int ch = 0; ch < 2; ++ch) {
-    float s[20];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 5; ++j) s[i * 5 + j] = ch ? col[i + 1][j].y : col[i + 1][j].x;
-    d_mid6of20(s);
-#pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      float t[11];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) t[k] = s[k + 1];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) t[6 + j] = ch ? col[o ? 5 : 0][j].y : col[o ? 5 : 0][j].x;
-      m[o][ch] = d_median11(t);
-    }
-  }
-  if (xp + 1 < w && ((w & 1) == 0)) *reinterpret_cast<float4*>(&dst[size_t(y) * w + xp]) = make_float4(m[0][0], m[0][1], m[1][0], m[1][1]);
+  float2 m0, m1;
+  d_median_pair(col, m0, m1);
+  if (xp + 1 < w && ((w & 1) == 0)) *reinterpret_cast<float4*>(&dst[size_t(y) * w + xp]) = make_float4(m0.x, m0.y, m1.x, m1.y);
   else {
-    dst[size_t(y) * w + xp] = make_float2(m[0][0], m[0][1]);
-    if (xp + 1 < w) dst[size_t(y) * w + xp + 1] = make_float2(m[1][0], m[1][1]);
+    dst[size_t(y) * w + xp] = m0;
+    if (xp + 1 < w) dst[size_t(y) * w + xp + 1] = m1;
   }
 }
 constexpr long kMedTiledMinPx = 3000000;
