@@ -41,38 +41,39 @@ def _load(name):
     return mod
 
 
-def cpu_baseline(L, R, blend, max_pct):
-    """The oracle (a port: the reference's CPU/ cannot be compiled here) on the GPU box's host cores, on the SAME pair.
-    (i) 1 thread: both directions one after the other (the reference has no threading of its own);
-    (ii) 2 threads: one per flow direction, the only result-preserving parallelism the algorithm has
-    (OpticalFlow.cpp:130-139).  Both legs run at the same time on three host threads (the box has hundreds)."""
+def cpu_baseline(L, R, blend, max_pct, more_pairs=()):
+    """The oracle (a port: the reference's CPU/ cannot be compiled here) on the GPU box's host cores, on the SAME pair.  Three legs,
+    ONE AFTER THE OTHER:
+    (ii) 2 threads: one per flow direction, the only result-preserving parallelism the algorithm has (OpticalFlow.cpp:130-139);
+    (iii) config 5: one pair per two cores -- `more_pairs` further (L, R) sub-strips solved at the same time as this one, two
+          threads each (pairs are independent: CPU/main.cpp:70,82);
+    (i) 1 thread: both directions one after the other (the reference has no threading of its own)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
     orc.build()
     res = [None, None]
-    t_one = [0.0]
-    t_two = [0.0, 0.0]
 
-    def serial():
+    def timed(fn, *a):
         t0 = time.perf_counter()
-        for d in (0, 1):
-            res[d] = orc.flow_one_dir(L, R, max_pct, d)
-        t_one[0] = time.perf_counter() - t0
+        r = fn(*a)
+        return time.perf_counter() - t0, r
 
-    def single(d):
-        t0 = time.perf_counter()
-        orc.flow_one_dir(L, R, max_pct, d)
-        t_two[d] = time.perf_counter() - t0
+    def two_threads(Lx, Rx, keep):
+        th = [threading.Thread(target=lambda d=d: keep.__setitem__(d, orc.flow_one_dir(Lx, Rx, max_pct, d))) for d in (0, 1)]
+        [t.start() for t in th]; [t.join() for t in th]
 
-    th = [threading.Thread(target=serial)] + [threading.Thread(target=single, args=(d,)) for d in (0, 1)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    t0 = time.perf_counter()
-    out = orc.combine_novel_views(L, R, res[0], res[1], blend)
-    t_blend = time.perf_counter() - t0
-    return t_one[0] + t_blend, max(t_two) + t_blend, res[0], res[1], out
+    t_two, _ = timed(two_threads, L, R, res)
+    t_many = None
+    if more_pairs:
+        sinks = [[None, None] for _ in more_pairs]
+        def many():
+            th = [threading.Thread(target=two_threads, args=(L, R, [None, None]))]
+            th += [threading.Thread(target=two_threads, args=(Lp, Rp, sk)) for (Lp, Rp), sk in zip(more_pairs, sinks)]
+            [t.start() for t in th]; [t.join() for t in th]
+        t_many, _ = timed(many)
+    t_one, _ = timed(lambda: [orc.flow_one_dir(L, R, max_pct, d) for d in (0, 1)])
+    t_blend, out = timed(orc.combine_novel_views, L, R, res[0], res[1], blend)
+    return t_one + t_blend, t_two + t_blend, (t_many + t_blend) if t_many else None, res[0], res[1], out
 
 
 def measure_t_step(pf, ctx, np):
@@ -93,6 +94,58 @@ def measure_t_step(pf, ctx, np):
     ms, n = ctx.profile()["sweep"]
     ctx.profile_reset()
     return 1000.0 * ms / n / (w + h - 1)
+
+
+def copy_rates(torch, pf, ctx, np, L, R, out, f0, f1):
+    """H2D / D2H of the `value` workload's buffers, reported separately and never part of `value` (the timed region
+    starts with the images resident in HBM and ends with flows + strip resident in HBM): the two input images up, both flows and
+    the blended strip down, through the library's own copy entry points, from pageable memory and from pf_host_alloc (page-locked)
+    memory; plus the device's measured copy bandwidth (a 2 GiB device-to-device copy, read + write counted)."""
+    def timed(fn):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); return time.perf_counter() - t0
+    ups = [(L, L.numel()), (R, R.numel())]
+    downs = [(f0, f0.numel() * 4), (f1, f1.numel() * 4), (out, out.numel())]
+    res = {}
+    for kind in ("pageable", "pinned"):
+        hb = {}
+        for t, nbytes in ups + downs:
+            hb[id(t)] = np.empty(nbytes, np.uint8) if kind == "pageable" else ctx.host_array((nbytes,), np.uint8)
+            hb[id(t)][:] = 1   # touch the pages
+        up = lambda: [ctx.upload(t.data_ptr(), hb[id(t)]) for t, _ in ups]
+        down = lambda: [ctx.download(hb[id(t)], t.data_ptr()) for t, _ in downs]
+        saved = [t.clone() for t, _ in ups]
+        down(); tu = min(timed(up) for _ in range(2)); td = min(timed(down) for _ in range(2))
+        for (t, _), sv in zip(ups, saved):
+            t.copy_(sv)       # (the uploads overwrote the inputs with the staging buffers' content)
+        nu = sum(n for _, n in ups); nd = sum(n for _, n in downs)
+        res[kind] = {"h2d_ms": round(1000 * tu, 2), "h2d_GBps": round(nu / tu / 1e9, 2), "d2h_ms": round(1000 * td, 2), "d2h_GBps": round(nd / td / 1e9, 2)}
+        del hb
+    res["h2d_bytes"] = sum(n for _, n in ups); res["d2h_bytes"] = sum(n for _, n in downs)
+    a = torch.empty(1 << 31, dtype=torch.uint8, device=L.device); b = torch.empty_like(a)
+    b.copy_(a)
+    td2d = min(timed(lambda: b.copy_(a)) for _ in range(3))
+    res["hbm_copy_measured_GBps"] = round(2 * a.numel() / td2d / 1e9, 1)
+    res["note"] = "copies of the `value` workload's buffers through pf_upload / pf_download; never part of `value`; hbm_copy = 2 GiB device-to-device, read + write"
+    del a, b
+    torch.cuda.empty_cache()
+    return res
+
+
+def fixture_verdict(np, cols, rows, alg, seed, L, R, blend, f0, f1, strip):
+    """This rank's pair against the oracle fixture of ITS seed (tests/golden/dense_<size>[_s<seed>].npz: SHA-256 of the inputs and of
+    the oracle's two flows and blended strip, computed in the build container): the TIMED pair's own outputs, no extra pass."""
+    import hashlib
+    fx = os.path.join(ROOT, "tests", "golden", "dense_%dx%d%s.npz" % (cols, rows, "" if seed == 1234 else "_s%d" % seed))
+    if alg != "pixflow_low" or not os.path.exists(fx):
+        return None, "no fixture for %dx%d seed %d %s" % (cols, rows, seed, alg)
+    g = np.load(fx)
+    sha = lambda t: hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()
+    if [sha(L), sha(R), sha(blend)] != [str(v) for v in g["sha_inputs"]]:
+        return False, "the generated inputs are not the fixture's (synth.make_pair must give the host's bytes on every device)"
+    got = [sha(f0), sha(f1), sha(strip)]
+    want = [str(v) for v in g["sha_outputs"]]
+    return got == want, {"flow_l2r_bit_identical": got[0] == want[0], "flow_r2l_bit_identical": got[1] == want[1], "blend_byte_identical": got[2] == want[2],
+                         "strip_sha256": want[2]}
 
 
 def main():
@@ -224,6 +277,27 @@ def main():
     med_ms = statistics.median(step_ms)
     swept = ctx.last_swept_steps()
 
+    # ---- self-validation, off the clock: EVERY rank holds the outputs of its own timed pair (seed 1234 + rank) against the oracle
+    # fixture of that seed; the verdicts are all-reduced, and rank 0 additionally checks every gathered slot against the SHA-256 of
+    # the strip its producer should have made -- an N-GPU run needs nothing else to be trusted ----
+    last_out = og.bufs[(og.k - 1) % 2] if og else out
+    fx_ok, fx_detail = fixture_verdict(np, cols, rows, args.alg, 1234 + rank, L, R, blend, f0, f1, last_out)
+    fx_all = fx_ok
+    if world > 1 or force_dist:
+        code = torch.tensor([2 if fx_ok is None else (1 if fx_ok else 0)], device=dev)
+        dist.all_reduce(code, op=dist.ReduceOp.MIN)
+        fx_all = None if int(code.item()) == 2 else bool(int(code.item()))
+    slots_ok = None
+    if og and rank == 0 and fx_ok is not None:
+        import hashlib
+        slots_ok = True
+        for r in range(world):
+            fxr = os.path.join(ROOT, "tests", "golden", "dense_%dx%d%s.npz" % (cols, rows, "" if r == 0 else "_s%d" % (1234 + r)))
+            if not os.path.exists(fxr):
+                slots_ok = None; break
+            want_sha = str(np.load(fxr)["sha_outputs"][2])
+            slots_ok = slots_ok and hashlib.sha256(og.last()[r].cpu().numpy().tobytes()).hexdigest() == want_sha
+
     prof = ctx.profile()
     # per-family breakdown from ONE extra, untimed step with every family instrumented
     ctx.profile_reset(); ctx.profile_enable(1); step(); ctx.profile_enable(0)
@@ -244,7 +318,8 @@ def main():
             "config": {"workload": "%s: one dense %dx%d overlap pair per GPU (the same for every --gpus N), %s, flow L->R + R->L + novel-view blend, %d pair(s) in flight per GPU"
                                    % (which, cols, rows, args.alg, max(1, args.concurrent)),
                        "levels": nlev, "level_pixels": P, "sweep_steps_per_direction": sweep_steps, "swept_steps_per_direction_in_gated_window": swept,
-                       "final_gather": ((gather_note or "rccl send/recv to rank 0 inside libpanoflow.so (pf_dist_*), overlapped with the next pair") + "; rank-0 slot verified: %s" % gathered_ok) if og else "none (single rank)"},
+                       "final_gather": ((gather_note or "rccl send/recv to rank 0 inside libpanoflow.so (pf_dist_*), overlapped with the next pair") + "; rank-0 slot verified: %s; every rank's slot equals its oracle fixture's strip: %s" % (gathered_ok, slots_ok)) if og else "none (single rank)"},
+            "fixture_ok": fx_all,
             "ms_per_step_median": round(med_ms, 3), "value_at_median": round(npairs * mpix / (med_ms * 1e-3), 3),
         }
         # roofline of the dominant kernel (the exact wavefront sweep): algorithmic bytes per launch =
@@ -277,6 +352,11 @@ def main():
         res["roofline_path"] = {"bound": "hbm", "achieved": round(ach_path, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach_path / 8000.0, 6),
                                 "algorithmic_bytes_per_pair": b_alg}
         res["kernels_ms_per_step"] = {k: round(v[0], 3) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}
+        res["parity_vs_cpu"] = {"full_pair_vs_oracle_fixture": dict(fx_detail, inputs="the timed pair itself (every rank its own: seed 1234 + rank; verdicts all-reduced into fixture_ok)",
+                                                                    fixture="tests/golden/dense_%dx%d[_s<seed>].npz (SHA-256 of the oracle's outputs, computed in the build container)" % (cols, rows))
+                                if isinstance(fx_detail, dict) else fx_detail}
+        if not args.no_extras and args.concurrent <= 1:
+            res["copies"] = copy_rates(torch, pf, ctx, np, L, R, last_out, f0, f1)
 
         if world == 1 and not args.no_extras and args.concurrent <= 1:
             # ---- the honest bound of the sweeps: a dependency chain of `swept` steps per direction x the time of one step
@@ -346,41 +426,26 @@ def main():
             # run on exactly that sub-strip.  The full pair is held to the oracle through the committed fixture's SHA-256.
             x0 = max(0, (cols - 2000) // 2); x1 = min(cols, x0 + 2000)
             Lh, Rh, bh = L[:, x0:x1].contiguous().cpu().numpy(), R[:, x0:x1].contiguous().cpu().numpy(), blend[:, x0:x1].contiguous().cpu().numpy()
-            t1, t2, r0, r1, rout = cpu_baseline(Lh, Rh, bh, max_pct)
+            # leg (iii): the same sub-strip of config 5's seven other pairs (seeds 1235..1241), generated on the GPU (the host's bytes)
+            more = []
+            if not args.no_extras:
+                for sd in range(1235, 1242):
+                    Lp, Rp, _, _ = synth.make_pair(cols, rows, sd, dev)
+                    more.append((Lp[:, x0:x1].contiguous().cpu().numpy(), Rp[:, x0:x1].contiguous().cpu().numpy()))
+                    del Lp, Rp
+            t1, t2, t3, r0, r1, rout = cpu_baseline(Lh, Rh, bh, max_pct, more)
             cg = pf.Context(local_rank)
             gout, g0, g1 = cg.novel_view(Lh, Rh, max_pct, bh)
             cg.close()
             smp = (x1 - x0) * rows / 1e6
             res["cpu_baseline"] = {"value": round(smp / t2, 4), "unit": "Mpix/s", "cores": 2, "kind": "port",
-                                   "sample": "columns [%d, %d) of the same %dx%d pair (a %dx%d sub-strip), whole path once: 2 flow directions on 2 threads + blend (%.1f s)" % (x0, x1, cols, rows, x1 - x0, rows, t2),
+                                   "sample": "columns [%d, %d) of the same %dx%d pair (a %dx%d sub-strip), whole path once: 2 flow directions on 2 threads + blend (%.1f s); the three legs run one after the other" % (x0, x1, cols, rows, x1 - x0, rows, t2),
                                    "one_thread": {"value": round(smp / t1, 4), "unit": "Mpix/s", "cores": 1, "seconds": round(t1, 2)},
-                                   "host_threads_available": os.cpu_count(),
-                                   "note": "leg (iii) of SURVEY 8(d) (one pair per core) only applies to config 5 and is not run"}
-            res["parity_vs_cpu"] = {"sample_max_abs_dflow_px": float(max(np.abs(g0 - r0).max(), np.abs(g1 - r1).max())),
-                                    "sample_blend_bytes_off": int((gout != rout).sum())}
-            fx = os.path.join(ROOT, "tests", "golden", "dense_%dx%d.npz" % (cols, rows))
-            if os.path.exists(fx) and args.alg == "pixflow_low":
-                import hashlib
-                g = np.load(fx)
-                sha = lambda t: hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()
-                note = "the timed pair itself (generated on this GPU) is the fixture's"
-                last_out = og.bufs[(og.k - 1) % 2] if og else out
-                if [sha(L), sha(R), sha(blend)] != list(g["sha_inputs"]):
-                    # sin/cos of the synthetic texture round differently on the GPU in a few pixels: regenerate the fixture's pair on
-                    # the host, and run ONE more (untimed) pass of the same entry point on it
-                    Lc, Rc, bc, _ = synth.make_pair(cols, rows, 1234 + rank, "cpu")
-                    L.copy_(Lc); R.copy_(Rc); blend.copy_(bc)
-                    torch.cuda.synchronize()
-                    ctx.novel_view_dev(L.data_ptr(), R.data_ptr(), cols, rows, max_pct, blend.data_ptr(), out.data_ptr(), f0.data_ptr(), f1.data_ptr())
-                    last_out = out
-                    note = "the fixture's pair regenerated on the host (the GPU-generated texture differs from it in a few pixels), one extra untimed pass"
-                if [sha(L), sha(R), sha(blend)] == list(g["sha_inputs"]):
-                    res["parity_vs_cpu"]["full_pair_vs_oracle_fixture"] = {
-                        "flow_l2r_bit_identical": sha(f0) == str(g["sha_outputs"][0]), "flow_r2l_bit_identical": sha(f1) == str(g["sha_outputs"][1]),
-                        "blend_byte_identical": sha(last_out) == str(g["sha_outputs"][2]), "inputs": note,
-                        "fixture": "tests/golden/dense_%dx%d.npz (SHA-256 of the oracle's outputs for this very pair, computed in the build container)" % (cols, rows)}
-                else:
-                    res["parity_vs_cpu"]["full_pair_vs_oracle_fixture"] = "synthetic pair differs from the fixture's even when generated on the host: not compared"
+                                   "pairs_in_parallel": ({"value": round((1 + len(more)) * smp / t3, 4), "unit": "Mpix/s", "cores": 2 * (1 + len(more)), "pairs": 1 + len(more), "seconds": round(t3, 2),
+                                                          "note": "SURVEY 8(d) leg (iii), config 5: the same sub-strip of the 8 pairs (seeds 1234..1241) at the same time, two threads each"} if t3 else None),
+                                   "host_threads_available": os.cpu_count()}
+            res["parity_vs_cpu"].update({"sample_max_abs_dflow_px": float(max(np.abs(g0 - r0).max(), np.abs(g1 - r1).max())),
+                                         "sample_blend_bytes_off": int((gout != rout).sum())})
         if world == 1 and not args.no_extras and args.concurrent <= 1:
             # the main context's five streams give way first: a lane drives three streams and the runtime maps streams to
             # GPU_MAX_HW_QUEUES hardware queues round-robin -- more live streams than queues and two busy ones share a queue

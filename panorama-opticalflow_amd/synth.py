@@ -4,6 +4,12 @@ Analytic multi-sinusoid texture T, smooth displacement field d, L = T(x + d/2), 
 (gain exercises computeIntensityRatio), alpha holes (edge bands + one ellipse), horizontal blend ramp.
 Ground truth: flow L->R ~= -d, flow R->L ~= +d inside the valid-alpha region.
 Works on any torch device (the bench generates directly in HBM).
+
+THE HOST (CPU) RESULT IS THE DEFINITION: the oracle fixtures under tests/golden hold SHA-256 of host-generated pairs.  A GPU's
+sin / cos differ from the host's in the last places, which moves a value across a rounding boundary in a handful of the 10^8
+quantised samples of a 9000x4000 pair.  make_pair on a GPU therefore flags every sample whose pre-rounding value lies within
+1e-6 of a rounding boundary (and every pixel within 1e-9 of the ellipse's edge), re-evaluates exactly those pixels (a few hundred)
+on the host with the same expressions, and patches them in: the bytes are the host's on any device.
 """
 import math
 
@@ -64,33 +70,73 @@ def alpha_mask(x, y, cols, rows):
     return inside & ~ell
 
 
+_ROUND_MARGIN = 1e-6     # |device - host| of a pre-rounding value is ~1e-12: anything this close to a rounding boundary is re-done on the host
+_EDGE_MARGIN = 1e-9
+
+
+def _pixels(x, y, cols, rows, ks, disp_scale, want_flags=False):
+    """BGRA of L and R at the pixel coordinates (x, y) (float64 tensors of one shape): ([..., 4] uint8, [..., 4] uint8[, flags])."""
+    dx, dy = displacement(x, y, cols, rows, disp_scale)
+    a = alpha_mask(x, y, cols, rows)
+    tl = _texture(x + dx / 2, y + dy / 2, ks)
+    tr = _texture(x - dx / 2, y - dy / 2, ks)
+    L = torch.empty(x.shape + (4,), dtype=torch.uint8, device=x.device)
+    R = torch.empty(x.shape + (4,), dtype=torch.uint8, device=x.device)
+    flags = None
+    if want_flags:
+        ell = ((x - 0.7 * cols) / (cols / 10.0)) ** 2 + ((y - 0.3 * rows) / (rows / 12.0)) ** 2
+        flags = (ell - 1.0).abs() < _EDGE_MARGIN
+    for ch in range(3):
+        lv = torch.clamp(tl[ch], 16.0, 240.0)
+        rv = 1.05 * torch.clamp(tr[ch], 16.0, 240.0)
+        if want_flags:
+            for v in (lv, rv):
+                flags = flags | (((v - torch.floor(v)) - 0.5).abs() < _ROUND_MARGIN)
+        l = torch.clamp(torch.round(lv), 0, 255)
+        r = torch.clamp(torch.round(rv), 0, 255)
+        L[..., ch] = torch.where(a, l, torch.zeros_like(l)).to(torch.uint8)
+        R[..., ch] = torch.where(a, r, torch.zeros_like(r)).to(torch.uint8)
+    av = torch.where(a, 255, 0).to(torch.uint8)
+    L[..., 3] = av; R[..., 3] = av
+    return (L, R, flags) if want_flags else (L, R)
+
+
 def make_pair(cols, rows, seed=1234, device="cpu", disp_scale=1.0, row_chunk=512):
-    """Returns (L, R, blend, (dx, dy)): L,R uint8 [rows, cols, 4] BGRA; blend float32 [rows, cols]."""
+    """Returns (L, R, blend, None): L,R uint8 [rows, cols, 4] BGRA; blend float32 [rows, cols].  The same bytes on every device
+    (the host's: see the module docstring)."""
     ks = texture_params(seed)
+    on_host = torch.device(device).type == "cpu"
     L = torch.empty((rows, cols, 4), dtype=torch.uint8, device=device)
     R = torch.empty((rows, cols, 4), dtype=torch.uint8, device=device)
     xs = torch.arange(cols, dtype=torch.float64, device=device)[None, :]
+    redo = []
     for y0 in range(0, rows, row_chunk):
         y1 = min(rows, y0 + row_chunk)
         ys = torch.arange(y0, y1, dtype=torch.float64, device=device)[:, None]
         x = xs.expand(y1 - y0, cols); y = ys.expand(y1 - y0, cols)
-        dx, dy = displacement(x, y, cols, rows, disp_scale)
-        a = alpha_mask(x, y, cols, rows)
-        tl = _texture(x + dx / 2, y + dy / 2, ks)
-        tr = _texture(x - dx / 2, y - dy / 2, ks)
-        for ch in range(3):
-            l = torch.clamp(torch.round(torch.clamp(tl[ch], 16.0, 240.0)), 0, 255)
-            r = torch.clamp(torch.round(1.05 * torch.clamp(tr[ch], 16.0, 240.0)), 0, 255)
-            L[y0:y1, :, ch] = torch.where(a, l, torch.zeros_like(l)).to(torch.uint8)
-            R[y0:y1, :, ch] = torch.where(a, r, torch.zeros_like(r)).to(torch.uint8)
-        av = torch.where(a, 255, 0).to(torch.uint8)
-        L[y0:y1, :, 3] = av; R[y0:y1, :, 3] = av
+        if on_host:
+            L[y0:y1], R[y0:y1] = _pixels(x, y, cols, rows, ks, disp_scale)
+        else:
+            L[y0:y1], R[y0:y1], fl = _pixels(x, y, cols, rows, ks, disp_scale, want_flags=True)
+            idx = fl.nonzero()
+            if idx.numel():
+                idx[:, 0] += y0
+                redo.append(idx)
+    if redo:
+        idx = torch.cat(redo).cpu()
+        py, px = idx[:, 0], idx[:, 1]
+        Lh, Rh = _pixels(px.double(), py.double(), cols, rows, ks, disp_scale)
+        L[py.to(device), px.to(device)] = Lh.to(device)
+        R[py.to(device), px.to(device)] = Rh.to(device)
     blend = make_blend(cols, rows, device)
     return L, R, blend, None
 
 
 def make_blend(cols, rows, device="cpu"):
-    """Horizontal ramp 0->1 across the valid region, box-smoothed (width cols/32)."""
+    """Horizontal ramp 0->1 across the valid region, box-smoothed (width cols/32).  The one row is always computed on the host
+    (a device's parallel prefix sum rounds differently) and expanded on the device."""
+    out_device = device
+    device = "cpu"
     band = cols // 16
     x = torch.arange(cols, dtype=torch.float64, device=device)
     ramp = torch.clamp((x - band) / max(1.0, float(cols - 2 * band - 1)), 0.0, 1.0)
@@ -99,7 +145,7 @@ def make_blend(cols, rows, device="cpu"):
     rp = torch.cat([ramp[:1].expand(pad), ramp, ramp[-1:].expand(pad)])
     cs = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.float64, device=device), rp]), 0)
     sm = (cs[k:] - cs[:-k]) / k
-    return sm.to(torch.float32)[None, :].expand(rows, cols).contiguous()
+    return sm.to(torch.float32).to(out_device)[None, :].expand(rows, cols).contiguous()
 
 
 def ground_truth_flow(cols, rows, device="cpu", disp_scale=1.0):

@@ -5,7 +5,13 @@
 // into rank 0's HBM: grouped ncclSend/ncclRecv on the gather stream (pf_dist_gather_async), double-buffered so that the
 // gather of round j overlaps the compute of round j+1.  Host code is C++ over the C ABI; no Python, no torch.
 //
-//   pano_batch -pairs 8 -size 9000x4000 -flow_alg pixflow_search_20 [-gpus N] [-verify 1] [-in_flight K]
+//   pano_batch -pairs 8 -size 9000x4000 -flow_alg pixflow_search_20 [-gpus N] [-verify 1] [-in_flight K] [-golden DIR]
+//
+// -golden DIR: self-validation against the oracle fixtures (BASELINE config 5).  The inputs of pair p are read from
+// DIR/pair_<1234+p>_L.bgra, _R.bgra and DIR/blend.f32 (written by tests/golden/export_dense_inputs.py: the C++ generator below cannot
+// reproduce synth.py's torch arithmetic) and, AFTER the clock has stopped, every rank recomputes each of its pairs once more, requires
+// the device checksum of the recomputed strip to equal the one recorded for the timed strip, downloads it and compares its SHA-256
+// with DIR/dense_<size>.sha256.txt (the oracle's blended strip for that seed).  "golden_pairs_ok" in the JSON line; exit code 1 on a miss.
 //
 // -in_flight K (1..8, default 1): with more pairs than GPUs, each GPU solves K of its pairs through ONE set of kernel launches per
 // round (pf_novel_view_batch_dev: the exact sweeps of a lone pair leave most of the chip idle) and sends them as one block.
@@ -19,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <unistd.h>
 #include <string>
 #include <thread>
@@ -29,7 +36,78 @@
 
 namespace {
 
-struct Args { int pairs = 8, cols = 9000, rows = 4000, gpus = 0, verify = 1, in_flight = 1; std::string alg = "pixflow_low"; };
+// ---- SHA-256 (FIPS 180-4), for -golden ----
+struct Sha256 {
+  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  uint8_t buf[64]; size_t fill = 0; uint64_t total = 0;
+  static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+  void block(const uint8_t* p) {
+    static const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe,
+        0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7,
+        0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b,
+        0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+        0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t w[64];
+    for (int i = 0; i < 16; ++i) w[i] = (uint32_t(p[4 * i]) << 24) | (uint32_t(p[4 * i + 1]) << 16) | (uint32_t(p[4 * i + 2]) << 8) | p[4 * i + 3];
+    for (int i = 16; i < 64; ++i) {
+      const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; ++i) {
+      const uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+      const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+  void update(const void* data, size_t n) {
+    const uint8_t* p = static_cast<const uint8_t*>(data);
+    total += n;
+    if (fill) { const size_t k = std::min(n, 64 - fill); memcpy(buf + fill, p, k); fill += k; p += k; n -= k; if (fill == 64) { block(buf); fill = 0; } }
+    for (; n >= 64; p += 64, n -= 64) block(p);
+    if (n) { memcpy(buf, p, n); fill = n; }
+  }
+  std::string hex() {
+    const uint64_t bits = total * 8;
+    const uint8_t one = 0x80, zero = 0;
+    update(&one, 1);
+    while (fill != 56) update(&zero, 1);
+    uint8_t len[8];
+    for (int i = 0; i < 8; ++i) len[i] = uint8_t(bits >> (56 - 8 * i));
+    update(len, 8);
+    char out[65];
+    for (int i = 0; i < 8; ++i) snprintf(out + 8 * i, 9, "%08x", h[i]);
+    return std::string(out, 64);
+  }
+};
+std::string sha256_of(const void* p, size_t n) { Sha256 s; s.update(p, n); return s.hex(); }
+
+bool read_file(const std::string& path, void* dst, size_t bytes) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  const size_t got = fread(dst, 1, bytes, f);
+  const bool more = fgetc(f) != EOF;
+  fclose(f);
+  return got == bytes && !more;
+}
+// DIR/dense_<cols>x<rows>.sha256.txt: "seed sha_L sha_R sha_blend sha_flow_l2r sha_flow_r2l sha_strip" per line ('#' = comment)
+bool golden_line(const std::string& dir, int cols, int rows, int seed, std::string sha[6]) {
+  char name[64]; snprintf(name, sizeof name, "/dense_%dx%d.sha256.txt", cols, rows);
+  FILE* f = fopen((dir + name).c_str(), "r");
+  if (!f) return false;
+  char line[1024]; bool found = false;
+  while (!found && fgets(line, sizeof line, f)) {
+    if (line[0] == '#') continue;
+    int sd = 0; char h[6][80];
+    if (sscanf(line, "%d %79s %79s %79s %79s %79s %79s", &sd, h[0], h[1], h[2], h[3], h[4], h[5]) == 7 && sd == seed) { for (int i = 0; i < 6; ++i) sha[i] = h[i]; found = true; }
+  }
+  fclose(f);
+  return found;
+}
+
+struct Args { int pairs = 8, cols = 9000, rows = 4000, gpus = 0, verify = 1, in_flight = 1; std::string alg = "pixflow_low", golden; };
 
 bool parse(int argc, char** argv, Args& a) {
   for (int i = 1; i < argc; ++i) {
@@ -46,6 +124,16 @@ bool parse(int argc, char** argv, Args& a) {
     else if (k == "gpus") a.gpus = atoi(v.c_str());
     else if (k == "verify") a.verify = atoi(v.c_str());
     else if (k == "in_flight") a.in_flight = atoi(v.c_str());
+    else if (k == "golden") a.golden = v;
+    else if (k == "sha256") {   // self-test of the SHA-256 used by -golden (tests/test_batch_plan.py): prints the digest of a file
+      FILE* f = fopen(v.c_str(), "rb");
+      if (!f) return false;
+      Sha256 h; std::vector<uint8_t> b(1 << 16); size_t n;
+      while ((n = fread(b.data(), 1, b.size(), f)) > 0) h.update(b.data(), n);
+      fclose(f);
+      printf("%s\n", h.hex().c_str());
+      exit(0);
+    }
     else return false;
   }
   return a.pairs > 0 && a.cols > 0 && a.rows > 0 && a.in_flight >= 1 && a.in_flight <= 8;
@@ -80,6 +168,7 @@ struct Shared {
   std::vector<pf_ctx*> ctx;                        // one per device, all created (and checked) before any rank enters RCCL
   std::vector<uint64_t> sum_local, sum_gathered;   // per pair: device-side checksum at its producer / at rank 0 after the gather
   std::vector<double> secs;                        // per device
+  std::vector<int> golden_ok;                      // per pair (-golden): 1 = the strip is the oracle fixture's, 0 = it is not
 };
 
 // A rank that fails after the communicator exists cannot simply return: its peers would wait for it forever inside a grouped
@@ -110,7 +199,16 @@ void worker(Shared* s, int dev) {
   {
     std::vector<uint8_t> L, R; std::vector<float> blend;
     for (size_t k = 0; k < mine.size(); ++k) {
-      make_pair(a.cols, a.rows, 1234 + mine[k], L, R, blend);
+      if (a.golden.empty()) make_pair(a.cols, a.rows, 1234 + mine[k], L, R, blend);
+      else {
+        // the fixture's inputs (written by tests/golden/export_dense_inputs.py), checked against the fixture's input hashes
+        L.resize(ib); R.resize(ib); blend.resize(n);
+        const std::string base = a.golden + "/pair_" + std::to_string(1234 + mine[k]);
+        std::string sha[6];
+        if (!read_file(base + "_L.bgra", L.data(), ib) || !read_file(base + "_R.bgra", R.data(), ib) || !read_file(a.golden + "/blend.f32", blend.data(), n * 4)) die(dev, "-golden", "input files missing or of the wrong size (tests/golden/export_dense_inputs.py writes them)");
+        if (!golden_line(a.golden, a.cols, a.rows, 1234 + mine[k], sha)) die(dev, "-golden", "no fixture line for this pair's seed");
+        if (sha256_of(L.data(), ib) != sha[0] || sha256_of(R.data(), ib) != sha[1] || sha256_of(blend.data(), n * 4) != sha[2]) die(dev, "-golden", "the input files are not the fixture's inputs");
+      }
       void* l = pf_dev_alloc(ctx, ib); void* r = pf_dev_alloc(ctx, ib);
       if (!l || !r || pf_upload(ctx, l, L.data(), ib) || pf_upload(ctx, r, R.data(), ib)) die(dev, "upload", pf_last_error(ctx));
       dL[k] = static_cast<const uint8_t*>(l); dR[k] = static_cast<const uint8_t*>(r);
@@ -158,6 +256,18 @@ void worker(Shared* s, int dev) {
   s->secs[dev] = dt;
   if (pf_dist_max(dist, &dt)) die(dev, "max", pf_dist_last_error(dist));
   if (dev == 0) s->secs[0] = dt;   // the job's time: the slowest rank's
+  if (!a.golden.empty() && a.verify) {
+    // off the clock: recompute each of my pairs once more; same device checksum as the timed strip + the fixture's SHA-256 = the timed
+    // strip was the oracle's
+    std::vector<uint8_t> host(ib);
+    for (size_t k = 0; k < mine.size(); ++k) {
+      const int p = mine[k];
+      uint64_t sum = 0; std::string sha[6];
+      if (pf_novel_view_dev(ctx, dL[k], dR[k], a.cols, a.rows, s->max_pct, static_cast<const float*>(dBlend), static_cast<uint8_t*>(dOut[0]), nullptr, nullptr)) die(dev, "pf_novel_view", pf_last_error(ctx));
+      if (pf_checksum_dev(ctx, dOut[0], ib, &sum) || pf_download(ctx, host.data(), dOut[0], ib)) die(dev, "golden check", pf_last_error(ctx));
+      s->golden_ok[p] = golden_line(a.golden, a.cols, a.rows, 1234 + p, sha) && sum == s->sum_local[p] && sha256_of(host.data(), ib) == sha[5];
+    }
+  }
   pf_dist_destroy(dist);
   for (const uint8_t* p : dL) pf_dev_free(ctx, const_cast<uint8_t*>(p));
   for (const uint8_t* p : dR) pf_dev_free(ctx, const_cast<uint8_t*>(p));
@@ -176,7 +286,8 @@ int main(int argc, char** argv) {
   s.ndev = s.a.gpus > 0 ? s.a.gpus : have;
   if (s.ndev > have) { fprintf(stderr, "%d GPUs requested, %d present\n", s.ndev, have); return 1; }
   if (pf_dist_unique_id(s.id)) { fprintf(stderr, "%s\n", pf_dist_last_error(nullptr)); return 1; }
-  s.sum_local.assign(s.a.pairs, 0); s.sum_gathered.assign(s.a.pairs, 0); s.secs.assign(s.ndev, 0.0);
+  s.sum_local.assign(s.a.pairs, 0); s.sum_gathered.assign(s.a.pairs, 0); s.secs.assign(s.ndev, 0.0); s.golden_ok.assign(s.a.pairs, 0);
+  if (!s.a.golden.empty() && s.max_pct != 0) { fprintf(stderr, "-golden: the fixtures are pixflow_low solves\n"); return 2; }
   // every context first: a GPU that cannot be used is reported before any rank enters ncclCommInitRank (where the others would hang)
   s.ctx.assign(s.ndev, nullptr);
   for (int d = 0; d < s.ndev; ++d) {
@@ -193,8 +304,10 @@ int main(int argc, char** argv) {
   for (pf_ctx* c : s.ctx) pf_destroy(c);
   int bad = 0;
   if (s.a.verify) for (int p = 0; p < s.a.pairs; ++p) if (!s.sum_local[p] || s.sum_local[p] != s.sum_gathered[p]) { fprintf(stderr, "pair %d: gathered strip differs from its producer's\n", p); ++bad; }
+  int golden = -1;
+  if (!s.a.golden.empty() && s.a.verify) { golden = 0; for (int p = 0; p < s.a.pairs; ++p) golden += s.golden_ok[p]; if (golden != s.a.pairs) { fprintf(stderr, "-golden: %d of %d strips are the oracle fixture's\n", golden, s.a.pairs); ++bad; } }
   const double mpix = double(s.a.cols) * s.a.rows * s.a.pairs / 1e6;
-  printf("{\"tool\": \"pano_batch\", \"gpus\": %d, \"in_flight_per_gpu\": %d, \"pairs\": %d, \"size\": \"%dx%d\", \"flow_alg\": \"%s\", \"seconds\": %.4f, \"Mpix/s\": %.2f, \"verified_pairs\": %d, \"verification\": \"%s\", \"gather\": \"rccl send/recv to rank 0, overlapped\"}\n",
-         s.ndev, s.a.in_flight, s.a.pairs, s.a.cols, s.a.rows, s.a.alg.c_str(), s.secs[0], mpix / s.secs[0], s.a.verify ? s.a.pairs - bad : 0, s.a.verify ? "device-side checksums (pf_checksum_dev), no host copies inside the clock" : "off");
+  printf("{\"tool\": \"pano_batch\", \"gpus\": %d, \"in_flight_per_gpu\": %d, \"pairs\": %d, \"size\": \"%dx%d\", \"flow_alg\": \"%s\", \"seconds\": %.4f, \"Mpix/s\": %.2f, \"verified_pairs\": %d, \"verification\": \"%s\", \"golden_pairs_ok\": %d, \"gather\": \"rccl send/recv to rank 0, overlapped\"}\n",
+         s.ndev, s.a.in_flight, s.a.pairs, s.a.cols, s.a.rows, s.a.alg.c_str(), s.secs[0], mpix / s.secs[0], s.a.verify ? s.a.pairs - bad : 0, s.a.verify ? "device-side checksums (pf_checksum_dev), no host copies inside the clock" : "off", golden);
   return bad ? 1 : 0;
 }

@@ -45,7 +45,24 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def write_sidecar(cols=9000, rows=4000):
+    """dense_<cols>x<rows>.sha256.txt: the fixtures' hashes as plain text (one line per seed), for the C++ driver (pano_batch -golden)."""
+    import glob
+    rowsf = []
+    for f in glob.glob(os.path.join(HERE, "dense_%dx%d*.npz" % (cols, rows))):
+        g = np.load(f)
+        rowsf.append((int(g["seed"]), [str(v) for v in g["sha_inputs"]] + [str(v) for v in g["sha_outputs"]]))
+    with open(os.path.join(HERE, "dense_%dx%d.sha256.txt" % (cols, rows)), "w") as o:
+        o.write("# BASELINE config 5 (8 dense 9000x4000 pairs, seeds 1234..1241, pixflow_low): SHA-256 of the synthetic inputs (L, R, blend ramp) and of the\n"
+                "# oracle's outputs (flow L->R, flow R->L, blended strip), copied from dense_9000x4000[_s<seed>].npz by tests/golden/make_dense_golden.py --sidecar\n"
+                "# (plain text so that the C++ driver can read it: pano_batch -golden <dir>).  seed  sha_L sha_R sha_blend  sha_flow_l2r sha_flow_r2l sha_strip\n")
+        for seed, sh in sorted(rowsf):
+            o.write("%d %s\n" % (seed, " ".join(sh)))
+
+
 def main():
+    if "--sidecar" in sys.argv:
+        return write_sidecar()
     cols, rows = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (9000, 4000)
     max_pct = {"pixflow_low": 0, "pixflow_search_20": 20}[sys.argv[3] if len(sys.argv) > 3 else "pixflow_low"]
     seed = int(sys.argv[4]) if len(sys.argv) > 4 else SEED

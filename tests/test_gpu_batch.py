@@ -47,3 +47,42 @@ def test_pf_dist_self_gather_and_max(pf):
     assert d.max(3.5) == 3.5
     d.barrier()
     d.close(); c.dev_free(a); c.dev_free(b); c.close()
+
+
+def test_pano_batch_golden_self_validation(tmp_path):
+    """pano_batch -golden: the C++ driver reads the fixture's inputs (exported by tests/golden/export_dense_inputs.py, generated on this
+    GPU: synth.py gives the host's bytes on any device), and after the clock requires every strip to be the ORACLE's (SHA-256 from
+    tests/golden/dense_9000x4000.sha256.txt) -- what makes a multi-GPU run of config 5 trustworthy without Python."""
+    import sys
+    from conftest import ROOT
+    d = str(tmp_path / "golden_in")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "export_dense_inputs.py"), d, "2"], check=True, timeout=600)
+    exe = os.path.join(PKG, "tools", "pano_batch")
+    r = subprocess.run([exe, "-pairs", "2", "-size", "9000x4000", "-flow_alg", "pixflow_low", "-gpus", "1", "-golden", d], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["pairs"] == 2 and res["verified_pairs"] == 2 and res["golden_pairs_ok"] == 2
+    # a wrong input file is refused, not silently benchmarked
+    with open(os.path.join(d, "pair_1235_R.bgra"), "r+b") as f:
+        f.seek(12345); f.write(b"\x07")
+    r = subprocess.run([exe, "-pairs", "2", "-size", "9000x4000", "-flow_alg", "pixflow_low", "-gpus", "1", "-golden", d], capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0 and "not the fixture's inputs" in r.stderr
+
+
+def test_bench_forced_dist_path_validates_itself():
+    """PANOFLOW_FORCE_DIST=1 on one GPU takes bench.py's multi-rank path (RCCL self-gather inside libpanoflow.so, all-reduced fixture
+    verdict): same keys as the single-rank line, fixture_ok true, the gathered slot equal to the oracle fixture's strip."""
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    lines = {}
+    for force in ("0", "1"):
+        e = dict(env, PANOFLOW_FORCE_DIST=force)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=e)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        lines[force] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    a, b = lines["0"], lines["1"]
+    assert set(a) == set(b), set(a) ^ set(b)
+    assert a["fixture_ok"] is True and b["fixture_ok"] is True
+    assert "pf_dist_" in b["config"]["final_gather"] and "every rank's slot equals its oracle fixture's strip: True" in b["config"]["final_gather"]
+    assert b["value"] > 0.8 * a["value"]
