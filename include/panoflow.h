@@ -76,6 +76,10 @@ typedef struct pf_config {
   int record_path;          /* 0: k_sweep_prep in front of the sweep; 1: loader waves compute the records; 2: prepass blocks inside the sweep launch */
 } pf_config;
 void pf_config_init(pf_config* cfg);
+/* Self-test that pf_create already ran once for the context's device: the sweep's asm-block packed-fp32 chains against the
+ * compiler-scheduled forms of the same arithmetic.  0 = identical bits (or a -DPF_SAFE_PK build, which has no such blocks);
+ * > 0 = threads whose results differed (pf_create would have refused the device); < 0 = error code. */
+int pf_selftest_packed_chains(pf_ctx* ctx);
 pf_ctx* pf_create_cfg(const pf_config* cfg);
 void pf_destroy(pf_ctx* ctx);
 const char* pf_last_error(const pf_ctx* ctx);  /* ctx may be NULL (creation errors) */

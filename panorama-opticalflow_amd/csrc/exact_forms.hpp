@@ -4,6 +4,16 @@
 #include <hip/hip_runtime.h>
 namespace pf {
 typedef float f2p __attribute__((ext_vector_type(2)));
+// PF_PK_ASM: the serial packed-fp32 chains as single inline-asm blocks (below).  That form makes an assumption about the HARDWARE
+// (no wait state between a v_pk_*_f32 and a VALU instruction that reads its result), so it only exists for the one target it was
+// established on -- gfx950 -- and only where the probe vouches for it: pf_create runs a short form of tests/micro/pk_hazard_probe.hip
+// on the device and refuses to create a context on a mismatch.  Everywhere else, and with -DPF_SAFE_PK, the same arithmetic is plain
+// packed-vector C++: the compiler emits the sequences with its own wait states (identical bits, 3 more issue slots per step).
+#if defined(__gfx950__) && !defined(PF_SAFE_PK)
+#define PF_PK_ASM 1
+#else
+#define PF_PK_ASM 0
+#endif
 // ---- chains of packed fp32 instructions as ONE inline-asm block ----------------------------------------------
 // The compiler (ROCm 7.2 LLVM) separates every v_pk_*_f32 from an immediately dependent VALU instruction with an s_nop:
 // its "dst_sel forwarding hazard" test reads bit 3 of src0_modifiers, which is DST_OP_SEL for VOP3 but op_sel_hi[0] for
@@ -60,7 +70,23 @@ __device__ __forceinline__ f2p div_core2(f2p a, float c, float y) {
 // (tests/micro/sqrt_exhaust.hip, run by tests/test_gpu_exact_forms.py).
 // Also returns frexp_exp(x.x) (the callers' range guard wants it): it is the independent instruction that fills the wait
 // state a VALU instruction needs after the v_rsq_f32 whose result it reads.
+// the eight operations as plain packed-vector C++: the compiler schedules them and inserts its wait states
+__device__ __forceinline__ f2p sqrt_core2_safe(f2p x, int& exp_x0) {
+  const f2p xt = x + f2p{0x1p-126f, 0x1p-126f};
+  const f2p r = {__builtin_amdgcn_rsqf(xt.x), __builtin_amdgcn_rsqf(xt.y)};
+  const f2p half = {0.5f, 0.5f};
+  exp_x0 = __builtin_amdgcn_frexp_expf(x.x);
+  f2p s = x * r, h = r * half;
+  const f2p e = __builtin_elementwise_fma(-h, s, half);
+  h = __builtin_elementwise_fma(h, e, h);
+  s = __builtin_elementwise_fma(s, e, s);
+  const f2p d = __builtin_elementwise_fma(-s, s, x);
+  return __builtin_elementwise_fma(d, h, s);
+}
 __device__ __forceinline__ f2p sqrt_core2(f2p x, int& exp_x0) {
+#if !PF_PK_ASM
+  return sqrt_core2_safe(x, exp_x0);
+#else
   const f2p xt = x + f2p{0x1p-126f, 0x1p-126f};
   const f2p r = {__builtin_amdgcn_rsqf(xt.x), __builtin_amdgcn_rsqf(xt.y)};
   f2p s, h, e, out;
@@ -75,5 +101,6 @@ __device__ __forceinline__ f2p sqrt_core2(f2p x, int& exp_x0) {
       "v_pk_fma_f32 %3, %2, %1, %0"                      // s + d * h, correctly rounded
       : "=&v"(s), "=&v"(h), "=&v"(e), "=&v"(out), "=&v"(exp_x0) : "v"(x), "v"(r), "v"(x0));
   return out;
+#endif
 }
 }  // namespace pf

@@ -263,7 +263,11 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
     i1y = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
   }
   f2p di, di2;   // (i0 - i1)^2 per channel: one asm block, see exact_forms.hpp
+#if PF_PK_ASM
   asm("v_pk_add_f32 %0, %2, %3 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_mul_f32 %1, %0, %0" : "=&v"(di), "=&v"(di2) : "v"(f2p{i0x, i0y}), "v"(f2p{i1x, i1y}));
+#else
+  di = f2p{i0x, i0y} - f2p{i1x, i1y}; di2 = di * di;
+#endif
   float d2 = di2.x + di2.y;
   asm volatile("" : "+v"(d2));   // a scalar add into the register next to s2 (not a packed add + a move of s2)
   vmax = __builtin_fmaxf(vmax, d2);
@@ -1244,6 +1248,55 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
       if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Load-time gate of the asm-block packed chains (exact_forms.hpp, PF_PK_ASM): the product's own two blocks -- the packed square-root
+// sequence and (i0 - i1)^2 -- against the compiler-scheduled forms of the same arithmetic, dependent chains of them back to back,
+// from one wave per CU up to 16 waves per SIMD.  pf_create runs it once per device and process (~0.1 ms) and refuses to create a
+// context if a single bit differs: the assumption "a v_pk_*_f32 result may be read by the next instruction" is then checked on the
+// very chip the library runs on, not only on the one the round-3 probe (tests/micro/pk_hazard_probe.hip) ran on.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_pk_probe(int rounds, unsigned* __restrict__ bad) {
+  unsigned s = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s; };
+  // operands inside the range guard: 2^-90 .. 2^90, both signs for the difference
+  auto val = [&]() { const unsigned u = rnd(); return __uint_as_float((u & 0x007fffffu) | ((37u + (u >> 23) % 180u) << 23)); };
+  float a = val(), b = val();
+  unsigned diff = 0;
+  for (int r = 0; r < rounds; ++r) {
+    const float c = val(), d = val();
+    int e0, e1;
+    const f2p q = sqrt_core2(f2p{a, b}, e0), qs = sqrt_core2_safe(f2p{a, b}, e1);
+    f2p di, di2;
+#if PF_PK_ASM
+    asm("v_pk_add_f32 %0, %2, %3 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_mul_f32 %1, %0, %0" : "=&v"(di), "=&v"(di2) : "v"(f2p{c, q.x}), "v"(f2p{q.y, d}));
+#else
+    di = f2p{c, q.x} - f2p{q.y, d}; di2 = di * di;
+#endif
+    const f2p ds = f2p{c, qs.x} - f2p{qs.y, d}, ds2 = ds * ds;
+    diff |= (__float_as_uint(q.x) ^ __float_as_uint(qs.x)) | (__float_as_uint(q.y) ^ __float_as_uint(qs.y)) | unsigned(e0 ^ e1) |
+            (__float_as_uint(di2.x) ^ __float_as_uint(ds2.x)) | (__float_as_uint(di2.y) ^ __float_as_uint(ds2.y));
+    // the next operands depend on this round's results (a dependent chain, like a sweep step), folded back into the guard's range
+    const unsigned ua = __float_as_uint(di2.x), ub = __float_as_uint(q.y);
+    a = __uint_as_float((ua & 0x007fffffu) | ((37u + ((ua >> 23) & 0xffu) % 180u) << 23));
+    b = __uint_as_float((ub & 0x007fffffu) | ((37u + ((ub >> 23) & 0xffu) % 180u) << 23));
+  }
+  if (diff) atomicAdd(bad, 1u);
+}
+// 0 = the asm-block forms and the compiler-scheduled forms agree bit for bit on this device (or the build has no asm blocks); bad = scratch word on the device
+int sweep_pk_probe(hipStream_t st, unsigned* bad) {
+#if defined(PF_SAFE_PK)
+  (void)st; (void)bad;
+  return 0;
+#else
+  if (hipMemsetAsync(bad, 0, 4, st) != hipSuccess) return -1;
+  hipLaunchKernelGGL(k_pk_probe, dim3(256), dim3(64), 0, st, 256, bad);          // one wave per CU
+  hipLaunchKernelGGL(k_pk_probe, dim3(256 * 4), dim3(1024), 0, st, 24, bad);      // 16 waves per SIMD
+  unsigned h = 1;
+  if (hipMemcpyAsync(&h, bad, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+  return int(h);
+#endif
 }
 
 // ---- host side ----

@@ -724,6 +724,28 @@ pf_ctx* create_ctx(const pf_config& cfg, bool lane) {
   if (ok) { *c->h_status = 0; memset(c->h_gate, 0, kMaxBatch * kGateWords * sizeof(int)); }
   if (!ok) { fail(nullptr, PF_ERR_DEVICE, "stream/event creation failed"); delete c; return nullptr; }
   c->cfg = cfg;
+  {
+    // Once per device and process: the sweep's asm-block packed chains (csrc/exact_forms.hpp) against the compiler-scheduled forms
+    // of the same arithmetic, on THIS device.  A mismatch means the hardware assumption behind them does not hold here: refuse,
+    // rather than compute wrong flows (a -DPF_SAFE_PK build has no such blocks and passes trivially).
+    static std::mutex probe_mu;
+    static std::map<int, int> probe_result;
+    std::lock_guard<std::mutex> lk(probe_mu);
+    auto it = probe_result.find(device);
+    if (it == probe_result.end()) {
+      unsigned* scratch = nullptr;
+      int r = -1;
+      if (hipMalloc((void**)&scratch, 256) == hipSuccess) { r = sweep_pk_probe(c->s_main, scratch); hipFree(scratch); }
+      it = probe_result.emplace(device, r).first;
+    }
+    if (it->second != 0) {
+      fail(nullptr, PF_ERR_DEVICE, it->second < 0 ? "the packed-fp32 probe could not run on device %d"
+                                                   : "device %d: the sweep's asm-block packed-fp32 chains do not reproduce the compiler-scheduled forms (%d threads differ); rebuild with -DPF_SAFE_PK",
+           device, it->second);
+      pf_destroy(c);
+      return nullptr;
+    }
+  }
   c->g5 = make_gauss(5, 0.25); c->g3_05 = make_gauss(3, 0.5); c->g3_1 = make_gauss(3, 1.0); c->g15 = make_gauss(15, 8.0);
   // Pre-sizing: every buffer a bidirectional solve / a stitch step on max_cols x max_rows needs is
   // allocated now, so that the first call does not pay ~40 hipMallocs.  0 x 0 = allocate lazily (the arena only grows).
@@ -838,6 +860,13 @@ int pf_download(pf_ctx* c, void* dst, const void* src, size_t bytes) {
   return 0;
 }
 int pf_sync(pf_ctx* c) { if (int e = use(c)) return e; return finish(c); }
+int pf_selftest_packed_chains(pf_ctx* c) {
+  if (int e = use(c)) return e;
+  unsigned* scratch = (unsigned*)ensure(c, "pk_probe", 256);
+  if (!scratch) return PF_ERR_NOMEM;
+  const int r = sweep_pk_probe(c->s_main, scratch);
+  return r < 0 ? fail(c, PF_ERR_DEVICE, "the packed-fp32 probe could not run") : r;
+}
 // 64-bit content checksum of `bytes` bytes at d_ptr (8-byte aligned), computed on the device: results that live in HBM -- on this
 // GPU or gathered from others -- are compared without a trip through the host.  ~25 us per 144 MB strip.
 int pf_checksum_dev(pf_ctx* c, const void* d_ptr, size_t bytes, uint64_t* out) {

@@ -149,6 +149,7 @@ int sweep2_num_wgs(int H);
 int sweep2_num_wgs_max(int W, int H);          // workgroups a sweep launch on a W x H level can have (either band orientation)
 size_t sweep2_boundary_elems(int W, int H);   // granules one sweep launch may need (either band orientation)
 size_t sweep2_rec_bytes(int W, int H);
+int sweep_pk_probe(hipStream_t st, unsigned* d_scratch);   // 0 = the sweep's asm-block packed chains give the compiler forms' bits on this device; > 0 mismatching threads; < 0 HIP error
 bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec);  // v2: prepass + 8 lanes/pixel + helper waves; false = empty window, nothing launched
 size_t sweep_relax_boundary_elems(int W, int H);
 bool launch_sweep_relax(hipStream_t st, const SweepArgs& a);   // lab build only (pf_config::sweep_impl = 3): event-driven relaxation on LDS-resident tiles, kernels_relax.inl

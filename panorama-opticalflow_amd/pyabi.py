@@ -82,7 +82,7 @@ def lib(exp=False):
 EXPORTS = [
     "pf_device_count", "pf_create", "pf_config_init", "pf_create_cfg", "pf_destroy", "pf_last_error", "pf_version", "pf_max_percentage_by_name",
     "pf_flow", "pf_flow_bidir", "pf_blend", "pf_novel_view", "pf_stitch_prepare", "pf_stitch_match", "pf_stitch_generate_blend", "pf_stitch_raw_blend", "pf_stitch_gather", "pf_stitch_step", "pf_stitch_prefetch",
-    "pf_dev_alloc", "pf_dev_free", "pf_host_alloc", "pf_host_free", "pf_upload", "pf_download", "pf_sync", "pf_checksum_dev",
+    "pf_dev_alloc", "pf_dev_free", "pf_host_alloc", "pf_host_free", "pf_upload", "pf_download", "pf_sync", "pf_checksum_dev", "pf_selftest_packed_chains",
     "pf_flow_bidir_dev", "pf_blend_dev", "pf_novel_view_dev", "pf_novel_view_batch_dev",
     "pf_stage_preprocess", "pf_stage_pyr_down", "pf_stage_gradients", "pf_stage_gauss", "pf_stage_median5", "pf_stage_sweep",
     "pf_stage_diffusion", "pf_stage_upsample_cubic", "pf_stage_final", "pf_stage_adjust_initial_flow", "pf_stage_level",
@@ -298,6 +298,14 @@ class Context:
         if not p:
             raise PanoflowError(self.l.pf_last_error(self.h).decode())
         return p
+
+    def selftest_packed_chains(self):
+        """0 = the sweep's asm-block packed-fp32 chains give the compiler-scheduled forms' bits on this device"""
+        self.l.pf_selftest_packed_chains.argtypes = [C.c_void_p]
+        r = self.l.pf_selftest_packed_chains(self.h)
+        if r < 0:
+            self._chk(r)
+        return r
 
     def dev_free(self, p):
         self.l.pf_dev_free(self.h, C.c_void_p(p))

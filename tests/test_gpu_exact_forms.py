@@ -9,11 +9,14 @@ import subprocess
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-BIN = os.path.join(HERE, "..", "panorama-opticalflow_amd", "tools", "exact_forms_check")
+BIN0 = os.path.join(HERE, "..", "panorama-opticalflow_amd", "tools", "exact_forms_check")
 
 
 @pytest.mark.gpu
-def test_exact_forms_exhaustive():
+@pytest.mark.parametrize("which", ["", "_safe"])
+def test_exact_forms_exhaustive(which):
+    """"" = the product's forms (asm-block packed chains), "_safe" = the compiler-scheduled forms of -DPF_SAFE_PK (the lab build's)"""
+    BIN = BIN0 + which
     assert os.path.exists(BIN), "build first: python -c 'import __graft_entry__ as g; g.build()'"
     r = subprocess.run([BIN], capture_output=True, text=True, timeout=600)
     print(r.stdout)

@@ -152,11 +152,26 @@ def test_sweep_v1_kernel_cross_check(pf, orc):
     a = np.ones((h, w), np.float32); a[50:60, 30:90] = 0.2
     c1 = pf.Context(0, exp=True, sweep_impl=1)     # the v1 kernel only exists in the lab build (libpanoflow_exp.so)
     c2 = pf.Context(0)
+    c3 = pf.Context(0, exp=True)                   # the lab build's v2 sweep: -DPF_SAFE_PK, the packed chains as compiler-scheduled code
     for fwd in (1, 0):
         ref = orc.sweep(g0[..., 0], g0[..., 1], g1[..., 0], g1[..., 1], blurred, a, a, flow, fwd)
         assert np.array_equal(c1.stage_sweep(g0, g1, blurred, a, a, flow, fwd), ref)
         assert np.array_equal(c2.stage_sweep(g0, g1, blurred, a, a, flow, fwd), ref)
-    c1.close(); c2.close()
+        assert np.array_equal(c3.stage_sweep(g0, g1, blurred, a, a, flow, fwd), ref)
+    c1.close(); c2.close(); c3.close()
+
+
+def test_asm_block_packed_chains_equal_the_safe_build(pf, synth):
+    """The product's sweep issues its serial packed-fp32 chains as asm blocks without the compiler's wait states (csrc/exact_forms.hpp);
+    the lab build (-DPF_SAFE_PK) compiles the same arithmetic as plain packed-vector C++.  A whole bidirectional solve must give the
+    same bits from both, and the load-time probe (run by pf_create for every device, here once more) must report no mismatch."""
+    L, R, blend = synth.make_pair_np(700, 520, 31)
+    prod = pf.Context(0); safe = pf.Context(0, exp=True)
+    assert prod.selftest_packed_chains() == 0 and safe.selftest_packed_chains() == 0
+    o0, a0, b0 = prod.novel_view(L, R, 20, blend)
+    o1, a1, b1 = safe.novel_view(L, R, 20, blend)
+    assert np.array_equal(a0, a1) and np.array_equal(b0, b1) and np.array_equal(o0, o1)
+    prod.close(); safe.close()
 
 
 @pytest.mark.parametrize("w,h", [(140, 100), (100, 140)])
