@@ -111,6 +111,10 @@ int pf_novel_view(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, int
                   int max_percentage, const float* blend, size_t blend_step_bytes, uint8_t* out_bgra, size_t out_step_bytes,
                   float* flow_l2r, float* flow_r2l, size_t flow_step_bytes);
 
+/* Size limit of the three stitch entry points that build the blend ramp (pf_stitch_prepare, pf_stitch_generate_blend, pf_stitch_step):
+ * the tile smoothing of GenerateBlend (CPU/StitchTool.cpp:130-143) keeps one tile's window, (step + k - 1)^2 floats + (step + k - 1) x step
+ * doubles with step = min(cols, rows) / 200 and k = rows / 130, in the 160 KB of LDS of a CU: canvases up to ~15,000 rows (a 30000x15000
+ * equirectangular panorama) -- beyond that they return PF_ERR_ARG.  The solver and blend entry points have no such limit. */
 /* Stitchtools::prepare, CPU/StitchTool.cpp:7-36 (MatchImages :38-50, GenerateBlend :98-146,
  * countblend :148-191).  merged_dis may be NULL.  All planes cols x rows, packed rows of `step`. */
 int pf_stitch_prepare(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, int cols, int rows, size_t step_bytes,

@@ -13,7 +13,7 @@ namespace pf {
 __global__ __launch_bounds__(256) void k_intensity_ratio(const float* __restrict__ i0, const float* __restrict__ i1, const float* __restrict__ a0,
                                                          const float* __restrict__ a1, int n, float* __restrict__ ratio, size_t bstride) {
   { const size_t bo = size_t(blockIdx.z) * bstride; PF_BOFF(i0, bo); PF_BOFF(i1, bo); PF_BOFF(a0, bo); PF_BOFF(a1, bo); PF_BOFF(ratio, bo); }
-  __shared__ float pl[1024], pr[1024];
+  __shared__ __attribute__((aligned(16))) float pl[1024], pr[1024];
   float sumL = 0.f, sumR = 0.f;
   for (int base = 0; base < n; base += 1024) {
     for (int i = threadIdx.x; i < 1024 && base + i < n; i += blockDim.x) {
@@ -23,58 +23,96 @@ __global__ __launch_bounds__(256) void k_intensity_ratio(const float* __restrict
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+      // ONE lane adds in the reference's order; eight products of each plane are fetched per step (two 16-byte LDS reads each), so
+      // that what paces the loop is the chain of dependent additions (two independent chains side by side), not LDS round trips
       const int m = (n - base) < 1024 ? (n - base) : 1024;
-      for (int i = 0; i < m; ++i) { sumL += pl[i]; sumR += pr[i]; }
+      int i = 0;
+      for (; i + 8 <= m; i += 8) {
+        const float4 l0 = *reinterpret_cast<const float4*>(&pl[i]), l1 = *reinterpret_cast<const float4*>(&pl[i + 4]);
+        const float4 r0 = *reinterpret_cast<const float4*>(&pr[i]), r1 = *reinterpret_cast<const float4*>(&pr[i + 4]);
+        sumL += l0.x; sumR += r0.x; sumL += l0.y; sumR += r0.y; sumL += l0.z; sumR += r0.z; sumL += l0.w; sumR += r0.w;
+        sumL += l1.x; sumR += r1.x; sumL += l1.y; sumR += r1.y; sumL += l1.z; sumR += r1.z; sumL += l1.w; sumR += r1.w;
+      }
+      for (; i < m; ++i) { sumL += pl[i]; sumR += pr[i]; }
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) *ratio = sumL / sumR;
 }
 
-// computePatchError (PixFlow.hpp:157-188); I1 is equalised on the fly: I1eq = I1*ratio + 0 ([OpenCV] Mat*scalar)
-__device__ __forceinline__ float d_patch_error(const float* __restrict__ i0, const float* __restrict__ a0, int i0x, int i0y, const float* __restrict__ i1,
-                                               const float* __restrict__ a1, int i1x, int i1y, int w, int h, float ratio, int dist) {
+// computePatchError (PixFlow.hpp:157-188) on LDS tiles.  A block owns a segment of 64 pixels of one row; everything its 19 candidates x 25
+// taps read is staged once: rows y-2 .. y+2 of I0 and alpha0 (out-of-image taps are SKIPPED by the reference, so the bounds test stays
+// with the tap), and the window of the equalised I1 = I1 * ratio + 0 ([OpenCV] Mat * scalar, PixFlow.hpp:235) and of alpha1 that the 5x5
+// patch sweeps while it slides over the search box, with the reference's clamped coordinates applied at staging time (a clamped tap of
+// candidate (i1x, i1y) is the texel at the clamped ABSOLUTE coordinate, whichever candidate asks).  The sums keep the reference's tap
+// order (dy outer, dx inner, sequential fp32), so the bits are the same; round 3 read every tap from global memory -- 4 dependent-latency
+// loads x 475 taps per pixel, ~130 us per launch for <= 1.8 k pixels -- which this brings to ~10 us.
+struct PatchTiles {
+  const float* i0; const float* a0;   // [5][kSegW + 4]: rows y-2 .. y+2, columns x0-2 .. x0+kSegW+1 (unclamped: taps outside the image are skipped)
+  const float* i1; const float* a1;   // [th][tw]: rows y-2+by .. , columns x0-2+bx .. (clamped coordinates)
+  int tw;
+};
+constexpr int kSegW = 64;
+__device__ __forceinline__ float d_patch_error_lds(const PatchTiles& t, int lx, int i0x, int i0y, int ox, int oy, int w, int h, int dist) {
+  // (ox, oy) = candidate offset relative to the box origin: its taps are t.i1[(oy + dy + 2) * tw + lx + ox + dx + 2]
   float sad = 0.f, alpha = 0.f;
+#pragma unroll
   for (int dy = -2; dy <= 2; ++dy) {
     const int d0y = i0y + dy;
-    if (0 <= d0y && d0y < h) {
-      const int d1y = d_replicate(i1y + dy, h);
-      for (int dx = -2; dx <= 2; ++dx) {
-        const int d0x = i0x + dx;
-        if (0 <= d0x && d0x < w) {
-          const int d1x = d_replicate(i1x + dx, w);
-          const float i1eq = i1[size_t(d1y) * w + d1x] * ratio + 0.0f;
-          const float difference = i0[size_t(d0y) * w + d0x] - i1eq;
-          sad += fabsf(difference);
-          alpha += a0[size_t(d0y) * w + d0x] * a1[size_t(d1y) * w + d1x];
-        }
-      }
+    const bool rowIn = 0 <= d0y && d0y < h;
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) {
+      const int d0x = i0x + dx;
+      const bool in = rowIn && 0 <= d0x && d0x < w;
+      const int k0 = (dy + 2) * (kSegW + 4) + lx + dx + 2, k1 = (oy + dy + 2) * t.tw + lx + ox + dx + 2;
+      const float difference = t.i0[k0] - t.i1[k1];
+      const float s1 = sad + fabsf(difference), a1 = alpha + t.a0[k0] * t.a1[k1];
+      sad = in ? s1 : sad; alpha = in ? a1 : alpha;   // a skipped tap leaves both sums untouched, as in the reference's loop
     }
   }
-  sad /= alpha;
-  const float fx = float(i1x - i0x), fy = float(i1y - i0y);
-  const float length = (float)sqrt((double)fx * fx + (double)fy * fy);
-  sad *= 1 + length / dist;
-  return sad;
+  return sad / alpha;
+}
+__device__ __forceinline__ float d_patch_penalty(float sad, int fxI, int fyI, int dist) {
+  const float fx = float(fxI), fy = float(fyI);
+  const float length = (float)sqrt((double)fx * fx + (double)fy * fy);   // [OpenCV] cv::norm(Point2f): sqrt in double
+  return sad * (1 + length / dist);
 }
 
 // adjustInitialFlow (PixFlow.hpp:226-270)
-__global__ __launch_bounds__(64) void k_adjust_initial_flow(const float* __restrict__ i0, const float* __restrict__ i1, const float* __restrict__ a0,
-                                                            const float* __restrict__ a1, int w, int h, int bx, int by, int bw, int bh, int dist,
-                                                            const float* __restrict__ ratio_p, float2* __restrict__ flow, size_t bstride) {
-  const int i0x = blockIdx.x * blockDim.x + threadIdx.x, i0y = blockIdx.y;
-  if (i0x >= w) return;
+__global__ __launch_bounds__(kSegW) void k_adjust_initial_flow(const float* __restrict__ i0, const float* __restrict__ i1, const float* __restrict__ a0,
+                                                               const float* __restrict__ a1, int w, int h, int bx, int by, int bw, int bh, int dist,
+                                                               const float* __restrict__ ratio_p, float2* __restrict__ flow, size_t bstride) {
   { const size_t bo = size_t(blockIdx.z) * bstride; PF_BOFF(i0, bo); PF_BOFF(i1, bo); PF_BOFF(a0, bo); PF_BOFF(a1, bo); PF_BOFF(ratio_p, bo); PF_BOFF(flow, bo); }
-  if (!(a0[size_t(i0y) * w + i0x] > kUpdateAlphaThreshold)) return;
+  extern __shared__ float lds[];
+  const int x0 = blockIdx.x * kSegW, i0y = blockIdx.y, lx = threadIdx.x, i0x = x0 + lx;
+  const int tw = kSegW + 4 + (bw - 1), th = 5 + (bh - 1);
+  float* t_i0 = lds; float* t_a0 = t_i0 + 5 * (kSegW + 4); float* t_i1 = t_a0 + 5 * (kSegW + 4); float* t_a1 = t_i1 + th * tw;
   const float ratio = *ratio_p;
+  for (int k = lx; k < 5 * (kSegW + 4); k += kSegW) {
+    const int ty = k / (kSegW + 4), tx = k - ty * (kSegW + 4);
+    const int Y = i0y - 2 + ty, X = x0 - 2 + tx;
+    const bool in = 0 <= Y && Y < h && 0 <= X && X < w;
+    t_i0[k] = in ? i0[size_t(Y) * w + X] : 0.f; t_a0[k] = in ? a0[size_t(Y) * w + X] : 0.f;
+  }
+  for (int k = lx; k < th * tw; k += kSegW) {
+    const int ty = k / tw, tx = k - ty * tw;
+    const size_t o = size_t(d_replicate(i0y - 2 + by + ty, h)) * w + d_replicate(x0 - 2 + bx + tx, w);
+    t_i1[k] = i1[o] * ratio + 0.0f; t_a1[k] = a1[o];
+  }
+  __syncthreads();
+  if (i0x >= w) return;
+  if (!(t_a0[2 * (kSegW + 4) + lx + 2] > kUpdateAlphaThreshold)) return;
+  const PatchTiles t{t_i0, t_a0, t_i1, t_a1, tw};
   const float kFraction = 0.8f;
-  float errorBest = kFraction * d_patch_error(i0, a0, i0x, i0y, i1, a1, i0x, i0y, w, h, ratio, dist);
+  // the zero-flow candidate: offset (0, 0) relative to the pixel = (-bx, -by) relative to the box origin (inside the tile for every
+  // search box of computeSearchBox: the box always contains the zero flow)
+  float errorBest = kFraction * d_patch_penalty(d_patch_error_lds(t, lx, i0x, i0y, -bx, -by, w, h, dist), 0, 0, dist);
   int i1xBest = i0x, i1yBest = i0y;
   for (int dy = by; dy < by + bh; ++dy)
     for (int dx = bx; dx < bx + bw; ++dx) {
       const int i1x = i0x + dx, i1y = i0y + dy;
       if (0 <= i1x && i1x < w && 0 <= i1y && i1y < h) {
-        const float error = d_patch_error(i0, a0, i0x, i0y, i1, a1, i1x, i1y, w, h, ratio, dist);
+        const float error = d_patch_penalty(d_patch_error_lds(t, lx, i0x, i0y, dx - bx, dy - by, w, h, dist), dx, dy, dist);
         if (errorBest > error) { errorBest = error; i1xBest = i1x; i1yBest = i1y; }
       }
     }
@@ -95,8 +133,9 @@ void launch_adjust_initial_flow(hipStream_t st, const float* i0, const float* i1
     default: return;
   }
   hipLaunchKernelGGL(k_intensity_ratio, dim3(1, 1, bt.n), dim3(256), 0, st, i0, i1, a0, a1, w * h, ratio_tmp, bt.stride);
-  dim3 grid((w + 63) / 64, h, bt.n);
-  hipLaunchKernelGGL(k_adjust_initial_flow, grid, dim3(64), 0, st, i0, i1, a0, a1, w, h, bx, by, bw, bh, dist, ratio_tmp,
+  dim3 grid((w + kSegW - 1) / kSegW, h, bt.n);
+  const size_t lds = (size_t(2) * 5 * (kSegW + 4) + size_t(2) * (5 + bh - 1) * (kSegW + 4 + bw - 1)) * sizeof(float);   // <= ~14 KB at max_percentage 100
+  hipLaunchKernelGGL(k_adjust_initial_flow, grid, dim3(kSegW), lds, st, i0, i1, a0, a1, w, h, bx, by, bw, bh, dist, ratio_tmp,
                      reinterpret_cast<float2*>(flow), bt.stride);
 }
 
@@ -469,12 +508,16 @@ void launch_tile_blur(hipStream_t st, float* blend, const float* mergedDis, int 
   if (shmem > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_blur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   hipMemsetAsync(work, 0, tile_blur_work_bytes(cols, rows, step, k), st);
   // every block must be resident (grid barrier): one block per CU at most, and no more than the longest diagonal has tiles
-  static const int ncu = [] { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 64; return p.multiProcessorCount; }();
+  // (the CU count of the device this launch goes to -- contexts on different GPU models may live in one process -- and what the
+  // occupancy calculator says fits beside nothing else: a block that can never be resident would leave the others spinning)
+  int dev = 0, ncu = 64, per_cu = 1;
+  if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_tile_blur), 256, shmem) != hipSuccess || per_cu < 1) per_cu = 1;
   // Few blocks: a diagonal rarely holds more than a dozen active tiles, a barrier among 32 blocks is cheaper than among 128, and
   // in pf_stitch_step this launch runs BESIDE the two flow solves, whose latency-bound sweeps should not share their CUs and
   // the L2 channel of the barrier word with a crowd of pollers.
   int blocks = nty < 32 ? nty : 32;
-  if (blocks > ncu / 2) blocks = ncu / 2;
+  if (blocks > ncu * per_cu / 2) blocks = ncu * per_cu / 2;
   if (blocks < 1) blocks = 1;
   const long long budget = 200000000ll * 5;   // 10 s of 100 MHz ticks: the launch may queue behind other work of the process
   hipLaunchKernelGGL(k_tile_blur, dim3(blocks), dim3(256), shmem, st, blend, mergedDis, cols, rows, step, k, dskew, ntx, nty, static_cast<TileBlurWork*>(work), budget);

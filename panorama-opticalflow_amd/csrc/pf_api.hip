@@ -56,7 +56,7 @@ struct pf_ctx {
   // pf_stitch_prefetch: `hint` = the image announced for the NEXT step (one-shot: the next pf_stitch_step latches and clears it, uploads
   // it into "ch_l_next" while its own kernels run, and records it as `ready`); `ready` = what sits in "ch_l_next" for the step after
   // (one-shot as well: that step either consumes it or drops it -- a stale host pointer is never dereferenced or matched later)
-  struct HostImage { const uint8_t* src = nullptr; int cols = 0, rows = 0; size_t step = 0; };
+  struct HostImage { const uint8_t* src = nullptr; int cols = 0, rows = 0; size_t step = 0; uint64_t sig = 0; /* content signature at upload time (host_image_sig) */ };
   HostImage hint, ready;
   hipStream_t s_copy = nullptr;         // uploads that overlap compute (created on first use, like s_aux: a context that only solves
                                         // pairs drives three streams, so that six lanes of the throughput mode fit the hardware queues)
@@ -371,7 +371,12 @@ int wait_gate_boxes(pf_ctx* c, hipStream_t st, int epoch, int nlevels, std::vect
   const auto t0 = std::chrono::steady_clock::now();
   long spins = 0;
   while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != epoch) {
-    __builtin_ia32_pause();   // the wait is microseconds long: stay on the core, but leave the pipeline to its sibling thread
+    // the wait is microseconds long: stay on the core, but leave the pipeline to its sibling thread
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield");
+#endif
     if ((++spins & 0xfff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
       HIPCHK(c, hipStreamSynchronize(st));   // surfaces a launch failure, if that is what happened
       if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != epoch) return fail(c, PF_ERR_DEVICE, "gate bounding boxes never arrived");
@@ -1236,6 +1241,20 @@ int pf_stitch_gather(pf_ctx* c, const uint8_t* l, const uint8_t* r, const uint8_
 // One whole iteration of the reference's stitch loop (CPU/main.cpp:70-95) without leaving the device:
 // Stitchtools::prepare -> NovelViewGeneratorAsymmetricFlow::prepare/generateNovelView -> Gather.
 // r_bgra == NULL chains on the previous call's result, which stays resident in HBM (main.cpp:64-65).
+// Content signature of a host image: 16 evenly spaced rows, 8 bytes at a time (~0.1 ms at 9000x4000).  The prefetched device copy of
+// an image is only used if the caller's buffer still carries the signature it had when it was uploaded: pointer, size and step alone
+// cannot tell a buffer from another image that an allocator later placed at the same address (the intended use is one cv::Mat freed and
+// re-read per image).
+static uint64_t host_image_sig(const uint8_t* p, int cols, int rows, size_t step) {
+  uint64_t h = 0x9E3779B97F4A7C15ull;
+  const size_t rb = size_t(cols) * 4;
+  for (int i = 0; i < 16; ++i) {
+    const uint8_t* row = p + size_t((long long)(rows - 1) * i / 15) * step;
+    for (size_t o = 0; o + 8 <= rb; o += 8) { uint64_t v; memcpy(&v, row + o, 8); h = (h ^ v) * 0xBF58476D1CE4E5B9ull; h ^= h >> 29; }
+  }
+  return h;
+}
+
 int pf_stitch_step(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int rows, size_t step, int max_pct, uint8_t* out, size_t ostep) {
   if (int e = use(c)) return e;
   CallGuard guard_(c);
@@ -1254,7 +1273,7 @@ int pf_stitch_step(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int 
   // both prefetch records are one-shot: latched and cleared here, whatever this step does with them
   const pf_ctx::HostImage ready = c->ready, hint = c->hint;
   c->ready = pf_ctx::HostImage(); c->hint = pf_ctx::HostImage();
-  if (ready.src == l && ready.cols == cols && ready.rows == rows && ready.step == step) {
+  if (ready.src == l && ready.cols == cols && ready.rows == rows && ready.step == step && ready.sig == host_image_sig(l, cols, rows, step)) {
     // this step's left image was uploaded while the previous step computed: the two buffers trade places (no copy; the old
     // "ch_l" is free -- the previous call drained every stream -- and receives the next prefetch)
     std::swap(c->bufs["ch_l"], c->bufs["ch_l_next"]);
@@ -1269,9 +1288,9 @@ int pf_stitch_step(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int 
   }
   { PROF(c, sm, "match_images"); launch_match_images(sm, dl, dr, cols, rows, dm, dol, dor); }
   // The blend ramp (GenerateBlend + countblend + smoothing, StitchTool.cpp:98-191) only depends on the map and is only
-  // needed by the final blend: it runs on its own stream beside the two flow solves.  Its ~850 tiny launches (the tile
-  // smoothing is one launch per anti-diagonal of tiles) are enqueued AFTER the solver's: enqueued first, they kept the
-  // host busy for >2 ms per step before the solver's first kernel could be launched.
+  // needed by the final blend: it runs on its own stream beside the two flow solves.  Its launches (a dozen since the tile smoothing
+  // became ONE persistent launch in round 3; ~850 before) are enqueued AFTER the solver's, so that the solver's first kernel is not
+  // kept waiting by them.
   if (!c->s_aux) HIPCHK(c, hipStreamCreateWithFlags(&c->s_aux, hipStreamNonBlocking));
   if (!c->s_copy) HIPCHK(c, hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
   hipStream_t sa = c->s_aux;
@@ -1294,6 +1313,7 @@ int pf_stitch_step(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int 
     else HIPCHK(c, hipMemcpy2DAsync(dnext, size_t(cols) * 4, hint.src, hint.step, size_t(cols) * 4, rows, hipMemcpyHostToDevice, c->s_copy));
     HIPCHK(c, hipStreamSynchronize(c->s_copy));
     c->ready = hint;
+    c->ready.sig = host_image_sig(hint.src, cols, rows, hint.step);
   }
   HIPCHK(c, hipGetLastError());
   if (int e = finish(c)) return e;

@@ -8,7 +8,7 @@ from conftest import load_pkg_module
 pf = load_pkg_module("pyabi"); synth = load_pkg_module("synth")
 dev = torch.device("cuda", 0)
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
-fams = sys.argv[2].split(",") if len(sys.argv) > 2 else ["median5", "tile_blur", "box_blur", "countblend", "sweep"]
+fams = sys.argv[2].split(",") if len(sys.argv) > 2 else ["median5", "tile_blur", "box_blur", "countblend", "sweep", "adjust_initial_flow"]
 def med(f, n=5):
     f(); return statistics.median([f() for _ in range(n)])
 res = {}

@@ -125,6 +125,16 @@ def test_stitch_prefetch_is_one_shot_and_result_neutral(pf, synth):
     buf[...] = imgs[3]                             # same address, new content
     o2 = c.stitch_step(buf, None, 20)              # must NOT match the stale record
     assert np.array_equal(o0, ref2[0]) and np.array_equal(o1, ref2[1]) and np.array_equal(o2, ref2[2])
+    # the allocator-reuse case of the round-3 advice: the announced buffer is overwritten with ANOTHER image (same address, size and
+    # step) between the step that uploaded it and the step that passes it -- the content signature taken at upload time no longer
+    # matches, so the step uploads what the buffer holds now instead of using the stale device copy
+    ref3 = chain(c, [imgs[0], imgs[3]], False)
+    buf2 = imgs[1].copy()
+    c.stitch_prefetch(buf2)
+    p0 = c.stitch_step(imgs[0], top, 20)           # uploads buf2 (= image 1) behind its own kernels
+    buf2[...] = imgs[3]                            # "freed and re-read": same address, another image
+    p1 = c.stitch_step(buf2, None, 20)
+    assert np.array_equal(p0, ref3[0]) and np.array_equal(p1, ref3[1])
     c.close()
 
 
