@@ -328,12 +328,12 @@ def main():
         # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is
         # READ FROM A COMMITTED FILE -- the rocprofv3 --pmc passes of this same command (profiles/, see its note) -- and labelled so.
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r04_pmc_bench.json")
         if (cols, rows, args.alg) == (9000, 4000, "pixflow_low") and os.path.exists(pmc_path):
             try:
                 pl = json.load(open(pmc_path))["sweep_per_launch"]
                 traffic = round(0.5 * (pl["traffic_bytes_lo"] + pl["traffic_bytes_hi"]))
-                traffic_src = "from_file: profiles/r03_pmc_bench.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per sweep launch; read side bracketed [raw, 2x raw], midpoint reported; NOT measured by this run)"
+                traffic_src = "from_file: profiles/r04_pmc_bench.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per sweep launch; read side bracketed [raw, 2x raw], midpoint reported; NOT measured by this run)"
             except Exception:
                 pass
         if "sweep" in prof and prof["sweep"][1] > 0:
@@ -361,21 +361,21 @@ def main():
         if world == 1 and not args.no_extras and args.concurrent <= 1:
             # ---- the honest bound of the sweeps: a dependency chain of `swept` steps per direction x the time of one step
             # of a lone band (measured live); hw_floor_us = the same chain priced with the guide's instruction latencies
-            # (profiles/r03_sweep_step_isa.txt) ----
+            # (profiles/r04_sweep_step_isa.txt) ----
             t_step = measure_t_step(pf, ctx, np)
             if sweep_ms_per_dir:
                 bound_ms = swept * t_step * 1e-3
                 lb = {"swept_steps": swept, "t_step_us": round(t_step, 4), "bound_ms": round(bound_ms, 3),
                       "measured_sweep_ms_per_direction": round(sweep_ms_per_dir, 3), "frac_of_bound": round(bound_ms / sweep_ms_per_dir, 4),
                       "note": "bound = swept_steps x t_step of ONE lone band (8 rows x 4096, HIP events); the two directions run concurrently"}
-                isa = os.path.join(ROOT, "profiles", "r03_sweep_step_isa.json")
+                isa = os.path.join(ROOT, "profiles", "r04_sweep_step_isa.json")
                 if os.path.exists(isa):
                     try:
                         hw = json.load(open(isa))
                         lb["hw_floor_us"] = hw["hw_floor_us"]
                         lb["hw_floor_ms"] = round(swept * hw["hw_floor_us"] * 1e-3, 3)
                         lb["frac_of_hw_floor"] = round(swept * hw["hw_floor_us"] * 1e-3 / sweep_ms_per_dir, 4)
-                        lb["hw_floor_source"] = "from_file: profiles/r03_sweep_step_isa.txt (loop-carried dependency chain of one step of compute_band<1,...>, priced with MI355X_MICROARCH.md latencies)"
+                        lb["hw_floor_source"] = "from_file: profiles/r04_sweep_step_isa.txt (loop-carried dependency chain of one step of compute_band<1,...>, priced with MI355X_MICROARCH.md latencies)"
                     except Exception:
                         pass
                 res["roofline"]["latency_bound"] = lb

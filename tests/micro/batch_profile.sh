@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 R=${1:-r04}; COLS=${2:-9000}; ROWS=${3:-4000}; PMC=${4:-1}
-export GPU_MAX_HW_QUEUES=32 TP_PAIRS=8 TP_LOOPS=2
+export GPU_MAX_HW_QUEUES=${BP_QUEUES:-32} TP_PAIRS=8 TP_LOOPS=2
 D=gpurun_out/bp_${R}_${COLS}
 rm -rf $D; mkdir -p $D
 python tests/micro/throughput_one.py 8 $COLS $ROWS > $D/plain.log 2>&1; grep queues $D/plain.log
