@@ -62,12 +62,16 @@ typedef struct pf_config {
   int sparse_sweep;         /* -1: pick the sweep variant that skips ungated anti-diagonals from the gate density, 0 / 1: force (-1) */
   int batch_pairs;          /* throughput mode (pf_novel_view_batch_dev): pairs that go through ONE set of launches (1..8; in_flight =
                                lanes x batch_pairs).  -1: in_flight itself up to 8 (one lane), half of it (two lanes) beyond */
-  int sweep_wide;           /* workgroup shape of the sweep launches: 0 = latency form (4 bands of 8 rows per workgroup, ONE compute wave per SIMD:
-                               the shortest step, what a lone pair wants), 1 = wide form (8 bands, two compute waves per SIMD: ~2x the steps per CU
-                               and second, what a batch that oversubscribes the chip wants), -1 = wide for the launches of a batch that ask for
-                               more latency-form workgroups than sweep_wide_threshold (-1).  Same bits either way. */
-  int sweep_wide_threshold; /* sweep_wide = -1: workgroups (pairs x 2 directions x workgroups per sweep) above which a launch goes wide (768 = three
-                               rounds of the chip: measured +2 % on 8 dense 9000x4000 pairs, -3.5 % on 2000x4000 strips at 560) */
+  int sweep_wide;           /* form of the sweep launches.  0 = latency form: 8 lanes per pixel evaluate a step's six energies at once, bands of 8 rows,
+                               ONE compute wave per SIMD -- the shortest step, what a lone pair wants.  2 = throughput form: 2 lanes per pixel, the
+                               reference's own order without speculation (two gather rounds per step), bands of 32 rows -- less than half the VALU
+                               instructions per pixel, what a batch that oversubscribes the chip wants.  1 = the latency form's step with two compute
+                               waves per SIMD (measured: no gain, kept as a cross-check).  -1 (default) = throughput form for the launches of a batch
+                               that ask for more latency-form workgroups than sweep_wide_threshold, latency form otherwise.  Same bits in every form. */
+  int sweep_wide_threshold; /* sweep_wide = -1: a launch takes the throughput form when (sweeps running at the same time: pairs of the batch x 2
+                               directions x lanes) x (its latency-form workgroups) exceeds this (512: two rounds of the chip) */
+  int sweep_throughput_transposed; /* sweep_wide = -1: sweeps whose bands step along y (windows taller than wide, e.g. 2000x4000 strips) may take the
+                               throughput form too; its gather-window loads do not coalesce in that orientation (0) */
   int full_width_batch_gradients; /* 1: in a batched solve the finest levels' gradients are one full-width launch (nothing to hide them
                                behind: the batch keeps every CU busy anyway), 0: the narrow launch of a lone pair (1) */
   /* Cross-check implementations -- only in libpanoflow_exp.so (the -DPF_EXPERIMENTS build used by the test-suite);

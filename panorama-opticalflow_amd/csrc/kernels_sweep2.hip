@@ -30,6 +30,7 @@
 // running), every spin is bounded and raises ctrl[1] instead of hanging.
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <algorithm>
 
 #include "pf_common.hpp"
 #include "sweep_window.hpp"
@@ -185,7 +186,10 @@ __device__ __forceinline__ float dpp_shl0(float src) {
 // within +-(kRad-1) texels of the pixel, otherwise from HBM.  Scheduled in three phases: (A) addresses + issue of
 // the texel reads, (B) every term that does not need the texels (smoothness, the two regularisers) in the shadow
 // of their latency, (C) bilinear + data term.  sched_barrier keeps the compiler from sinking B below the wait.
-template <bool TR, bool FWD, int kWA>
+// SKEW (throughput form, 32 rows per band): the window ring is indexed by u + (window row) instead of u -- at any step all 32 rows of a
+// band then touch the same ~31 ring slots although their pixels are 32 columns apart (a ring of 64 serves; unskewed it would take 128).
+// Moving one window row down also moves one slot on, and the first TWO ring columns are stored again behind column 63 (kWCPT).
+template <bool TR, bool FWD, int kWA, int WCP = kWCp, bool SKEW = false>
 __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __attribute__((address_space(3))) const float2* win, int ob, int W, int H, float wm2, float hm2,
                                               float fW, float rW, f2p pos, float i0x, float i0y, float bx, float by, f2p fd,
                                               int& emin, float& vmax) {
@@ -208,7 +212,7 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   const int ulo = TR ? cyl : cxl, vlo = TR ? cxl : cyl;
   // out-of-window lanes are clamped to a valid window row (they read garbage that the HBM path below overwrites)
   const int alo = min(max(vlo - ob, 0), kWA - 2);
-  auto q = [&](int dr, int dc) { return (FWD ? dr : 1 - dr) * kWCp + (FWD ? dc : 1 - dc); };   // texel (v0 + sg*dr, u0 + sg*dc), relative to the corner
+  auto q = [&](int dr, int dc) { return (FWD ? dr : 1 - dr) * (WCP + (SKEW ? 1 : 0)) + (FWD ? dc : 1 - dc); };   // texel (v0 + sg*dr, u0 + sg*dc), relative to the corner
   const int o00 = q(0, 0);                            // texel (x0, y0)
   const int o10 = TR ? q(1, 0) : q(0, 1);             // texel (x0+1, y0)
   const int o01 = TR ? q(0, 1) : q(1, 0);             // texel (x0, y0+1)
@@ -219,11 +223,11 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   typedef __attribute__((address_space(3))) const f2v lds_f2;
   // explicit LDS address space: ds_read2_b64, never a flat access.  The corner's byte address as (ring column << 3) + window, then
   // + row * stride in one 24-bit multiply-add: five instructions from (x0, y0) to the address.
-  unsigned ringCol = unsigned(ulo & (kWC - 1));
+  unsigned ringCol = unsigned((SKEW ? ulo + alo : ulo) & (kWC - 1));
   asm("" : "+v"(ringCol));   // (x & 63) << 3 + base as v_and + v_lshl_add, not the canonical v_lshl + v_and + v_add
   const unsigned cornerCol = (ringCol << 3) + (unsigned)(size_t)win;
   unsigned cornerAddr;   // = alo * row stride + cornerCol; written out because the compiler turns it into v_mul_u32_u24 + v_add3_u32 (one more)
-  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(cornerAddr) : "v"(alo), "s"(unsigned(kWCp * sizeof(float2))), "v"(cornerCol));
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(cornerAddr) : "v"(alo), "s"(unsigned(WCP * sizeof(float2))), "v"(cornerCol));
   lds_f2* win3 = (lds_f2*)(size_t)cornerAddr;
   const f2v w00 = win3[o00], w10 = win3[o10], w01 = win3[o01], w11 = win3[o11];
   float2 t00 = make_float2(w00.x, w00.y), t10 = make_float2(w10.x, w10.y), t01 = make_float2(w01.x, w01.y), t11 = make_float2(w11.x, w11.y);
@@ -667,15 +671,19 @@ __device__ __forceinline__ float2 own_gradient_step(float2 f, float e0, float ex
 
 // One record of the prepass (slot = linear index in wavefront order, see k_sweep_prep): shared by the prepass kernel and by
 // the prepass blocks that ride inside the sweep launch (k_sweep2, MODE 2).
+// ROWS = rows per band (8: latency / wide form, 32: throughput form).  RC: the record carries rC, the current flow after its own gradient
+// step (three energies per pixel: what the 8-lane step needs); !RC (throughput form): it carries C itself and E(C) only -- that step
+// takes the winner's gradient step itself, the current flow's included (one energy per pixel here instead of three).
+template <int ROWS = kRows, bool RC = true>
 __device__ __forceinline__ void d_make_record(size_t tid, size_t total, const float2* __restrict__ g0, const float2* __restrict__ g1,
                                               const float2* __restrict__ blurred, const uint8_t* __restrict__ gate, const float2* __restrict__ flow, int W,
                                               int H, int forward, int transposed, int nstepsPad, float rW, int uLo, int uHi, int bandLo, float4& a,
                                               float4& b, float4& c) {
   const int LS = transposed ? H : W, LB = transposed ? W : H;   // extent along the step axis / across the bands
-  const int r = int(tid % kRows);
-  const int s = int((tid / kRows) % nstepsPad);
-  const int band = int(tid / (size_t(kRows) * nstepsPad));
-  const int ia = uLo + s - r, ib = (bandLo + band) * kRows + r;
+  const int r = int(tid % ROWS);
+  const int s = int((tid / ROWS) % nstepsPad);
+  const int band = int(tid / (size_t(ROWS) * nstepsPad));
+  const int ia = uLo + s - r, ib = (bandLo + band) * ROWS + r;
   // A pixel that is not updated (gate <= 0) carries E(C) = kKeepEnergy and rC = C: every proposal's energy is >= 0 (or NaN), so
   // the selection keeps rC = C -- the sweep's step needs no "if not gated keep C" of its own (two v_cndmask per step).
   a = make_float4(0.f, 0.f, 0.f, 0.f); b = make_float4(kKeepEnergy, 0.f, 0.f, kKeepEnergy); c = a;
@@ -691,10 +699,13 @@ __device__ __forceinline__ void d_make_record(size_t tid, size_t total, const fl
       const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
       a = make_float4(g.x, g.y, bl.x, bl.y);
       const float e0 = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x, f.y);
-      const float e1 = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x + kGradEpsilon, f.y + 0.0f);
-      const float e2 = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
-      const float2 rc0 = own_gradient_step(f, e0, e1, e2);
-      b.x = e0; b.y = rc0.x; b.z = rc0.y;
+      b.x = e0;
+      if (RC) {
+        const float e1 = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x + kGradEpsilon, f.y + 0.0f);
+        const float e2 = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
+        const float2 rc0 = own_gradient_step(f, e0, e1, e2);
+        b.y = rc0.x; b.z = rc0.y;
+      }
       b.w = (ia > 0) ? e0 : kKeepEnergy;   // E(C) as the proposal from the previous pixel ALONG the step axis sees it: unbeatable at the first pixel of a row (there is none)
     }
   }
@@ -713,6 +724,7 @@ __device__ __forceinline__ void d_make_record(size_t tid, size_t total, const fl
 // When the window does not start at the first band, the row above it never changes during this sweep: its flow
 // is written as the granule row the first workgroup's poller reads (top0).
 // ------------------------------------------------------------------------------------------------
+template <int ROWS, bool RC>
 __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g0, const float2* __restrict__ g1, const float2* __restrict__ blurred,
                                                     const uint8_t* __restrict__ gate, const float2* __restrict__ flow, int W, int H, int forward,
                                                     int transposed, int nstepsPad, int nbandsPad, float rW, float4* __restrict__ rec, int uLo, int uHi,
@@ -722,24 +734,32 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
     PF_BOFF(g0, bo); PF_BOFF(g1, bo); PF_BOFF(blurred, bo); PF_BOFF(gate, bo); PF_BOFF(flow, bo); PF_BOFF(rec, bo);
     if (top0 != nullptr) PF_BOFF(top0, bo);
   }
-  const size_t tid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
+  // Which of the block's 256 record slots this thread computes.  Slots are in wavefront order (row fastest).  With 8 rows per band a
+  // wave's 64 slots are 8 rows x 8 consecutive columns: 64-byte runs of every input plane.  With 32 rows they would be 32 rows x 2
+  // columns (16-byte runs: the throughput form's first prepass ran 1.5x LONGER than the latency form's with a third of the arithmetic),
+  // so the block's 8 steps x 32 rows are dealt out column-fastest instead; the LDS stage below puts the records back in slot order.
+  const unsigned lt = (ROWS == 32) ? (threadIdx.x & 7) * 32 + (threadIdx.x >> 3) : threadIdx.x;
+  const size_t tid = size_t(blockIdx.x) * blockDim.x + lt;
+  const size_t total = size_t(nbandsPad) * nstepsPad * ROWS;
   if (top0 != nullptr && tid < size_t(uHi - uLo)) {
-    const int ia = uLo + int(tid), ib = bandLo * kRows - 1;
+    const int ia = uLo + int(tid), ib = bandLo * ROWS - 1;
     const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;
     const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
     top0[tid] = pack2(flow[size_t(y) * W + x]);
   }
   // (no early return: the block stages its 256 records in LDS so that they leave as three fully coalesced 4 KB stores instead
   // of 16-byte pieces at a 48-byte stride)
-  __shared__ float4 stage[256 * 3];
+  // (throughput form: 32-byte records -- the step forms the pixel's coordinates itself, the record stream is what bounds this kernel there)
+  constexpr int kQuads = RC ? 3 : 2;
+  __shared__ float4 stage[256 * kQuads];
   float4 a, b, c;
-  d_make_record(tid, total, g0, g1, blurred, gate, flow, W, H, forward, transposed, nstepsPad, rW, uLo, uHi, bandLo, a, b, c);
-  stage[threadIdx.x * 3 + 0] = a; stage[threadIdx.x * 3 + 1] = b; stage[threadIdx.x * 3 + 2] = c;
+  d_make_record<ROWS, RC>(tid, total, g0, g1, blurred, gate, flow, W, H, forward, transposed, nstepsPad, rW, uLo, uHi, bandLo, a, b, c);
+  stage[lt * kQuads + 0] = a; stage[lt * kQuads + 1] = b;
+  if (kQuads == 3) stage[lt * kQuads + 2] = c;
   __syncthreads();
-  const size_t base = size_t(blockIdx.x) * blockDim.x * 3, lim = total * 3;   // in float4 units
+  const size_t base = size_t(blockIdx.x) * blockDim.x * kQuads, lim = total * kQuads;   // in float4 units
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < kQuads; ++k) {
     const size_t o = base + size_t(k) * 256 + threadIdx.x;
     if (o < lim) rec[o] = stage[k * 256 + threadIdx.x];
   }
@@ -1299,6 +1319,8 @@ int sweep_pk_probe(hipStream_t st, unsigned* bad) {
 #endif
 }
 
+#include "kernels_sweep_t.inl"   // the throughput form (32 rows per wave, 2 lanes per pixel): k_sweep_t, launch_sweep_t
+
 // ---- host side ----
 // Bands run across the SHORTER side of the active window (fewer band-to-band hand-offs on the critical path):
 // normal = bands of 8 rows stepping along x; transposed = bands of 8 columns stepping along y.
@@ -1322,7 +1344,10 @@ size_t sweep_boundary_elems(int W, int H) {   // hand-off granules a sweep launc
 }
 size_t sweep2_rec_bytes(int W, int H) {
   const size_t a = size_t(wgs_for(H, SwWide::kWaves)) * SwWide::kWaves * steps_pad(W), b = size_t(wgs_for(W, SwWide::kWaves)) * SwWide::kWaves * steps_pad(H);
-  return (a > b ? a : b) * kRows * 48;
+  // throughput form: bands of 32 rows, three per workgroup, tRows - 1 more steps per band
+  auto t_records = [](int LB, int LS) { const size_t nb = (size_t(LB) + tRows - 1) / tRows, nwg = (nb + tWaves - 1) / tWaves; return nwg * tWaves * tRows * (size_t(LS + tRows - 1 + kChunk - 1) / kChunk * kChunk); };
+  const size_t t = std::max(t_records(H, W), t_records(W, H));
+  return std::max((a > b ? a : b) * kRows * 48, t * 32);
 }
 template <class G>
 static bool launch_sweep2_form(hipStream_t st, const SweepArgs& a, float* rec) {
@@ -1346,7 +1371,7 @@ static bool launch_sweep2_form(hipStream_t st, const SweepArgs& a, float* rec) {
   constexpr int mode = 0;
 #endif
   if (mode == 0)
-    hipExtLaunchKernelGGL(k_sweep_prep, dim3((unsigned)((prepThreads + 255) / 256), 1, a.bt.n), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate, a.flow,
+    hipExtLaunchKernelGGL((k_sweep_prep<kRows, true>), dim3((unsigned)((prepThreads + 255) / 256), 1, a.bt.n), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate, a.flow,
                           a.W, a.H, a.forward, tr, nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo,
                           bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride);
   hipEvent_t evs = mode == 0 ? nullptr : a.ev_start;   // without a prepass kernel the sweep launch carries both events
@@ -1375,10 +1400,12 @@ static bool launch_sweep2_form(hipStream_t st, const SweepArgs& a, float* rec) {
 bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
   int wide = a.wide;
   if (wide < 0) {
+    // oversubscribed launches of a batch: the throughput form where it exists (dense, bands stepping along x), else the latency form
     const SweepWindow win = make_sweep_window(a.W, a.H, a.forward, a.ax0, a.ay0, a.ax1, a.ay1, kRows, SwLatency::kWaves, kChunk);
-    wide = (!win.empty && long(win.nwg) * a.bt.n * 2 > long(a.wide_threshold_wgs)) ? 1 : 0;
+    wide = (!win.empty && long(win.nwg) * a.concurrent_sweeps > long(a.wide_threshold_wgs) && !a.sparse && (!win.tr || a.wide_tr)) ? 2 : 0;
   }
-  return wide ? launch_sweep2_form<SwWide>(st, a, rec) : launch_sweep2_form<SwLatency>(st, a, rec);
+  if (wide == 2 && !a.sparse) return launch_sweep_t(st, a, rec);
+  return wide == 1 ? launch_sweep2_form<SwWide>(st, a, rec) : launch_sweep2_form<SwLatency>(st, a, rec);
 }
 
 #ifdef PF_EXPERIMENTS

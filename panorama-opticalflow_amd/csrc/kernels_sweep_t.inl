@@ -1,0 +1,489 @@
+// K6, THROUGHPUT form of the exact Gauss-Seidel sweep (CPU/PixFlow.hpp:315-337) -- included by kernels_sweep2.hip.
+//
+// The latency form (compute_band above) spends lanes to buy time: 8 lanes per pixel evaluate the six energies a step may need AT
+// ONCE, speculatively, so that a step is one gather round.  That is right for ONE pair, whose sweeps are a dependency chain and leave
+// most of the chip idle.  A BATCH of pairs asks for several times more sweep workgroups than the chip has CUs, and there the
+// measured bound is the SIMDs' VALU issue (profiles/r04_wide_sweep.txt: one 8-lane compute wave keeps its SIMD's VALU pipe ~60 % busy;
+// a second one on the same SIMD runs at 0.43 instead of 0.29 us per step) -- what counts is VALU instructions per PIXEL:
+//   latency form:    ~118 instructions per step of a wave = 8 pixels  -> 14.7 per pixel (+ a prepass of three energies per pixel)
+//   throughput form: ~210 instructions per step of a wave = 32 pixels ->  6.6 per pixel (+ a prepass of one energy per pixel)
+// This form does what the reference does, in the reference's order, two lanes per pixel and without speculation:
+//   round 1: lane a evaluates E(along proposal), lane b E(across proposal)          (proposeFlowUpdate x 2, PixFlow.hpp:342-362)
+//   select : current, then L, then T, strict '<' -> the winner W and E(W)           (both lanes, same instructions)
+//   round 2: lane a evaluates E(W + eps e_x), lane b E(W + eps e_y)                 (errorGradient, PixFlow.hpp:364-386)
+//   update : W - 0.5 * ((E(W+dx), E(W+dy)) - E(W)) / eps                            (PixFlow.hpp:322-323)
+// Two dependent gather rounds per step (~0.45 us instead of 0.29), but four times the rows per wave.  Same arithmetic (d_error_fast with
+// its range guard and whole-wave IEEE redo, exact_forms.hpp), same operands, same order => the same bits as the latency form and the oracle.
+//
+// Geometry: a band = 32 rows, lane = 32 * role + row; the partner's value comes by v_permlane32_swap (one instruction hands both lanes
+// both values), the row above's result by a wave_shr:1 DPP move.  A workgroup = 3 compute waves (96 rows; the CU's 160 KB of LDS hold
+// three bands' rings and windows) + 3 loaders + publisher + poller + drainer = 576 threads; the helpers share the fourth SIMD and the
+// compute waves' SIMDs.  Rings, counters, granules, tickets and deadlines work as in the latency form.  The gather window is SKEWED:
+// ring slot = (u + window row) & 63, because the 32 pixels of a step lie on an anti-diagonal 32 columns wide -- in (u + row) they all sit
+// within 31 slots of each other (d_error_fast<.., SKEW>).  Dense, non-transposed sweeps only (what a batch of dense pairs runs at its
+// large levels); everything else keeps the latency form.
+namespace {
+constexpr int tRows = 32;                       // rows per compute wave
+constexpr int tWaves = 3;                       // compute waves (bands) per workgroup
+constexpr int tRS = 16;                         // record ring (steps)
+constexpr int tOS = 16;                         // result ring (steps)
+constexpr int tWA = tRows + 2 * kRad + 1;       // window rows (49)
+constexpr int kWCPT = kWC + 2;                  // window row stride: ring columns 0 and 1 again behind column 63 (the skewed footprint reaches slot + 2)
+constexpr int tThreads = 64 * (2 * tWaves + 3);
+
+struct SmemTF {
+  float4 rec[tWaves][tRS][tRows][2];            // the 32-byte records (I0x, I0y, blurred.x, blurred.y | E(C), C.x, C.y, Ea)
+  float2 out[tWaves][tOS][tRows];
+  float2 win[tWaves][tWA][kWCPT];
+  unsigned long long bnd[kBS];
+  int recHead[tWaves], outHead[tWaves], outTail[tWaves];
+  int pubTail, bndHead, abort, wg;
+  long long deadline;
+};
+
+// V_PERMLANE32_SWAP: lanes 32-63 of `a` trade places with lanes 0-31 of `b`.  With a == b == v: lo = role a's v in every lane, hi = role b's.
+__device__ __forceinline__ void swap_roles(float v, float& lo, float& hi) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+}
+
+// One step for one wave.  FAST: the exact cheap forms + range guard (emin / vmax out); !FAST: the IEEE sequence (cold redo path).
+template <bool FAST, bool TR, bool FWD>
+__device__ __forceinline__ float2 t_step(const float2* __restrict__ g1, __attribute__((address_space(3))) const float2* win, int ob, int W, int H, float wm2, float hm2,
+                                         float fW, float rW, float rEps, f2p posv, float4 ra, float eC, float2 C, float eCL, bool okL, bool okT, float2 along,
+                                         float2 across, int role, int& emin, float& vmax) {
+  auto energy = [&](float2 f, int& em, float& vm) -> float {
+    if (FAST) return d_error_fast<TR, FWD, tWA, kWCPT, true>(g1, win, ob, W, H, wm2, hm2, fW, rW, posv, ra.x, ra.y, ra.z, ra.w, f2p{f.x, f.y}, em, vm);
+    em = 0; vm = 0.f;
+    return d_error2(g1, W, wm2, hm2, fW, int(posv.x), int(posv.y), ra.x, ra.y, ra.z, ra.w, f.x, f.y);
+  };
+  // ---- round 1: the two proposals (reference order: previous column = L, then previous row = T; transposed sweeps step along y) ----
+  const float2 p1 = role ? across : along;
+  int em1; float vm1;
+  const float e1 = energy(p1, em1, vm1);
+  float eA, eX;
+  swap_roles(e1, eA, eX);
+  const float eL = TR ? eX : eA, eT = TR ? eA : eX;
+  const float2 fL = TR ? across : along, fT = TR ? along : across;
+  const bool pickL = okL && (eL < eCL);   // eCL = E(C), or below every energy where L does not exist (see the records)
+  const float cur = pickL ? eL : eC;
+  const bool pickT = okT && (eT < cur);
+  float2 Wf; Wf.x = pickL ? fL.x : C.x; Wf.y = pickL ? fL.y : C.y;
+  Wf.x = pickT ? fT.x : Wf.x; Wf.y = pickT ? fT.y : Wf.y;
+  const float eW = pickT ? eT : cur;
+  // ---- round 2: the winner's finite differences, one per lane ----
+  const float2 p2 = make_float2(Wf.x + (role ? 0.0f : kGradEpsilon), Wf.y + (role ? kGradEpsilon : 0.0f));
+  int em2; float vm2;
+  const float e2 = energy(p2, em2, vm2);
+  float g1e, g2e;
+  swap_roles(e2, g1e, g2e);
+  float2 res;
+  if (FAST) {
+    const f2p dg = f2p{g1e, g2e} - f2p{eW, eW};
+    const float ax = fabsf(dg.x), ay = fabsf(dg.y);
+    const f2p gq = div_core2(dg, kGradEpsilon, rEps);
+    emin = min(min(em1, em2), min(__builtin_amdgcn_frexp_expf(ax), __builtin_amdgcn_frexp_expf(ay)));
+    vmax = __builtin_fmaxf(__builtin_fmaxf(vm1, vm2), __builtin_fmaxf(ax, ay));
+    const f2p r = __builtin_elementwise_fma(gq, f2p{-kGradientStepSize, -kGradientStepSize}, f2p{Wf.x, Wf.y});   // exact: see select_step
+    res = make_float2(r.x, r.y);
+  } else {
+    const float gx = (g1e - eW) / kGradEpsilon, gy = (g2e - eW) / kGradEpsilon;
+    res = make_float2(Wf.x - kGradientStepSize * gx, Wf.y - kGradientStepSize * gy);
+    emin = 0; vmax = 0.f;
+  }
+  return res;
+}
+
+// One compute wave of the throughput form: a band of 32 rows.  TOP as in compute_band.
+template <int TOP, bool TR, bool FWD>
+__device__ __forceinline__ bool compute_band_t(SmemTF& sm, const float2* __restrict__ g1, int W, int H, int nsteps, int w, int band, int nact, bool publishes,
+                                               float rW, float rEps, int uLo, int LSv) {
+  constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0;
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31, role = lane >> 5;
+  const int ib = band * tRows + r;
+  const int LS = transposed ? H : W;
+  const bool hasCross = (TOP != 0) || ib > 0;
+  typedef __attribute__((address_space(3))) const float2 lds_cf2;
+  lds_cf2* win = (lds_cf2*)&sm.win[w][0][0];
+  asm volatile("" : "+s"(win));
+  int ob = band * tRows - kRad;
+  asm volatile("" : "+s"(ob));
+  const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W), fLast = float(LS - 1);
+  const bool lastPub = publishes && (w == tWaves - 1);
+  const bool hasNext = (w + 1 < nact);
+  const int wp = (w > 0) ? w - 1 : 0;
+  const int* topHead = (TOP == 1) ? &sm.outHead[wp] : &sm.bndHead;
+  constexpr int kBias = (TOP == 1) ? tRows - 1 : 0;   // TOP==1: column c is the producer's step c + 31
+  auto top_slot = [&](int c) -> const unsigned long long* {
+    return (TOP == 1) ? reinterpret_cast<const unsigned long long*>(&sm.out[wp][(c + tRows - 1) % tOS][tRows - 1]) : &sm.bnd[c & (kBS - 1)];
+  };
+  const bool isL32 = lane == 32;
+  float2 prev = make_float2(0.f, 0.f);
+  bool dead = false, waitTop = true;
+  unsigned long long tv = 0;
+  int fcRec = 0, fcTail = 0, fcPub = 0, fcNext = 0;
+  float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+  // the pixel's image coordinates: the position across the bands is fixed, the position along the step axis advances by one per
+  // step (sweep order; mirrored for the backward sweep); exact small integers in fp32
+  const float acrossPos = forward ? float(ib) : float((transposed ? W : H) - 1 - ib);
+  float alongU = float(uLo - r);   // sweep-order column of step 0
+  for (int s0 = 0; s0 < nsteps; s0 += kChunk) {
+    if (dead) return false;
+    {
+      int spins = 0;
+      for (;;) {
+        const int rec = __builtin_amdgcn_readfirstlane(fcRec);
+        int lim = __builtin_amdgcn_readfirstlane(fcTail) + tOS;
+        if (lastPub) { const int c1 = __builtin_amdgcn_readfirstlane(fcPub) + tOS; lim = lim < c1 ? lim : c1; }
+        if (hasNext) { const int c2 = __builtin_amdgcn_readfirstlane(fcNext) + tOS + tRows - 1; lim = lim < c2 ? lim : c2; }
+        if (__builtin_expect(rec >= s0 + kChunk && lim >= s0 + kChunk, 1)) break;
+        if (spins) __builtin_amdgcn_s_sleep(1);
+        fcRec = ld_cnt(&sm.recHead[w]); fcTail = ld_cnt(&sm.outTail[w]);
+        if (lastPub) fcPub = ld_cnt(&sm.pubTail);
+        if (hasNext) fcNext = ld_cnt(&sm.outHead[w + 1]);
+        if (spin_expired(spins, sm) || (((spins & 255) == 0) && ld_cnt(&sm.abort))) return false;
+      }
+      if (__builtin_expect(spins != 0 || s0 == 0, 0)) {   // (re)load this chunk's first record: read ahead it was only good if already there
+        const float4* rp0 = &sm.rec[w][s0 % tRS][r][0];
+        ra = rp0[0]; rb = rp0[1];
+        asm volatile("" : "+v"(ra.x), "+v"(ra.y), "+v"(ra.z), "+v"(ra.w), "+v"(rb.x), "+v"(rb.y), "+v"(rb.z), "+v"(rb.w));
+      }
+    }
+    // counters for the NEXT chunk's check: read in the middle of this chunk (a 16-step ring cannot satisfy a check that is a whole chunk old)
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef float f2w __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) const f4v lds_f4;
+    typedef __attribute__((address_space(3))) f2w lds_wf2;
+    typedef __attribute__((address_space(3))) const unsigned long long lds_u64;
+    lds_f4* recChunk = (lds_f4*)&sm.rec[w][s0 % tRS][r][0];
+    lds_f4* recNext = (lds_f4*)&sm.rec[w][(s0 + kChunk) % tRS][r][0];
+    lds_wf2* outChunk = (lds_wf2*)&sm.out[w][s0 % tOS][r];   // (role a stores)
+    lds_u64* topChunk = (lds_u64*)((TOP == 1) ? top_slot(s0 + 1) : &sm.bnd[s0 & (kBS - 1)] + 1);
+    lds_u64* topNext = (lds_u64*)top_slot(s0 + kChunk);
+    typedef __attribute__((address_space(3))) int lds_int;
+    lds_int* cntp = (lds_int*)&sm.outHead[w];
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) {
+      const int s = s0 + j;
+      if (j == 5) {
+        fcRec = ld_cnt(&sm.recHead[w]); fcTail = ld_cnt(&sm.outTail[w]);
+        if (lastPub) fcPub = ld_cnt(&sm.pubTail);
+        if (hasNext) fcNext = ld_cnt(&sm.outHead[w + 1]);
+      }
+      if (TOP != 0) {
+        if (__builtin_expect(waitTop, 0)) {
+          if (!dead && s < LSv) {
+            const int need = (s + 1 + PF_MARGIN(TOP) < LSv) ? s + 1 + PF_MARGIN(TOP) : LSv;
+            int spins = 0;
+            for (;;) {
+              const int avail = __builtin_amdgcn_readfirstlane(ld_cnt(topHead)) - kBias;
+              if (avail >= need) break;
+              if (spin_expired(spins, sm) || (((spins & 255) == 0) && ld_cnt(&sm.abort))) { dead = true; break; }
+            }
+            tv = __hip_atomic_load(top_slot(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            unsigned tlo = unsigned(tv), thi = unsigned(tv >> 32);
+            asm volatile("" : "+v"(tlo), "+v"(thi));
+            tv = (unsigned long long)tlo | ((unsigned long long)thi << 32);
+          }
+        }
+      }
+      // the across proposal = the previous result of the row above: one lane down (same role); row 0 takes the ring value (lane 0 has
+      // no source lane and keeps `old`; lane 32 would read lane 31 -- role a's row 31 -- and is patched).  First band: no row above row 0,
+      // its across proposal is masked out of the selection (hasCross) and only has to be finite.
+      const float2 tvf = (TOP != 0) ? unpack2(tv) : prev;
+      float2 across;
+      across.x = dpp<0x138>(tvf.x, prev.x);   // wave_shr:1
+      across.y = dpp<0x138>(tvf.y, prev.y);
+      if (TOP != 0) { across.x = isL32 ? tvf.x : across.x; across.y = isL32 ? tvf.y : across.y; }
+      const float alongPos = forward ? alongU : fLast - alongU;
+      const f2p posv = transposed ? f2p{acrossPos, alongPos} : f2p{alongPos, acrossPos};
+      const float fpos = alongPos;
+      alongU += 1.0f;
+      const float eC = rb.x, eCa = rb.w;
+      const float2 C = make_float2(rb.y, rb.z);
+      const bool gated = eC >= 0.0f;
+      const bool hasAlong = transposed ? (forward ? (fpos > 0.0f) : (fpos < fLast)) : true;
+      const float eCL = transposed ? eC : eCa;
+      const bool okL = transposed ? hasCross : hasAlong, okT = transposed ? hasAlong : hasCross;
+      int emin; float vmax;
+      float2 fin = t_step<true, TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, rEps, posv, ra, eC, C, eCL, okL, okT, prev, across, role, emin, vmax);
+      // next step's inputs (LDS), behind the second gather round
+      float4 na, nb; int hN = 0; unsigned long long tvN = tv;
+      {
+        lds_f4* rpn = (j + 1 < kChunk) ? recChunk + (j + 1) * (tRows * 2) : recNext;
+        const f4v q0 = rpn[0]; const f4v q1 = rpn[1];
+        na = make_float4(q0.x, q0.y, q0.z, q0.w); nb = make_float4(q1.x, q1.y, q1.z, q1.w);
+      }
+      if (TOP != 0) {
+        lds_u64* tpn = (j + 1 < kChunk) ? topChunk + j * ((TOP == 1) ? tRows : 1) : topNext;
+        hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      asm volatile("" : "+v"(fin.x), "+v"(fin.y));
+      if (__builtin_expect(__any((emin < -94 || !(vmax <= 0x1p100f)) && gated), 0)) {
+        // an operand left the range where the fast forms are exact: the whole wave redoes the step with IEEE sqrt and division
+        fin = t_step<false, TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, rEps, posv, ra, eC, C, eCL, okL, okT, prev, across, role, emin, vmax);
+      }
+      fin.x = gated ? fin.x : C.x; fin.y = gated ? fin.y : C.y;   // a pixel that is not updated keeps its flow (PixFlow.hpp:317); slots without a pixel carry C = 0
+      if (TOP != 0) {
+        waitTop = __any(s + 1 + kBias >= hN);
+        asm volatile("" : "+v"(tvN));
+        tv = tvN;
+      }
+      prev = fin;
+      if (role == 0) outChunk[j * tRows] = f2w{fin.x, fin.y};
+      asm volatile("" ::: "memory");
+      __hip_atomic_store(cntp, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      ra = na; rb = nb;
+    }
+  }
+  return !dead;
+}
+}  // namespace
+
+template <bool TR, bool FWD>
+__global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
+                                                      unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H, int nstepsPad, int nbands,
+                                                      float rW, float rEps, int uLo, int LSv, int bandLo, long long budgetTicks, size_t bstride) {
+  {
+    const size_t bo = size_t(blockIdx.z) * bstride;
+    PF_BOFF(rec, bo); PF_BOFF(g1, bo); PF_BOFF(flow, bo); PF_BOFF(boundary, bo); PF_BOFF(ctrl, bo);
+  }
+  constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0;
+  __shared__ SmemTF sm;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  if (tid == 0) {
+    sm.wg = atomicAdd(&ctrl[0], 1);
+    sm.bndHead = 0; sm.abort = 0; sm.pubTail = 0;
+    sm.deadline = (long long)wall_clock64() + budgetTicks;
+  }
+  if (tid < tWaves) { sm.recHead[tid] = 0; sm.outHead[tid] = 0; sm.outTail[tid] = 0; }
+  __syncthreads();
+  const int wg = sm.wg;
+  const int LS = transposed ? H : W, LB = transposed ? W : H;
+  const int nsteps = nstepsPad;
+  const int band0 = wg * tWaves;
+  const int nact = (nbands - band0) < tWaves ? (nbands - band0) : tWaves;
+  const bool publishes = band0 + tWaves < nbands;
+  const bool staticTop = bandLo > 0;
+  auto give_up = [&]() { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+
+  if (wave < tWaves) {
+    // ======================= compute wave: band of 32 rows =======================
+    if (wave >= nact) return;
+    __builtin_amdgcn_s_setprio(3);
+    const int top = (wave > 0) ? 1 : ((wg > 0 || staticTop) ? 2 : 0);
+    const int band = bandLo + band0 + wave;
+    bool ok;
+    if (top == 1) ok = compute_band_t<1, TR, FWD>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
+    else if (top == 2) ok = compute_band_t<2, TR, FWD>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
+    else ok = compute_band_t<0, TR, FWD>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
+    if (!ok) give_up();
+    return;
+  }
+  __builtin_amdgcn_s_setprio(1);
+  if (wave < 2 * tWaves) {
+    // ======================= loader of band w: records + skewed gather window HBM -> LDS =======================
+    // Window batch b = the ring slots d in [8b - 8, 8b) (d = u - uLo + window row), 8 x 49 texels: row a holds u = uLo + d - a.  A band working
+    // on chunk j reads d in [8j - 6, 8j + 31] = batches j .. j+4: batch j+4 is loaded with chunk j (batches 0..3 in the first round) and
+    // overwrites batch j-4, which the band left when it finished chunk j-4 (the 16-step record ring asks for more: chunk j-2).
+    const int w = wave - tWaves;
+    if (w >= nact) return;
+    constexpr int kKT = (8 * tWA + 63) / 64;   // window texels per lane and batch (7)
+    int ta[kKT], td[kKT]; bool tvalid[kKT];
+#pragma unroll
+    for (int k = 0; k < kKT; ++k) { const int t = lane + 64 * k; ta[k] = t >> 3; td[k] = t & 7; tvalid[k] = t < 8 * tWA; }
+    float2* winw = &sm.win[w][0][0];
+    const int v0 = (bandLo + band0 + w) * tRows - kRad;
+    auto win_addr = [&](int b, int k, int& slot) -> const float2* {
+      const int d = 8 * b - 8 + td[k];                     // relative skewed index
+      const int u = uLo + d - ta[k], v = v0 + ta[k];       // absolute sweep-order texel
+      slot = ta[k] * kWCPT + ((u + ta[k]) & (kWC - 1));
+      if (!tvalid[k] || u < 0 || u >= LS || v < 0 || v >= LB) return nullptr;
+      const int cxc = TR ? v : u, cyc = TR ? u : v;
+      const int x = FWD ? cxc : W - 1 - cxc, y = FWD ? cyc : H - 1 - cyc;
+      return g1 + (y * W + x);
+    };
+    auto win_store = [&](int slot, float2 v) {   // ring columns 0 and 1 also go behind column 63
+      winw[slot] = v;
+      if (slot % kWCPT < 2) winw[slot + kWC] = v;
+    };
+    const float4* recw = rec + size_t(band0 + w) * nstepsPad * (tRows * 2);
+    constexpr int kQ = 8 * tRows * 2 / 64;   // a chunk's records: 512 float4, 8 per lane, the ring's layout is the stream's
+    int rh = 0, idle = 0;
+    bool first = true;
+    for (;;) {
+      const int oh = first ? 0 : ld_cnt(&sm.outHead[w]);
+      const bool ld = rh < nsteps && (rh + kChunk - oh <= tRS);
+      float4 q[kQ];
+      float2 wv[kKT]; int ws[kKT]; bool wok[kKT];
+#pragma unroll
+      for (int k = 0; k < kKT; ++k) { wv[k] = make_float2(0.f, 0.f); ws[k] = 0; wok[k] = false; }
+      if (ld) {
+        const float4* src = recw + size_t(rh) * (tRows * 2);
+#pragma unroll
+        for (int k = 0; k < kQ; ++k) q[k] = src[lane + 64 * k];
+        const int b = rh / kChunk + 4;
+#pragma unroll
+        for (int k = 0; k < kKT; ++k) {
+          const float2* p = win_addr(b, k, ws[k]);
+          wok[k] = p != nullptr;
+          if (wok[k]) wv[k] = *p;
+        }
+      }
+      if (first) {
+        float2 pv[4][kKT]; int ps[4][kKT]; bool pk[4][kKT];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int k = 0; k < kKT; ++k) {
+            pv[b][k] = make_float2(0.f, 0.f);
+            const float2* p = win_addr(b, k, ps[b][k]);
+            pk[b][k] = p != nullptr;
+            if (pk[b][k]) pv[b][k] = *p;
+          }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int k = 0; k < kKT; ++k) if (pk[b][k]) win_store(ps[b][k], pv[b][k]);
+        first = false;
+      }
+      if (ld) {
+        float4* d4 = &sm.rec[w][rh % tRS][0][0];
+#pragma unroll
+        for (int k = 0; k < kQ; ++k) d4[lane + 64 * k] = q[k];
+#pragma unroll
+        for (int k = 0; k < kKT; ++k) if (wok[k]) win_store(ws[k], wv[k]);
+        rh += kChunk;
+        st_cnt(&sm.recHead[w], rh);
+        idle = 0;
+      }
+      if (rh >= nsteps) break;
+      if (!ld) {
+        __builtin_amdgcn_s_sleep(4);
+        if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { give_up(); break; }
+      }
+    }
+    return;
+  }
+  if (wave == 2 * tWaves + 2) {
+    // ======================= drainer: results LDS ring -> flow plane =======================
+    int idle = 0;
+    for (;;) {
+      bool progress = false, done = true;
+#pragma unroll
+      for (int w = 0; w < tWaves; ++w) {
+        if (w < nact) {
+          int ot = sm.outTail[w];
+          const int oh = ld_cnt(&sm.outHead[w]);
+          int n = oh - ot; n = n > 8 ? 8 : n;
+          if (n > 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int i = lane + 64 * u, j = i & 7, r = i >> 3, t = ot + j;   // a store covers 8 rows x 8 consecutive columns (64-byte runs)
+              if (j < n) {
+                const float2 val = sm.out[w][t % tOS][r];
+                const int ia = uLo + t - r, ib = (bandLo + band0 + w) * tRows + r;
+                if (t - r >= 0 && t - r < LSv && ib < LB) {
+                  const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;
+                  const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
+                  flow[size_t(y) * W + x] = val;
+                }
+              }
+            }
+            ot += n;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            st_cnt(&sm.outTail[w], ot);
+            progress = true;
+          }
+          if (ot < nsteps) done = false;
+        }
+      }
+      if (done) break;
+      if (progress) idle = 0;
+      else {
+        __builtin_amdgcn_s_sleep(4);
+        if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { give_up(); break; }
+      }
+    }
+    return;
+  }
+  if (wave == 2 * tWaves) {
+    // ======================= publisher: last row of the workgroup -> granules in HBM =======================
+    if (!publishes) return;
+    unsigned long long* bnd_out = boundary + size_t(wg + 1) * LSv;
+    const int wl = tWaves - 1;
+    int pt = 0, idle = 0;
+    while (pt < nsteps) {
+      const int ohl = ld_cnt(&sm.outHead[wl]);
+      int n = ohl - pt; n = n > tOS ? tOS : n;
+      if (n > 0) {
+        const int t = pt + lane;
+        if (lane < n) {
+          const float2 val = sm.out[wl][t % tOS][tRows - 1];
+          const int cx = t - (tRows - 1);
+          if (cx >= 0 && cx < LSv) __hip_atomic_store(bnd_out + cx, pack2(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        pt += n;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        st_cnt(&sm.pubTail, pt);
+        idle = 0;
+      } else {
+        __builtin_amdgcn_s_sleep(PF_PUB_SLEEP);
+        if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { give_up(); break; }
+      }
+    }
+    return;
+  }
+  // ======================= poller: previous workgroup's granules HBM -> LDS ring =======================
+  {
+    if ((wg == 0 && !staticTop) || wave != 2 * tWaves + 1) return;
+    const unsigned long long* bnd_in = boundary + size_t(wg) * LSv;
+    int bh = 0, idle = 0;
+    while (bh < LSv) {
+      const int oh0 = ld_cnt(&sm.outHead[0]);
+      if (bh + 64 - oh0 <= kBS) {
+        unsigned long long g = kNotReady;
+        if (bh + lane < LSv) g = __hip_atomic_load(bnd_in + bh + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ready = (g != kNotReady) || (bh + lane >= LSv);
+        const unsigned long long m = __ballot(ready);
+        const int n = (m == ~0ull) ? 64 : __builtin_ctzll(~m);
+        if (n > 0) {
+          if (lane < n && bh + lane < LSv) sm.bnd[(bh + lane) % kBS] = g;
+          bh += n;
+          st_cnt(&sm.bndHead, bh);
+          idle = 0;
+          continue;
+        }
+        __builtin_amdgcn_s_sleep(PF_POLL_SLEEP);
+      } else {
+        __builtin_amdgcn_s_sleep(8);
+      }
+      if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { give_up(); break; }
+    }
+  }
+}
+
+// host side of the throughput form
+static bool launch_sweep_t(hipStream_t st, const SweepArgs& a, float* rec) {
+  const SweepWindow win = make_sweep_window(a.W, a.H, a.forward, a.ax0, a.ay0, a.ax1, a.ay1, tRows, tWaves, kChunk);
+  if (win.empty) return false;
+  const int tr = win.tr, uLo = win.uLo, uHi = win.uHi, LSv = win.LSv, bandLo = win.bandLo, nbands = win.nbands;
+  const int nwg = win.nwg, nbandsPad = nwg * tWaves, nstepsPad = win.nstepsPad;
+  const size_t total = size_t(nbandsPad) * nstepsPad * tRows;
+  const size_t prepThreads = total > size_t(LSv) ? total : size_t(LSv);
+  const float rW = (float)(1.0 / (double)(float)a.W), rEps = (float)(1.0 / (double)kGradEpsilon);
+  hipExtLaunchKernelGGL((k_sweep_prep<tRows, false>), dim3((unsigned)((prepThreads + 255) / 256), 1, a.bt.n), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate,
+                        a.flow, a.W, a.H, a.forward, tr, nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo,
+                        bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride);
+  const long long budget = 200000000ll + 1000ll * 50ll * (long long)(nstepsPad + 40 * nbands);
+  const dim3 grid(nwg, 1, a.bt.n), block(tThreads);
+  const float4* r4 = reinterpret_cast<const float4*>(rec);
+#define PF_LAUNCH_SWEEP_T(TRV, FWV) hipExtLaunchKernelGGL((k_sweep_t<TRV, FWV>), grid, block, 0, st, nullptr, a.ev_stop, 0, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.bt.stride)
+  if (tr) { if (a.forward) PF_LAUNCH_SWEEP_T(true, true); else PF_LAUNCH_SWEEP_T(true, false); }
+  else { if (a.forward) PF_LAUNCH_SWEEP_T(false, true); else PF_LAUNCH_SWEEP_T(false, false); }
+#undef PF_LAUNCH_SWEEP_T
+  return true;
+}

@@ -50,6 +50,7 @@ struct pf_ctx {
   int prof = 0;   // 0 off, 1 every kernel family, 2 only the dominant family (the sweeps): fewer events in a timed region
   pf_config cfg;  // scheduling knobs (pf_create_cfg); results never depend on them
   bool is_lane = false;   // one of several lanes of pf_novel_view_batch_dev running side by side
+  int lanes_running = 1;  // throughput mode: lanes (this one included) solving batches side by side on the device right now
   long fuse_ups_px = 0;   // levels up to this many pixels get their incoming flow upsampled inside their first Gaussian (0 = never)
   int chain_cols = 0, chain_rows = 0;   // size of the stitch-chain result resident in "ch_final"
   long long last_swept_steps = 0;       // wavefront steps of one direction of the last solve (both sweeps, all levels, gated windows)
@@ -219,6 +220,8 @@ void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, cons
   // workgroup shape (pf_config::sweep_wide): a lone pair never oversubscribes the chip (126 workgroups at 9000x4000) and keeps the latency form
   sa.wide = c->cfg.sweep_wide < 0 ? (bt.n > 1 ? -1 : 0) : c->cfg.sweep_wide;
   sa.wide_threshold_wgs = c->cfg.sweep_wide_threshold;
+  sa.wide_tr = c->cfg.sweep_throughput_transposed;
+  sa.concurrent_sweeps = 2 * bt.n * c->lanes_running;   // both directions of every pair of every lane's batch sweep at the same time
   // Timing a sweep (profile mode 1 or 2) attaches the two events to the launches themselves (hipExtLaunchKernel) instead of
   // recording markers around them.  Same-box A/B, ms per step: no timing 27.38, markers 27.65, attached events 27.60 -- bench.py's
   // roofline needs per-launch HIP events inside its timed region, so ~0.2 ms of every timed step is the measurement itself.
@@ -685,7 +688,7 @@ void pf_config_init(pf_config* cfg) {
   cfg->struct_size = (int)sizeof *cfg;
   cfg->stagger_levels = -1; cfg->fuse_small_level_px = -1; cfg->fine_gradient_blocks = 64; cfg->pyramid_chaining = 1;
   cfg->sweep_window = 1; cfg->sparse_sweep = -1; cfg->sweep_impl = 2; cfg->record_path = 0; cfg->batch_pairs = -1;
-  cfg->sweep_wide = -1; cfg->sweep_wide_threshold = 768; cfg->full_width_batch_gradients = 1;
+  cfg->sweep_wide = -1; cfg->sweep_wide_threshold = 512; cfg->full_width_batch_gradients = 1;
 }
 
 pf_ctx* pf_create(int device, int max_cols, int max_rows) {
@@ -794,7 +797,7 @@ pf_ctx* pf_create_cfg(const pf_config* user) {
 #endif
   if (cfg.batch_pairs == 0 || cfg.batch_pairs < -1 || cfg.batch_pairs > kMaxBatch) { fail(nullptr, PF_ERR_ARG, "pf_create_cfg: batch_pairs must be -1 or 1..%d", kMaxBatch); return nullptr; }
   if (cfg.fine_gradient_blocks < 1 || cfg.stagger_levels < -1 || cfg.fuse_small_level_px < -1 || cfg.sparse_sweep < -1 || cfg.sparse_sweep > 1 ||
-      cfg.sweep_wide < -1 || cfg.sweep_wide > 1 || cfg.sweep_wide_threshold < 0) {
+      cfg.sweep_wide < -1 || cfg.sweep_wide > 2 || cfg.sweep_wide_threshold < 0) {
     fail(nullptr, PF_ERR_ARG, "pf_create_cfg: knob out of range");
     return nullptr;
   }
@@ -997,7 +1000,8 @@ int pf_novel_view_batch_dev(pf_ctx* c, int n_pairs, const uint8_t* const* d_l, c
   std::vector<std::string> msg(nlanes);
   auto run = [&](int k) {
     pf_ctx* lane = k == 0 ? c : c->lanes[k - 1];
-    struct Restore { pf_ctx* l; long v; bool b; ~Restore() { l->fuse_ups_px = v; l->is_lane = b; } } restore{lane, lane->fuse_ups_px, lane->is_lane};
+    struct Restore { pf_ctx* l; long v; bool b; ~Restore() { l->fuse_ups_px = v; l->is_lane = b; l->lanes_running = 1; } } restore{lane, lane->fuse_ups_px, lane->is_lane};
+    lane->lanes_running = nlanes;
     // lanes side by side: launches count more than their length, the small levels fold two kernels into their neighbours (see solve_n()).
     // A batch pays every launch once for all its pairs, and there the separate (shorter) kernels win again: 8 in one batch 1374 vs 1347 Mpix/s.
     if (in_flight > 1) { lane->fuse_ups_px = per_batch > 1 ? 0 : 262144; lane->is_lane = true; }
@@ -1415,7 +1419,8 @@ int pf_stage_sweep(pf_ctx* c, const float* g0, const float* g1, const float* blu
   HIPCHK(c, hipMemsetAsync(pcnt, 0, 2 * size_t(sweep2_num_wgs_max(w, h)) * sizeof(int), sm));
   SweepArgs sa; sa.prepcnt = pcnt; sa.g0 = (const float2*)dg0; sa.g1 = (const float2*)dg1; sa.blurred = (const float2*)dbl; sa.gate = gate; sa.flow = (float2*)df;
   sa.boundary = bnd; sa.ctrl = ctrl; sa.W = w; sa.H = h; sa.forward = forward; sa.sparse = (w * h) % 2;   // stage test: exercise both variants
-  sa.wide = c->cfg.sweep_wide == 1 ? 1 : 0;   // the workgroup shape the context was created for (auto = latency form: one pair)
+  sa.wide = c->cfg.sweep_wide > 0 ? c->cfg.sweep_wide : 0;   // the sweep form the context was created for (auto = latency form: one pair)
+  if (sa.wide == 2) sa.sparse = 0;            // (the throughput form has no sparse variant)
   {
     std::vector<int> box; LevelTable t; t.n = 1; t.w[0] = w; t.h[0] = h; t.off[0] = 0;
     if (int e = gate_boxes_to_host(c, sm, gate, t, n, box)) return e;

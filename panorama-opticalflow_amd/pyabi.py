@@ -35,7 +35,7 @@ class Config(C.Structure):
     """pf_config (include/panoflow.h)"""
     _fields_ = [("struct_size", C.c_int), ("device", C.c_int), ("max_cols", C.c_int), ("max_rows", C.c_int), ("stagger_levels", C.c_int),
                 ("fuse_small_level_px", C.c_int64), ("fine_gradient_blocks", C.c_int), ("pyramid_chaining", C.c_int), ("sweep_window", C.c_int),
-                ("sparse_sweep", C.c_int), ("batch_pairs", C.c_int), ("sweep_wide", C.c_int), ("sweep_wide_threshold", C.c_int),
+                ("sparse_sweep", C.c_int), ("batch_pairs", C.c_int), ("sweep_wide", C.c_int), ("sweep_wide_threshold", C.c_int), ("sweep_throughput_transposed", C.c_int),
                 ("full_width_batch_gradients", C.c_int), ("sweep_impl", C.c_int), ("record_path", C.c_int)]
 
 

@@ -18,6 +18,7 @@ if os.environ.get("TP_STAGGER"): knobs["stagger_levels"] = int(os.environ["TP_ST
 if os.environ.get("TP_FUSE"): knobs["fuse_small_level_px"] = int(os.environ["TP_FUSE"])
 if os.environ.get("TP_WIDE"): knobs["sweep_wide"] = int(os.environ["TP_WIDE"])
 if os.environ.get("TP_WIDE_THR"): knobs["sweep_wide_threshold"] = int(os.environ["TP_WIDE_THR"])
+if os.environ.get("TP_WIDE_TR"): knobs["sweep_throughput_transposed"] = int(os.environ["TP_WIDE_TR"])
 if os.environ.get("TP_GRAD_FULL"): knobs["full_width_batch_gradients"] = int(os.environ["TP_GRAD_FULL"])
 c = pf.Context(0, cols, rows, **knobs)
 call = lambda: c.novel_view_batch_dev([p[0].data_ptr() for p in pairs], [p[1].data_ptr() for p in pairs], cols, rows, 0,
