@@ -688,7 +688,7 @@ void pf_config_init(pf_config* cfg) {
   cfg->struct_size = (int)sizeof *cfg;
   cfg->stagger_levels = -1; cfg->fuse_small_level_px = -1; cfg->fine_gradient_blocks = 64; cfg->pyramid_chaining = 1;
   cfg->sweep_window = 1; cfg->sparse_sweep = -1; cfg->sweep_impl = 2; cfg->record_path = 0; cfg->batch_pairs = -1;
-  cfg->sweep_wide = -1; cfg->sweep_wide_threshold = 512; cfg->full_width_batch_gradients = 1;
+  cfg->sweep_wide = -1; cfg->sweep_wide_threshold = 512; cfg->sweep_throughput_transposed = 1; cfg->full_width_batch_gradients = 1;
 }
 
 pf_ctx* pf_create(int device, int max_cols, int max_rows) {
