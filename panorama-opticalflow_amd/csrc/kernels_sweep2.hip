@@ -238,6 +238,9 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
       const float2* p = g1 + (y0 * W + x0);
       t00 = p[0]; t10 = p[1]; t01 = p[W]; t11 = p[W + 1];
     }
+    // (throughput form: its compute wave has record loads in flight; the wait for these four must sit INSIDE this cold branch, or the
+    // in-order memory counter would make every step wait for the newest record request)
+    if (SKEW) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): a real instruction, so that the compiler's counter tracking knows nothing is pending at the join
   }
   __builtin_amdgcn_sched_barrier(0);
   // ---- B ----
@@ -1345,7 +1348,8 @@ size_t sweep_boundary_elems(int W, int H) {   // hand-off granules a sweep launc
 size_t sweep2_rec_bytes(int W, int H) {
   const size_t a = size_t(wgs_for(H, SwWide::kWaves)) * SwWide::kWaves * steps_pad(W), b = size_t(wgs_for(W, SwWide::kWaves)) * SwWide::kWaves * steps_pad(H);
   // throughput form: bands of 32 rows, three per workgroup, tRows - 1 more steps per band
-  auto t_records = [](int LB, int LS) { const size_t nb = (size_t(LB) + tRows - 1) / tRows, nwg = (nb + tWaves - 1) / tWaves; return nwg * tWaves * tRows * (size_t(LS + tRows - 1 + kChunk - 1) / kChunk * kChunk); };
+  // (12 = a multiple of both workgroup sizes, 3 and 4 bands; + tPre steps that the record-prefetching form reads past the last band's end)
+  auto t_records = [](int LB, int LS) { const size_t nb = (size_t(LB) + tRows - 1) / tRows, nbp = (nb + 11) / 12 * 12; return nbp * tRows * (size_t(LS + tRows - 1 + kChunk - 1) / kChunk * kChunk) + size_t(tPre) * tRows; };
   const size_t t = std::max(t_records(H, W), t_records(W, H));
   return std::max((a > b ? a : b) * kRows * 48, t * 32);
 }
@@ -1404,7 +1408,8 @@ bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
     const SweepWindow win = make_sweep_window(a.W, a.H, a.forward, a.ax0, a.ay0, a.ax1, a.ay1, kRows, SwLatency::kWaves, kChunk);
     wide = (!win.empty && long(win.nwg) * a.concurrent_sweeps > long(a.wide_threshold_wgs) && !a.sparse && (!win.tr || a.wide_tr)) ? 2 : 0;
   }
-  if (wide == 2 && !a.sparse) return launch_sweep_t(st, a, rec);
+  if (wide == 3 && !a.sparse) return launch_sweep_t<false>(st, a, rec);   // (the LDS-record variant of the throughput form: cross-check / A-B)
+  if (wide == 2 && !a.sparse) return launch_sweep_t<true>(st, a, rec);
   return wide == 1 ? launch_sweep2_form<SwWide>(st, a, rec) : launch_sweep2_form<SwLatency>(st, a, rec);
 }
 

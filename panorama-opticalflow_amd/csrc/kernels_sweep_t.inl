@@ -24,19 +24,30 @@
 // large levels); everything else keeps the latency form.
 namespace {
 constexpr int tRows = 32;                       // rows per compute wave
-constexpr int tWaves = 3;                       // compute waves (bands) per workgroup
+// Two ways the records reach a compute wave (template parameter RG of everything below):
+//   RG = false: through an LDS ring filled by the band's loader wave, like the latency form -- 46 KB of LDS per band: THREE bands per workgroup;
+//   RG = true : the compute wave requests its own records six steps ahead with LDS-DMA (global_load_lds_dwordx4: one instruction copies a
+//               step's 32 records = 1 KB straight into an 8-step LDS ring, no registers, no loader; its completion is counted by hand with
+//               s_waitcnt vmcnt -- the compiler does not track it, and with a register destination its conservative vmcnt(0) at every
+//               loop / branch join drained the queue twice per chunk: measured, 0.54 instead of 0.47 us per step) -- 38 KB per band:
+//               FOUR bands (128 rows) per workgroup, one compute wave on every SIMD, and a batch's level-0 launches (8 pairs x 2 directions x
+//               16 workgroups = 256) fit the chip in ONE round instead of 1.3.
+template <bool RG> struct TGeom { static constexpr int kWaves = RG ? 4 : 3; static constexpr int kThreads = 64 * (2 * kWaves + 3); };
+constexpr int tPre = 6;                         // RG: steps a record is requested ahead of its use
+constexpr int tRSG = 8;                         // RG: record ring (steps): tPre in flight + the one being read + one being overwritten
 constexpr int tRS = 16;                         // record ring (steps)
 constexpr int tOS = 16;                         // result ring (steps)
 constexpr int tWA = tRows + 2 * kRad + 1;       // window rows (49)
 constexpr int kWCPT = kWC + 2;                  // window row stride: ring columns 0 and 1 again behind column 63 (the skewed footprint reaches slot + 2)
-constexpr int tThreads = 64 * (2 * tWaves + 3);
 
+template <bool RG>
 struct SmemTF {
-  float4 rec[tWaves][tRS][tRows][2];            // the 32-byte records (I0x, I0y, blurred.x, blurred.y | E(C), C.x, C.y, Ea)
+  static constexpr int tWaves = TGeom<RG>::kWaves;
+  float4 rec[tWaves][RG ? tRSG : tRS][tRows][2];   // the 32-byte records (I0x, I0y, blurred.x, blurred.y | E(C), C.x, C.y, Ea)
   float2 out[tWaves][tOS][tRows];
   float2 win[tWaves][tWA][kWCPT];
   unsigned long long bnd[kBS];
-  int recHead[tWaves], outHead[tWaves], outTail[tWaves];
+  int recHead[tWaves], outHead[tWaves], outTail[tWaves];   // recHead: steps whose records (RG: whose window batches) are in LDS
   int pubTail, bndHead, abort, wg;
   long long deadline;
 };
@@ -95,10 +106,10 @@ __device__ __forceinline__ float2 t_step(const float2* __restrict__ g1, __attrib
 }
 
 // One compute wave of the throughput form: a band of 32 rows.  TOP as in compute_band.
-template <int TOP, bool TR, bool FWD>
-__device__ __forceinline__ bool compute_band_t(SmemTF& sm, const float2* __restrict__ g1, int W, int H, int nsteps, int w, int band, int nact, bool publishes,
-                                               float rW, float rEps, int uLo, int LSv) {
-  constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0;
+template <bool RG, int TOP, bool TR, bool FWD>
+__device__ __forceinline__ bool compute_band_t(SmemTF<RG>& sm, const float2* __restrict__ g1, const float4* __restrict__ recg, int W, int H, int nsteps, int w, int band,
+                                               int nact, bool publishes, float rW, float rEps, int uLo, int LSv) {
+  constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0, tWaves = TGeom<RG>::kWaves;
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, role = lane >> 5;
   const int ib = band * tRows + r;
@@ -128,6 +139,24 @@ __device__ __forceinline__ bool compute_band_t(SmemTF& sm, const float2* __restr
   // step (sweep order; mirrored for the backward sweep); exact small integers in fp32
   const float acrossPos = forward ? float(ib) : float((transposed ? W : H) - 1 - ib);
   float alongU = float(uLo - r);   // sweep-order column of step 0
+  // RG: LDS-DMA of one step's records (64 lanes x 16 bytes = the step's 32 records) into ring slot (step % tRSG).  M0 carries the LDS
+  // destination and is compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md, LDS-DMA recipe).
+  const char* recBytes = reinterpret_cast<const char*>(recg) + lane * 16;
+  const unsigned recLds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&sm.rec[w][0][0][0]);
+  auto dma_step = [&](int step) {
+    const char* gsrc = recBytes + size_t(step) * (tRows * 32);
+    const unsigned dst = recLds + unsigned(step % tRSG) * (tRows * 32);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+  };
+  if (RG) {
+#pragma unroll
+    for (int d = 0; d < tPre; ++d) dma_step(d);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(tPre - 1) : "memory");   // step 0's records have landed
+    const float4* rp0 = &sm.rec[w][0][r][0];
+    ra = rp0[0]; rb = rp0[1];
+    asm volatile("" : "+v"(ra.x), "+v"(ra.y), "+v"(ra.z), "+v"(ra.w), "+v"(rb.x), "+v"(rb.y), "+v"(rb.z), "+v"(rb.w));
+  }
   for (int s0 = 0; s0 < nsteps; s0 += kChunk) {
     if (dead) return false;
     {
@@ -144,7 +173,7 @@ __device__ __forceinline__ bool compute_band_t(SmemTF& sm, const float2* __restr
         if (hasNext) fcNext = ld_cnt(&sm.outHead[w + 1]);
         if (spin_expired(spins, sm) || (((spins & 255) == 0) && ld_cnt(&sm.abort))) return false;
       }
-      if (__builtin_expect(spins != 0 || s0 == 0, 0)) {   // (re)load this chunk's first record: read ahead it was only good if already there
+      if (!RG && __builtin_expect(spins != 0 || s0 == 0, 0)) {   // (re)load this chunk's first record: read ahead it was only good if already there
         const float4* rp0 = &sm.rec[w][s0 % tRS][r][0];
         ra = rp0[0]; rb = rp0[1];
         asm volatile("" : "+v"(ra.x), "+v"(ra.y), "+v"(ra.z), "+v"(ra.w), "+v"(rb.x), "+v"(rb.y), "+v"(rb.z), "+v"(rb.w));
@@ -156,8 +185,8 @@ __device__ __forceinline__ bool compute_band_t(SmemTF& sm, const float2* __restr
     typedef __attribute__((address_space(3))) const f4v lds_f4;
     typedef __attribute__((address_space(3))) f2w lds_wf2;
     typedef __attribute__((address_space(3))) const unsigned long long lds_u64;
-    lds_f4* recChunk = (lds_f4*)&sm.rec[w][s0 % tRS][r][0];
-    lds_f4* recNext = (lds_f4*)&sm.rec[w][(s0 + kChunk) % tRS][r][0];
+    lds_f4* recChunk = (lds_f4*)&sm.rec[w][RG ? 0 : s0 % tRS][r][0];                    // RG: the ring IS one chunk long
+    lds_f4* recNext = (lds_f4*)&sm.rec[w][RG ? 0 : (s0 + kChunk) % tRS][r][0];
     lds_wf2* outChunk = (lds_wf2*)&sm.out[w][s0 % tOS][r];   // (role a stores)
     lds_u64* topChunk = (lds_u64*)((TOP == 1) ? top_slot(s0 + 1) : &sm.bnd[s0 & (kBS - 1)] + 1);
     lds_u64* topNext = (lds_u64*)top_slot(s0 + kChunk);
@@ -166,6 +195,7 @@ __device__ __forceinline__ bool compute_band_t(SmemTF& sm, const float2* __restr
 #pragma unroll
     for (int j = 0; j < kChunk; ++j) {
       const int s = s0 + j;
+      if (RG) dma_step(s + tPre);   // into the slot of step s - 2 (the stream is padded past its end)
       if (j == 5) {
         fcRec = ld_cnt(&sm.recHead[w]); fcTail = ld_cnt(&sm.outTail[w]);
         if (lastPub) fcPub = ld_cnt(&sm.pubTail);
@@ -211,6 +241,8 @@ __device__ __forceinline__ bool compute_band_t(SmemTF& sm, const float2* __restr
       // next step's inputs (LDS), behind the second gather round
       float4 na, nb; int hN = 0; unsigned long long tvN = tv;
       {
+        // RG: steps s+1 .. s+tPre are requested; all but the newest tPre - 1 have landed after this wait, i.e. step s+1 has
+        if (RG) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(tPre - 1) : "memory");
         lds_f4* rpn = (j + 1 < kChunk) ? recChunk + (j + 1) * (tRows * 2) : recNext;
         const f4v q0 = rpn[0]; const f4v q1 = rpn[1];
         na = make_float4(q0.x, q0.y, q0.z, q0.w); nb = make_float4(q1.x, q1.y, q1.z, q1.w);
@@ -241,16 +273,16 @@ __device__ __forceinline__ bool compute_band_t(SmemTF& sm, const float2* __restr
 }
 }  // namespace
 
-template <bool TR, bool FWD>
-__global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
+template <bool RG, bool TR, bool FWD>
+__global__ __launch_bounds__(TGeom<RG>::kThreads) void k_sweep_t(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
                                                       unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H, int nstepsPad, int nbands,
                                                       float rW, float rEps, int uLo, int LSv, int bandLo, long long budgetTicks, size_t bstride) {
   {
     const size_t bo = size_t(blockIdx.z) * bstride;
     PF_BOFF(rec, bo); PF_BOFF(g1, bo); PF_BOFF(flow, bo); PF_BOFF(boundary, bo); PF_BOFF(ctrl, bo);
   }
-  constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0;
-  __shared__ SmemTF sm;
+  constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0, tWaves = TGeom<RG>::kWaves;
+  __shared__ SmemTF<RG> sm;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -277,9 +309,10 @@ __global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__
     const int top = (wave > 0) ? 1 : ((wg > 0 || staticTop) ? 2 : 0);
     const int band = bandLo + band0 + wave;
     bool ok;
-    if (top == 1) ok = compute_band_t<1, TR, FWD>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
-    else if (top == 2) ok = compute_band_t<2, TR, FWD>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
-    else ok = compute_band_t<0, TR, FWD>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
+    const float4* recg = rec + size_t(band0 + wave) * nstepsPad * (tRows * 2);
+    if (top == 1) ok = compute_band_t<RG, 1, TR, FWD>(sm, g1, recg, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
+    else if (top == 2) ok = compute_band_t<RG, 2, TR, FWD>(sm, g1, recg, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
+    else ok = compute_band_t<RG, 0, TR, FWD>(sm, g1, recg, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
     if (!ok) give_up();
     return;
   }
@@ -316,15 +349,18 @@ __global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__
     bool first = true;
     for (;;) {
       const int oh = first ? 0 : ld_cnt(&sm.outHead[w]);
-      const bool ld = rh < nsteps && (rh + kChunk - oh <= tRS);
+      // LDS records: room in the 16-step ring.  RG: the window batch loaded with chunk rh / 8 overwrites the one the band left with chunk rh / 8 - 4
+      const bool ld = rh < nsteps && (rh + kChunk - oh <= (RG ? 32 : tRS));
       float4 q[kQ];
       float2 wv[kKT]; int ws[kKT]; bool wok[kKT];
 #pragma unroll
       for (int k = 0; k < kKT; ++k) { wv[k] = make_float2(0.f, 0.f); ws[k] = 0; wok[k] = false; }
       if (ld) {
-        const float4* src = recw + size_t(rh) * (tRows * 2);
+        if (!RG) {
+          const float4* src = recw + size_t(rh) * (tRows * 2);
 #pragma unroll
-        for (int k = 0; k < kQ; ++k) q[k] = src[lane + 64 * k];
+          for (int k = 0; k < kQ; ++k) q[k] = src[lane + 64 * k];
+        }
         const int b = rh / kChunk + 4;
 #pragma unroll
         for (int k = 0; k < kKT; ++k) {
@@ -351,9 +387,11 @@ __global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__
         first = false;
       }
       if (ld) {
-        float4* d4 = &sm.rec[w][rh % tRS][0][0];
+        if (!RG) {
+          float4* d4 = &sm.rec[RG ? 0 : w][RG ? 0 : rh % tRS][0][0];
 #pragma unroll
-        for (int k = 0; k < kQ; ++k) d4[lane + 64 * k] = q[k];
+          for (int k = 0; k < kQ; ++k) d4[lane + 64 * k] = q[k];
+        }
 #pragma unroll
         for (int k = 0; k < kKT; ++k) if (wok[k]) win_store(ws[k], wv[k]);
         rh += kChunk;
@@ -467,7 +505,9 @@ __global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__
 }
 
 // host side of the throughput form
+template <bool RG>
 static bool launch_sweep_t(hipStream_t st, const SweepArgs& a, float* rec) {
+  constexpr int tWaves = TGeom<RG>::kWaves;
   const SweepWindow win = make_sweep_window(a.W, a.H, a.forward, a.ax0, a.ay0, a.ax1, a.ay1, tRows, tWaves, kChunk);
   if (win.empty) return false;
   const int tr = win.tr, uLo = win.uLo, uHi = win.uHi, LSv = win.LSv, bandLo = win.bandLo, nbands = win.nbands;
@@ -479,9 +519,9 @@ static bool launch_sweep_t(hipStream_t st, const SweepArgs& a, float* rec) {
                         a.flow, a.W, a.H, a.forward, tr, nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo,
                         bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride);
   const long long budget = 200000000ll + 1000ll * 50ll * (long long)(nstepsPad + 40 * nbands);
-  const dim3 grid(nwg, 1, a.bt.n), block(tThreads);
+  const dim3 grid(nwg, 1, a.bt.n), block(TGeom<RG>::kThreads);
   const float4* r4 = reinterpret_cast<const float4*>(rec);
-#define PF_LAUNCH_SWEEP_T(TRV, FWV) hipExtLaunchKernelGGL((k_sweep_t<TRV, FWV>), grid, block, 0, st, nullptr, a.ev_stop, 0, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.bt.stride)
+#define PF_LAUNCH_SWEEP_T(TRV, FWV) hipExtLaunchKernelGGL((k_sweep_t<RG, TRV, FWV>), grid, block, 0, st, nullptr, a.ev_stop, 0, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.bt.stride)
   if (tr) { if (a.forward) PF_LAUNCH_SWEEP_T(true, true); else PF_LAUNCH_SWEEP_T(true, false); }
   else { if (a.forward) PF_LAUNCH_SWEEP_T(false, true); else PF_LAUNCH_SWEEP_T(false, false); }
 #undef PF_LAUNCH_SWEEP_T

@@ -797,7 +797,7 @@ pf_ctx* pf_create_cfg(const pf_config* user) {
 #endif
   if (cfg.batch_pairs == 0 || cfg.batch_pairs < -1 || cfg.batch_pairs > kMaxBatch) { fail(nullptr, PF_ERR_ARG, "pf_create_cfg: batch_pairs must be -1 or 1..%d", kMaxBatch); return nullptr; }
   if (cfg.fine_gradient_blocks < 1 || cfg.stagger_levels < -1 || cfg.fuse_small_level_px < -1 || cfg.sparse_sweep < -1 || cfg.sparse_sweep > 1 ||
-      cfg.sweep_wide < -1 || cfg.sweep_wide > 2 || cfg.sweep_wide_threshold < 0) {
+      cfg.sweep_wide < -1 || cfg.sweep_wide > 3 || cfg.sweep_wide_threshold < 0) {
     fail(nullptr, PF_ERR_ARG, "pf_create_cfg: knob out of range");
     return nullptr;
   }

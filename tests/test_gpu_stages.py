@@ -8,12 +8,12 @@ pytestmark = pytest.mark.gpu
 rng = np.random.default_rng(11)
 
 
-@pytest.fixture(scope="module", params=["latency", "wide", "throughput"])
+@pytest.fixture(scope="module", params=["latency", "wide", "throughput", "throughput_lds"])
 def ctx(pf, request):
     """Every stage test runs with every form of the sweep (pf_config::sweep_wide): the latency form a lone pair uses (8 lanes per pixel),
     the same step with two compute waves per SIMD ("wide"), and the throughput form of the batch mode (2 lanes per pixel, bands of 32
     rows, non-speculative two-round step, skewed gather window)."""
-    c = pf.Context(0, sweep_wide={"latency": 0, "wide": 1, "throughput": 2}[request.param])
+    c = pf.Context(0, sweep_wide={"latency": 0, "wide": 1, "throughput": 2, "throughput_lds": 3}[request.param])
     yield c
     c.close()
 
