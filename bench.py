@@ -452,8 +452,8 @@ def main():
             ctx.close()
             sc, sr = 2000, 4000
             os_ = torch.empty((sr, sc, 4), dtype=torch.uint8, device=dev)
-            # ---- throughput mode (never `value`): 16 independent strips in flight on this GPU (two lanes; a batch of 8 pairs shares every
-            # kernel launch), through the C ABI's batch entry ----
+            # ---- throughput mode (never `value`): 16 independent strips in flight on this GPU (one batch: the 16 pairs share every kernel
+            # launch), through the C ABI's batch entry ----
             nb, infl = 16, 16
             pairs_b = [synth.make_pair(sc, sr, 5000 + i, dev) for i in range(nb)]
             outs_b = [torch.empty_like(os_) for _ in range(nb)]
@@ -467,39 +467,29 @@ def main():
                 t1 = time.perf_counter(); call_b(); tbs.append(time.perf_counter() - t1)
             tb = statistics.median(tbs)
             res["throughput_mode"] = {"value": round(nb * sc * sr / 1e6 / tb, 3), "unit": "Mpix/s", "pairs": nb, "in_flight": infl, "entry": "pf_novel_view_batch_dev",
-                                      "workload": "16 independent 2000x4000 strips in flight: two lanes, 8 strips through each set of launches (blockIdx.z = pair)", "runs": 3, "warmup": 1, "statistic": "median",
+                                      "workload": "16 independent 2000x4000 strips in flight: one batch, all 16 through each set of launches (blockIdx.z = pair)", "runs": 3, "warmup": 1, "statistic": "median",
                                       "note": "several independent pairs side by side on one GPU; an extra figure, not the per-GPU workload `value` is quoted on"}
             del pairs_b, outs_b, os_
             ct.close()
             torch.cuda.empty_cache()
-            # ... and the same on the per-GPU workload's size: 8 dense 9000x4000 pairs through one set of launches
-            nb2 = 8
-            pairs_c = [synth.make_pair(cols, rows, 6000 + i, dev)[:3] for i in range(nb2)]
-            outs_c = [torch.empty((rows, cols, 4), dtype=torch.uint8, device=dev) for _ in range(nb2)]
-            torch.cuda.synchronize()
+            # ... and the same on the per-GPU workload's size: dense 9000x4000 pairs, 8 in flight (one batch: the round-3 figure's configuration),
+            # 16 (one batch of 16) and 32 (two lanes x 16: where the chip saturates)
+            pairs_c, outs_c = [], []
             ct = pf.Context(local_rank)
-            call_c = lambda: ct.novel_view_batch_dev([p[0].data_ptr() for p in pairs_c], [p[1].data_ptr() for p in pairs_c], cols, rows, max_pct,
-                                                      [p[2].data_ptr() for p in pairs_c], [o.data_ptr() for o in outs_c], None, None, in_flight=nb2)
-            call_c()
-            tcs = []
-            for _ in range(3):
-                t1 = time.perf_counter(); call_c(); tcs.append(time.perf_counter() - t1)
-            tcm = statistics.median(tcs)
-            res["throughput_mode"]["pairs_%dx%d" % (cols, rows)] = {"value": round(nb2 * mpix / tcm, 3), "unit": "Mpix/s", "pairs": nb2, "in_flight": nb2, "runs": 3, "warmup": 1,
-                                                                     "statistic": "median", "roofline_path_frac": round(nb2 * b_alg / tcm / 8e12, 6)}
-            # ... and 16 of them in flight (two lanes x one batch of 8): what the chip saturates at
-            pairs_c += [synth.make_pair(cols, rows, 6000 + i, dev)[:3] for i in range(nb2, 2 * nb2)]
-            outs_c += [torch.empty((rows, cols, 4), dtype=torch.uint8, device=dev) for _ in range(nb2)]
-            torch.cuda.synchronize()
-            call_d = lambda: ct.novel_view_batch_dev([p[0].data_ptr() for p in pairs_c], [p[1].data_ptr() for p in pairs_c], cols, rows, max_pct,
-                                                      [p[2].data_ptr() for p in pairs_c], [o.data_ptr() for o in outs_c], None, None, in_flight=2 * nb2)
-            call_d()
-            tds = []
-            for _ in range(3):
-                t1 = time.perf_counter(); call_d(); tds.append(time.perf_counter() - t1)
-            tdm = statistics.median(tds)
-            res["throughput_mode"]["pairs_%dx%d_16_in_flight" % (cols, rows)] = {"value": round(2 * nb2 * mpix / tdm, 3), "unit": "Mpix/s", "pairs": 2 * nb2, "in_flight": 2 * nb2, "runs": 3,
-                                                                                  "warmup": 1, "statistic": "median", "roofline_path_frac": round(2 * nb2 * b_alg / tdm / 8e12, 6)}
+            for nfl in (8, 16, 32):
+                pairs_c += [synth.make_pair(cols, rows, 6000 + i, dev)[:3] for i in range(len(pairs_c), nfl)]
+                outs_c += [torch.empty((rows, cols, 4), dtype=torch.uint8, device=dev) for _ in range(len(outs_c), nfl)]
+                torch.cuda.synchronize()
+                call_c = lambda: ct.novel_view_batch_dev([p[0].data_ptr() for p in pairs_c], [p[1].data_ptr() for p in pairs_c], cols, rows, max_pct,
+                                                          [p[2].data_ptr() for p in pairs_c], [o.data_ptr() for o in outs_c], None, None, in_flight=nfl)
+                call_c()
+                tcs = []
+                for _ in range(3):
+                    t1 = time.perf_counter(); call_c(); tcs.append(time.perf_counter() - t1)
+                tcm = statistics.median(tcs)
+                key = "pairs_%dx%d" % (cols, rows) + ("" if nfl == 8 else "_%d_in_flight" % nfl)
+                res["throughput_mode"][key] = {"value": round(nfl * mpix / tcm, 3), "unit": "Mpix/s", "pairs": nfl, "in_flight": nfl, "runs": 3, "warmup": 1,
+                                               "statistic": "median", "roofline_path_frac": round(nfl * b_alg / tcm / 8e12, 6)}
             del pairs_c, outs_c
             ct.close()
             torch.cuda.empty_cache()

@@ -60,8 +60,8 @@ typedef struct pf_config {
   int pyramid_chaining;     /* 1: small pyramid levels are built two or three per launch, 0: one launch per level (1) */
   int sweep_window;         /* 1: a sweep covers the bounding box of the gated pixels only, 0: the whole level (1) */
   int sparse_sweep;         /* -1: pick the sweep variant that skips ungated anti-diagonals from the gate density, 0 / 1: force (-1) */
-  int batch_pairs;          /* throughput mode (pf_novel_view_batch_dev): pairs that go through ONE set of launches (1..8; in_flight =
-                               lanes x batch_pairs).  -1: in_flight itself up to 8 (one lane), half of it (two lanes) beyond */
+  int batch_pairs;          /* throughput mode (pf_novel_view_batch_dev): pairs that go through ONE set of launches (1..16; in_flight =
+                               lanes x batch_pairs, at most 32).  -1: in_flight itself up to 16 (one lane), half of it (two lanes) beyond */
   int sweep_wide;           /* form of the sweep launches.  0 = latency form: 8 lanes per pixel evaluate a step's six energies at once, bands of 8 rows,
                                ONE compute wave per SIMD -- the shortest step, what a lone pair wants.  2 = throughput form: 2 lanes per pixel, the
                                reference's own order without speculation (two gather rounds per step), bands of 32 rows -- less than half the VALU

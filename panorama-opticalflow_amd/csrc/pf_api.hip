@@ -984,7 +984,7 @@ int pf_novel_view_batch_dev(pf_ctx* c, int n_pairs, const uint8_t* const* d_l, c
   if (int e = use(c)) return e;
   if (n_pairs < 0 || !d_l || !d_r || !d_blend || !d_out) return fail(c, PF_ERR_ARG, "bad argument");
   if (in_flight < 1) in_flight = 1;
-  if (in_flight > 16) in_flight = 16;
+  if (in_flight > 2 * kMaxBatch) in_flight = 2 * kMaxBatch;
   if (in_flight > n_pairs) in_flight = n_pairs > 0 ? n_pairs : 1;
   int nlanes = 1, per_batch = 1;
   batch_split(c, in_flight, nlanes, per_batch);

@@ -79,7 +79,7 @@ __device__ __forceinline__ void d_resize_linear_px(const float* __restrict__ src
 // working buffers lie in identically laid-out slabs `stride` bytes apart, so a kernel reaches pair z's copy of ANY internal buffer
 // by adding z * stride to the pointer it was given for pair 0 (blockIdx.z = pair; kernels that already use z for planes keep the
 // plane in its low bits).  Caller-owned buffers (input images, blend ramp, outputs) come as per-pair pointer tables instead.
-constexpr int kMaxBatch = 8;
+constexpr int kMaxBatch = 16;
 struct Batch { int n = 1; size_t stride = 0; };
 struct ExtPtrs { const void* p[kMaxBatch]; };   // caller-owned buffers of the pairs of a batch (read-only or written, by use)
 #define PF_BOFF(ptr, off) (ptr = reinterpret_cast<decltype(ptr)>(reinterpret_cast<uintptr_t>(ptr) + (off)))

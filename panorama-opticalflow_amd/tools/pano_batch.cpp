@@ -13,7 +13,7 @@
 // the device checksum of the recomputed strip to equal the one recorded for the timed strip, downloads it and compares its SHA-256
 // with DIR/dense_<size>.sha256.txt (the oracle's blended strip for that seed).  "golden_pairs_ok" in the JSON line; exit code 1 on a miss.
 //
-// -in_flight K (1..8, default 1): with more pairs than GPUs, each GPU solves K of its pairs through ONE set of kernel launches per
+// -in_flight K (1..16, default 1): with more pairs than GPUs, each GPU solves K of its pairs through ONE set of kernel launches per
 // round (pf_novel_view_batch_dev: the exact sweeps of a lone pair leave most of the chip idle) and sends them as one block.
 //
 // Inputs are synthetic (textured pair with a smooth displacement, alpha holes at the edges) generated on the host per
@@ -136,7 +136,7 @@ bool parse(int argc, char** argv, Args& a) {
     }
     else return false;
   }
-  return a.pairs > 0 && a.cols > 0 && a.rows > 0 && a.in_flight >= 1 && a.in_flight <= 8;
+  return a.pairs > 0 && a.cols > 0 && a.rows > 0 && a.in_flight >= 1 && a.in_flight <= 16;
 }
 
 // deterministic synthetic pair: three sinusoid layers per channel, L = T(x + d/2), R = 1.05 T(x - d/2)
@@ -235,7 +235,7 @@ void worker(Shared* s, int dev) {
     while (count < K && pano_batch::pair_of_k(j, dev, count, a.pairs, ndev, K) >= 0) ++count;
     if (count > 0) {
       const size_t k0 = size_t(j) * K;   // my pairs number k0 .. k0 + count - 1 are handled in round j
-      const float* blends[8]; uint8_t* outs[8];
+      const float* blends[16]; uint8_t* outs[16];
       for (int q = 0; q < count; ++q) { blends[q] = static_cast<const float*>(dBlend); outs[q] = reinterpret_cast<uint8_t*>(out + size_t(q) * ib); }
       const int rc = count == 1
           ? pf_novel_view_dev(ctx, dL[k0], dR[k0], a.cols, a.rows, s->max_pct, blends[0], outs[0], nullptr, nullptr)
@@ -278,7 +278,7 @@ void worker(Shared* s, int dev) {
 
 int main(int argc, char** argv) {
   Shared s;
-  if (!parse(argc, argv, s.a)) { fprintf(stderr, "usage: pano_batch -pairs P -size COLSxROWS -flow_alg pixflow_low|pixflow_search_20 [-gpus N] [-verify 0|1] [-in_flight 1..8]\n"); return 2; }
+  if (!parse(argc, argv, s.a)) { fprintf(stderr, "usage: pano_batch -pairs P -size COLSxROWS -flow_alg pixflow_low|pixflow_search_20 [-gpus N] [-verify 0|1] [-in_flight 1..16] [-golden DIR]\n"); return 2; }
   s.max_pct = pf_max_percentage_by_name(s.a.alg.c_str());
   if (s.max_pct < 0) { fprintf(stderr, "%s\n", pf_last_error(nullptr)); return 1; }
   const int have = pf_device_count();

@@ -23,7 +23,7 @@ def _fetch(c, d, cols, rows):
             c.download(np.empty((rows, cols, 2), np.float32), d["f1"]))
 
 
-@pytest.mark.parametrize("in_flight,batch_pairs,wide", [(4, -1, -1), (6, -1, -1), (6, 1, -1), (5, 5, -1), (7, 2, -1), (8, 8, -1), (8, 8, 1), (5, 5, 1), (6, 3, 1), (8, 8, 2), (5, 5, 2), (6, 3, 2)])
+@pytest.mark.parametrize("in_flight,batch_pairs,wide", [(4, -1, -1), (6, -1, -1), (6, 1, -1), (5, 5, -1), (7, 2, -1), (8, 8, -1), (8, 8, 1), (5, 5, 1), (6, 3, 1), (8, 8, 2), (5, 5, 2), (6, 3, 2), (12, 12, 2), (12, 12, -1), (7, 7, 3)])
 def test_batch_entry_point_equals_single_calls(pf, synth, in_flight, batch_pairs, wide):
     """pf_novel_view_batch_dev = lanes x batches: pairs of a batch share every kernel launch (blockIdx.z = pair, slab buffers, one
     sweep window = the union of the pairs' windows), lanes run side by side.  Whatever the split -- also with a ragged last batch,
@@ -31,7 +31,7 @@ def test_batch_entry_point_equals_single_calls(pf, synth, in_flight, batch_pairs
     wide = 1 / 2: every sweep launch of the batch in the wide workgroup shape / in the throughput form (pf_config::sweep_wide; by default
     only launches that oversubscribe the chip take the throughput form), held against single calls in the latency form."""
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-    cols, rows, n = 1000, 1400, 7
+    cols, rows, n = 1000, 1400, (12 if in_flight > 8 else 7)
     c = pf.Context(0, batch_pairs=batch_pairs, sweep_wide=wide)
     ref_ctx = pf.Context(0, sweep_wide=0)
     pairs = [_dev_pair(pf, c, synth, cols, rows, 100 + i) for i in range(n)]
