@@ -183,7 +183,7 @@ int pf_blend_dev(pf_ctx* ctx, const uint8_t* d_l, const uint8_t* d_r, const floa
 int pf_novel_view_dev(pf_ctx* ctx, const uint8_t* d_l, const uint8_t* d_r, int cols, int rows, int max_percentage,
                       const float* d_blend, uint8_t* d_out, float* d_flow_l2r, float* d_flow_r2l);
 
-/* Throughput mode: n_pairs independent pairs of one size, `in_flight` (1..16) of them on this GPU at a time (the exact sweeps of one
+/* Throughput mode: n_pairs independent pairs of one size, `in_flight` (1..32) of them on this GPU at a time (the exact sweeps of one
  * pair are a dependency chain that occupies ~1/4 of the CUs): batches of pairs that share every kernel launch, on one or more
  * lanes of streams (pf_config::batch_pairs).  Arrays of n_pairs device pointers; d_flow_* may be NULL (or hold NULL entries).
  * Same results as n_pairs calls of pf_novel_view_dev.  Needs GPU_MAX_HW_QUEUES >= 3 * lanes + 2 in the environment before the
