@@ -65,9 +65,10 @@ typedef struct pf_config {
   int sweep_wide;           /* form of the sweep launches.  0 = latency form: 8 lanes per pixel evaluate a step's six energies at once, bands of 8 rows,
                                ONE compute wave per SIMD -- the shortest step, what a lone pair wants.  2 = throughput form: 2 lanes per pixel, the
                                reference's own order without speculation (two gather rounds per step), bands of 32 rows -- less than half the VALU
-                               instructions per pixel, what a batch that oversubscribes the chip wants.  1 = the latency form's step with two compute
-                               waves per SIMD (measured: no gain, kept as a cross-check).  -1 (default) = throughput form for the launches of a batch
-                               that ask for more latency-form workgroups than sweep_wide_threshold, latency form otherwise.  Same bits in every form. */
+                               instructions per pixel, what a batch that oversubscribes the chip wants.  -1 (default) = throughput form for the launches of a
+                               batch that oversubscribe the chip (sweep_wide_threshold), latency form otherwise.  Same bits in every form.
+                               (1 = the latency step with two compute waves per SIMD, 3 = the throughput form with loader-staged records: measured
+                               and rejected, lab build only -- libpanoflow.so answers PF_ERR_ARG.) */
   int sweep_wide_threshold; /* sweep_wide = -1: a launch takes the throughput form when (sweeps running at the same time: pairs of the batch x 2
                                directions x lanes) x (its latency-form workgroups) exceeds this (512: two rounds of the chip) */
   int sweep_throughput_transposed; /* sweep_wide = -1: sweeps whose bands step along y (windows taller than wide, e.g. 2000x4000 strips) may take the

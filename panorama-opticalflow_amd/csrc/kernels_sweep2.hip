@@ -1408,9 +1408,14 @@ bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
     const SweepWindow win = make_sweep_window(a.W, a.H, a.forward, a.ax0, a.ay0, a.ax1, a.ay1, kRows, SwLatency::kWaves, kChunk);
     wide = (!win.empty && long(win.nwg) * a.concurrent_sweeps > long(a.wide_threshold_wgs) && !a.sparse && (!win.tr || a.wide_tr)) ? 2 : 0;
   }
-  if (wide == 3 && !a.sparse) return launch_sweep_t<false>(st, a, rec);   // (the LDS-record variant of the throughput form: cross-check / A-B)
   if (wide == 2 && !a.sparse) return launch_sweep_t<true>(st, a, rec);
-  return wide == 1 ? launch_sweep2_form<SwWide>(st, a, rec) : launch_sweep2_form<SwLatency>(st, a, rec);
+#ifdef PF_EXPERIMENTS
+  // measured-and-rejected forms, lab build only (profiles/r04_wide_sweep.txt, r04_throughput_form.txt): the latency step with two compute
+  // waves per SIMD, and the throughput form with loader-staged records (three bands per workgroup)
+  if (wide == 3 && !a.sparse) return launch_sweep_t<false>(st, a, rec);
+  if (wide == 1) return launch_sweep2_form<SwWide>(st, a, rec);
+#endif
+  return launch_sweep2_form<SwLatency>(st, a, rec);
 }
 
 #ifdef PF_EXPERIMENTS

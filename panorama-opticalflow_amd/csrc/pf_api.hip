@@ -790,8 +790,8 @@ pf_ctx* pf_create_cfg(const pf_config* user) {
   if (cfg.sweep_impl != 1 && cfg.sweep_impl != 3) cfg.sweep_impl = 2;
   if (cfg.record_path < 0 || cfg.record_path > 2) cfg.record_path = 0;
 #else
-  if (cfg.sweep_impl != 2 || cfg.record_path != 0) {
-    fail(nullptr, PF_ERR_ARG, "sweep_impl / record_path select cross-check implementations that only the -DPF_EXPERIMENTS build (libpanoflow_exp.so) contains");
+  if (cfg.sweep_impl != 2 || cfg.record_path != 0 || cfg.sweep_wide == 1 || cfg.sweep_wide == 3) {
+    fail(nullptr, PF_ERR_ARG, "sweep_impl / record_path / sweep_wide 1 and 3 select cross-check implementations that only the -DPF_EXPERIMENTS build (libpanoflow_exp.so) contains");
     return nullptr;
   }
 #endif

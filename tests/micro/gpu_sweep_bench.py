@@ -3,7 +3,8 @@ import sys, os, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from conftest import load_pkg_module
 pf = load_pkg_module("pyabi")
-ctx = pf.Context(0, sweep_wide=int(os.environ.get("SW_WIDE", "0")))
+_form = int(os.environ.get("SW_WIDE", "0"))
+ctx = pf.Context(0, exp=_form in (1, 3), sweep_wide=_form)   # forms 1 and 3 live in the lab build only
 ctx.profile_enable(True)
 r = np.random.default_rng(0)
 shapes = [(4000, 8), (4000, 32), (4000, 64), (1100, 2000), (2000, 1100), (300, 500)]

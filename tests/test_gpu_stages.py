@@ -13,7 +13,8 @@ def ctx(pf, request):
     """Every stage test runs with every form of the sweep (pf_config::sweep_wide): the latency form a lone pair uses (8 lanes per pixel),
     the same step with two compute waves per SIMD ("wide"), and the throughput form of the batch mode (2 lanes per pixel, bands of 32
     rows, non-speculative two-round step, skewed gather window)."""
-    c = pf.Context(0, sweep_wide={"latency": 0, "wide": 1, "throughput": 2, "throughput_lds": 3}[request.param])
+    form = {"latency": 0, "wide": 1, "throughput": 2, "throughput_lds": 3}[request.param]
+    c = pf.Context(0, exp=form in (1, 3), sweep_wide=form)   # forms 1 and 3 (measured and rejected) only exist in the lab build
     yield c
     c.close()
 
@@ -323,6 +324,9 @@ def test_product_library_ships_one_sweep(pf):
         pf.Context(0, sweep_impl=1)
     with pytest.raises(pf.PanoflowError, match="PF_EXPERIMENTS"):
         pf.Context(0, record_path=2)
+    for form in (1, 3):   # the rejected sweep forms of round 4
+        with pytest.raises(pf.PanoflowError, match="PF_EXPERIMENTS"):
+            pf.Context(0, sweep_wide=form)
     blob = open(pf.SO_PATH, "rb").read()
     assert b"PANOFLOW_" not in blob and b"k_sweep_relax" not in blob
     assert b"k_sweep_relax" in open(pf.SO_PATH_EXP, "rb").read()

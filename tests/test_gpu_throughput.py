@@ -32,7 +32,7 @@ def test_batch_entry_point_equals_single_calls(pf, synth, in_flight, batch_pairs
     only launches that oversubscribe the chip take the throughput form), held against single calls in the latency form."""
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     cols, rows, n = 1000, 1400, (12 if in_flight > 8 else 7)
-    c = pf.Context(0, batch_pairs=batch_pairs, sweep_wide=wide)
+    c = pf.Context(0, exp=wide in (1, 3), batch_pairs=batch_pairs, sweep_wide=wide)   # forms 1 and 3 only exist in the lab build
     ref_ctx = pf.Context(0, sweep_wide=0)
     pairs = [_dev_pair(pf, c, synth, cols, rows, 100 + i) for i in range(n)]
     # pair 2: an extra hole in the alpha of both images -> a different gate / bounding box than its batch mates
