@@ -125,3 +125,30 @@ def test_batches_of_changing_size_on_one_context(pf, synth):
             for k in d.values():
                 c.dev_free(k)
     c.close(); ref_ctx.close()
+
+
+def test_throughput_form_soak_is_deterministic(pf, synth):
+    """The throughput form's compute waves request their records by LDS-DMA and count the completions by hand (kernels_sweep_t.inl):
+    a miscounted wait would show up as a rare wrong record, not as a steady failure.  40 batches of 8 pairs with every sweep in that
+    form (sweep_wide = 2), plus 6 batches of four 4000x2400 pairs (several workgroups per sweep, granule hand-offs): every output must
+    equal the first batch's, which must equal single calls in the latency form."""
+    import hashlib
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    for (cols, rows, n, reps) in ((1000, 1400, 8, 40), (4000, 2400, 4, 6)):
+        c = pf.Context(0, sweep_wide=2)
+        ref_ctx = pf.Context(0, sweep_wide=0)
+        pairs = [_dev_pair(pf, c, synth, cols, rows, 500 + i) for i in range(n)]
+        want = []
+        for d in pairs:
+            ref_ctx.novel_view_dev(d["L"], d["R"], cols, rows, 0, d["b"], d["o"], d["f0"], d["f1"])
+            want.append(tuple(hashlib.sha256(a.tobytes()).hexdigest() for a in _fetch(ref_ctx, d, cols, rows)))
+        ref_ctx.close()
+        for rep in range(reps):
+            c.novel_view_batch_dev([d["L"] for d in pairs], [d["R"] for d in pairs], cols, rows, 0, [d["b"] for d in pairs], [d["o"] for d in pairs],
+                                   [d["f0"] for d in pairs], [d["f1"] for d in pairs], in_flight=n)
+            got = [tuple(hashlib.sha256(a.tobytes()).hexdigest() for a in _fetch(c, d, cols, rows)) for d in pairs]
+            assert got == want, "repetition %d of %dx%d differs" % (rep, cols, rows)
+        for d in pairs:
+            for k in d.values():
+                c.dev_free(k)
+        c.close()
