@@ -35,27 +35,64 @@ __device__ __forceinline__ float2 d_gradient_px(const float* __restrict__ img, i
   float oy = k0 * ty[1] + 0.0f; oy += k1 * (ty[2] + ty[0]);
   return make_float2(ox, oy);
 }
+// The same pixel away from the border (2 <= x < w - 2, 2 <= y < h - 2): every reflect / replicate is the identity, so the 21 values of
+// the 5 x 5 neighbourhood (minus its corners) are loaded once and the same expressions applied in the same order -- identical bits,
+// ~90 instead of ~250 instructions (the index clamps and the 33 partly repeated loads were most of the general form; measured with
+// SQ_INSTS_VALU: this kernel took 8.7 % of a batch's vector instructions, profiles/r04_batch_instruction_counts.txt).
+__device__ __forceinline__ float2 d_gradient_px_interior(const float* __restrict__ img, int w, int x, int y, const Gauss& g) {
+  const float k0 = g.k[1], k1 = g.k[2];
+  const float* c = img + size_t(y) * w + x;
+  float v[5][5];   // v[r][q] = I(y - 2 + r, x - 2 + q); the four corners are not needed
+#pragma unroll
+  for (int r = 0; r < 5; ++r)
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      if (!((r == 0 || r == 4) && (q == 0 || q == 4))) v[r][q] = c[(r - 2) * w + (q - 2)];
+  float tx[3], ty[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float sx[3], sy[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      sx[i] = v[j + 1][i + 2] - v[j + 1][i];       // I(yy, xx + 1) - I(yy, xx - 1)
+      sy[i] = v[j + 2][i + 1] - v[j][i + 1];       // I(yy + 1, xx) - I(yy - 1, xx)
+    }
+    tx[j] = sx[1] * k0 + (sx[0] + sx[2]) * k1;
+    ty[j] = sy[1] * k0 + (sy[0] + sy[2]) * k1;
+  }
+  float ox = k0 * tx[1] + 0.0f; ox += k1 * (tx[2] + tx[0]);
+  float oy = k0 * ty[1] + 0.0f; oy += k1 * (ty[2] + ty[0]);
+  return make_float2(ox, oy);
+}
+__device__ __forceinline__ float2 d_gradient_any(const float* __restrict__ img, int w, int h, int x, int y, const Gauss& g) {
+  return (x >= 2 && x < w - 2 && y >= 2 && y < h - 2) ? d_gradient_px_interior(img, w, x, y, g) : d_gradient_px(img, w, h, x, y, g);
+}
 __global__ __launch_bounds__(256) void k_gradients(const float* __restrict__ img, int w, int h, float2* __restrict__ gxy, Gauss g) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= w) return;
-  gxy[size_t(y) * w + x] = d_gradient_px(img, w, h, x, y, g);
+  gxy[size_t(y) * w + x] = d_gradient_any(img, w, h, x, y, g);
 }
 // All pyramid levels of both images in ONE launch (the per-level launches of the small levels are pure launch latency):
 // a thread's flat index inside the pyramid plane -> level by binary search in the offset table -> (x, y).
 __global__ __launch_bounds__(256) void k_gradients_all(const float* __restrict__ img0, const float* __restrict__ img1, float2* __restrict__ g0,
                                                        float2* __restrict__ g1, LevelTable t, unsigned first, unsigned total, Gauss g, size_t bstride) {
   { const size_t bo = size_t(blockIdx.z) * bstride; PF_BOFF(img0, bo); PF_BOFF(img1, bo); PF_BOFF(g0, bo); PF_BOFF(g1, bo); }
-  // elements [first, total) of the pyramid plane; grid-stride, so that a launch can be made with few blocks on purpose
-  for (unsigned i = first + blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  // elements [first, total) of the pyramid plane; grid-stride, so that a launch can be made with few blocks on purpose.  The level
+  // is searched once per block and chunk (scalar instructions on the kernel arguments); only a chunk that runs into the next level
+  // makes its threads step on.
+  for (unsigned base = first + blockIdx.x * blockDim.x; base < total; base += gridDim.x * blockDim.x) {
+    const unsigned i = base + threadIdx.x;
+    if (i >= total) continue;
     int lo = 0, hi = t.n - 1;
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (i >= t.off[mid]) lo = mid; else hi = mid - 1; }
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (base >= t.off[mid]) lo = mid; else hi = mid - 1; }
+    while (lo + 1 < t.n && i >= t.off[lo + 1]) ++lo;
     const int w = t.w[lo], h = t.h[lo];
     const unsigned local = i - t.off[lo];
     if (local >= unsigned(w) * unsigned(h)) continue;   // padding between levels
     const int y = int(local / unsigned(w)), x = int(local - unsigned(y) * unsigned(w));
     const float* img = (blockIdx.y ? img1 : img0) + t.off[lo];
     float2* out = (blockIdx.y ? g1 : g0) + t.off[lo];
-    out[local] = d_gradient_px(img, w, h, x, y, g);
+    out[local] = d_gradient_any(img, w, h, x, y, g);
   }
 }
 void launch_gradients(hipStream_t st, const float* img, int w, int h, float* gxy, const Gauss& g3) {
