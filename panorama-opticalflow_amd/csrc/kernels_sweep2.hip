@@ -30,6 +30,7 @@
 // running), every spin is bounded and raises ctrl[1] instead of hanging.
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <stddef.h>
 #include <algorithm>
 
 #include "pf_common.hpp"

@@ -51,6 +51,9 @@ struct SmemTF {
   int pubTail, bndHead, abort, wg;
   long long deadline;
 };
+// the LDS-DMA destination travels in M0, whose LDS-address field is 16 bits wide: the record rings must lie in the first 64 KB of the
+// workgroup's LDS (they are the struct's first member: 32 KB)
+static_assert(offsetof(SmemTF<true>, rec) == 0 && sizeof(SmemTF<true>::rec) <= 65536, "LDS-DMA rings must sit below 64 KB");
 
 // V_PERMLANE32_SWAP: lanes 32-63 of `a` trade places with lanes 0-31 of `b`.  With a == b == v: lo = role a's v in every lane, hi = role b's.
 __device__ __forceinline__ void swap_roles(float v, float& lo, float& hi) {
