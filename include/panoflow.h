@@ -72,7 +72,7 @@ typedef struct pf_config {
   int sweep_wide_threshold; /* sweep_wide = -1: a launch takes the throughput form when (sweeps running at the same time: pairs of the batch x 2
                                directions x lanes) x (its latency-form workgroups) exceeds this (512: two rounds of the chip) */
   int sweep_throughput_transposed; /* sweep_wide = -1: sweeps whose bands step along y (windows taller than wide, e.g. 2000x4000 strips) may take the
-                               throughput form too (1; its gather-window loads do not coalesce in that orientation, still +15 % on 16 strips in flight) */
+                               throughput form too (1: +17 % on 16 strips in flight; 0 keeps them in the latency form) */
   int full_width_batch_gradients; /* 1: in a batched solve the finest levels' gradients are one full-width launch (nothing to hide them
                                behind: the batch keeps every CU busy anyway), 0: the narrow launch of a lone pair (1) */
   /* Cross-check implementations -- only in libpanoflow_exp.so (the -DPF_EXPERIMENTS build used by the test-suite);

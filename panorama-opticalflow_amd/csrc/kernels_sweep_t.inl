@@ -20,8 +20,8 @@
 // three bands' rings and windows) + 3 loaders + publisher + poller + drainer = 576 threads; the helpers share the fourth SIMD and the
 // compute waves' SIMDs.  Rings, counters, granules, tickets and deadlines work as in the latency form.  The gather window is SKEWED:
 // ring slot = (u + window row) & 63, because the 32 pixels of a step lie on an anti-diagonal 32 columns wide -- in (u + row) they all sit
-// within 31 slots of each other (d_error_fast<.., SKEW>).  Dense, non-transposed sweeps only (what a batch of dense pairs runs at its
-// large levels); everything else keeps the latency form.
+// within 31 slots of each other (d_error_fast<.., SKEW>).  Dense sweeps only (no variant that skips ungated anti-diagonals); sparse
+// and small launches keep the latency form.
 namespace {
 constexpr int tRows = 32;                       // rows per compute wave
 // Two ways the records reach a compute wave (template parameter RG of everything below):
@@ -330,14 +330,22 @@ __global__ __launch_bounds__(TGeom<RG>::kThreads) void k_sweep_t(const float4* _
     constexpr int kKT = (8 * tWA + 63) / 64;   // window texels per lane and batch (7)
     int ta[kKT], td[kKT]; bool tvalid[kKT];
 #pragma unroll
-    for (int k = 0; k < kKT; ++k) { const int t = lane + 64 * k; ta[k] = t >> 3; td[k] = t & 7; tvalid[k] = t < 8 * tWA; }
+    for (int k = 0; k < kKT; ++k) {
+      // which texel of a batch (8 ring slots d x 49 window rows a) this lane fetches: runs of 8 texels that are CONTIGUOUS in memory.
+      // Bands along x: a window row is an image row, a run = 8 consecutive d of one row a.  Transposed (bands along y): the window row
+      // index a is the image x, so a run = one image row u = d - a with 8 consecutive a -- the batch is a diagonal band of 56 such rows
+      // (dealt out by row a there, every texel would come from a cache line of its own).
+      const int t = lane + 64 * k;
+      if (TR) { const int ui = t >> 3, j = t & 7; ta[k] = tWA - 1 - ui + j; td[k] = j; tvalid[k] = ta[k] >= 0 && ta[k] < tWA; }
+      else { ta[k] = t >> 3; td[k] = t & 7; tvalid[k] = t < 8 * tWA; }
+    }
     float2* winw = &sm.win[w][0][0];
     const int v0 = (bandLo + band0 + w) * tRows - kRad;
     auto win_addr = [&](int b, int k, int& slot) -> const float2* {
       const int d = 8 * b - 8 + td[k];                     // relative skewed index
       const int u = uLo + d - ta[k], v = v0 + ta[k];       // absolute sweep-order texel
+      if (!tvalid[k] || u < 0 || u >= LS || v < 0 || v >= LB) { slot = 0; return nullptr; }
       slot = ta[k] * kWCPT + ((u + ta[k]) & (kWC - 1));
-      if (!tvalid[k] || u < 0 || u >= LS || v < 0 || v >= LB) return nullptr;
       const int cxc = TR ? v : u, cyc = TR ? u : v;
       const int x = FWD ? cxc : W - 1 - cxc, y = FWD ? cyc : H - 1 - cyc;
       return g1 + (y * W + x);
