@@ -149,6 +149,32 @@ def test_dense_canvas_pair_vs_oracle_fixture(pf, synth):
     assert np.array_equal(f0.view(np.uint32), h0.view(np.uint32)) and np.array_equal(f1.view(np.uint32), h1.view(np.uint32))
 
 
+def test_config5_batch_in_the_throughput_form_vs_oracle_fixtures(pf, synth):
+    """BASELINE config 5 on one GPU: its EIGHT pairs (dense 9000x4000, seeds 1234 .. 1241) solved as ONE batch through
+    pf_novel_view_batch_dev with the sweeps of the large levels in the throughput form (32 rows per wave, 2 lanes per pixel, records by
+    LDS-DMA; sweep_wide_threshold lowered so that the form reaches down to ~250-row levels) -- every pair's two flows and blended strip
+    must be the ORACLE's, by the SHA-256 of the fixtures computed in the build container (tests/golden/dense_9000x4000[_s<seed>].npz)."""
+    import torch
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    cols, rows, n = 9000, 4000, 8
+    dev = torch.device("cuda", 0)
+    fx = [np.load(os.path.join(here, "dense_9000x4000%s.npz" % ("" if k == 0 else "_s%d" % (1234 + k)))) for k in range(n)]
+    pairs = [synth.make_pair(cols, rows, 1234 + k, dev)[:3] for k in range(n)]
+    for k in range(n):
+        assert [_sha(t.cpu().numpy()) for t in pairs[k]] == [str(v) for v in fx[k]["sha_inputs"]], "pair %d: inputs are not the fixture's" % k
+    outs = [torch.empty((rows, cols, 4), dtype=torch.uint8, device=dev) for _ in range(n)]
+    f0 = [torch.empty((rows, cols, 2), dtype=torch.float32, device=dev) for _ in range(n)]
+    f1 = [torch.empty((rows, cols, 2), dtype=torch.float32, device=dev) for _ in range(n)]
+    torch.cuda.synchronize()
+    c = pf.Context(0, sweep_wide=-1, sweep_wide_threshold=128)
+    c.novel_view_batch_dev([p[0].data_ptr() for p in pairs], [p[1].data_ptr() for p in pairs], cols, rows, 0, [p[2].data_ptr() for p in pairs],
+                           [o.data_ptr() for o in outs], [t.data_ptr() for t in f0], [t.data_ptr() for t in f1], in_flight=n)
+    for k in range(n):
+        got = [_sha(f0[k].cpu().numpy()), _sha(f1[k].cpu().numpy()), _sha(outs[k].cpu().numpy())]
+        assert got == [str(v) for v in fx[k]["sha_outputs"]], "pair %d (seed %d) differs from the oracle fixture: %s" % (k, 1234 + k, got)
+    c.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # BASELINE config 4 (5+top chain, 9000x4000, pixflow_search_20) against the oracle chain computed in the build
 # container (tests/golden/make_chain_golden.py -> chain_9000x4000.npz).
