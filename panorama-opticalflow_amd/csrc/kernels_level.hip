@@ -392,14 +392,25 @@ __global__ __launch_bounds__(256) void k_gauss15_col(const float2* __restrict__ 
 // MIX fuses lowAlphaFlowDiffusion's alpha mix (PixFlow.hpp:396-403) into the epilogue.
 constexpr int kG15TX = 64, kG15TY = 32, kG15R = 7;
 constexpr int kG15SW = kG15TX + 2 * kG15R, kG15SH = kG15TY + 2 * kG15R;   // 78 x 46 source texels per tile
-constexpr int kG15Pre = (kG15SW * kG15SH + 255) / 256;                     // 15 texels per thread
+// Which texels of the 78 x 46 source tile a thread carries (the same map for the prefetch and for the LDS store).  AFFINE in the
+// prefetch index k, so that an interior tile's addresses are "tile base + constant": k < 12: row = wave + 4k, column = lane (the 64
+// left columns, whole-wave 512-byte runs); k = 12..14: the 14 right-hand columns of all rows, 644 texels dealt out 256 at a time
+// (row = i / 14, column = 64 + i % 14 with i = thread + 256 (k - 12)).  Before round 4 the map was t = thread + 256 k -> (t / 78, t % 78):
+// a division, two reflections and a bounds test per texel, ~600 of the kernel's ~1,800 vector instructions per tile.
+constexpr int kG15Main = (kG15SH + 3) / 4;                                 // 12
+constexpr int kG15TailW = kG15SW - 64;                                     // 14
+constexpr int kG15Tail = (kG15TailW * kG15SH + 255) / 256;                 // 3
+constexpr int kG15Pre = kG15Main + kG15Tail;                               // 15 texels per thread
 // The blocks are persistent (at most three per CU, the LDS limit) and walk the tiles with a stride of gridDim.x: the global
 // loads of a block's NEXT tile are issued into registers before it computes the current one, so that with only three blocks
 // per CU the load latency hides behind the two passes instead of in front of them.
+// A tile whose 78 x 46 footprint lies inside the plane (all but the rim) takes the INTERIOR form of every step: no reflection, no
+// bounds tests, no partial rows -- the same loads, products and sums in the same order, so the same bits.
 // UPS (small levels): the source plane does not exist yet -- it is the bicubic upsample of the coarser level's result
 // (PixFlow.hpp:122-125); the tile loader computes it on the fly (same expressions as k_upsample_cubic) and writes the tile's own
 // 64 x 32 pixels of it to `up_out`, which saves the separate upsample launch where a launch costs more than its work.
 struct UpsSrc { const float2* src; int sw, sh; double scale_x, scale_y; float mul; float2* up_out; };
+template <bool V> struct G15Flag { static constexpr bool value = V; };
 template <bool MIX, bool UPS, bool MED>
 __global__ __launch_bounds__(256, 3) void k_gauss15_fused(const float2* __restrict__ src, float2* __restrict__ dst, int w, int h, Gauss g,
                                                         const float* __restrict__ a0, const float* __restrict__ a1, int ntx, int ntiles, UpsSrc ups, size_t bstride) {
@@ -414,8 +425,34 @@ __global__ __launch_bounds__(256, 3) void k_gauss15_fused(const float2* __restri
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float2 pre[kG15Pre];
   float coef[8];   // MIX: diffusion coefficients of this thread's eight outputs of the prefetched tile
-  auto fetch = [&](int tile) {
+  // tail texels of this thread: i = thread + 256 j -> (i / 14, 64 + i % 14); 256 = 18 * 14 + 4
+  const int tr0 = int(threadIdx.x) / kG15TailW, tc0 = int(threadIdx.x) - tr0 * kG15TailW;
+  auto tail_rc = [&](int j, int& r, int& c) __attribute__((always_inline)) {
+    c = tc0 + 4 * j; r = tr0 + 18 * j;
+    if (c >= kG15TailW) { c -= kG15TailW; r += 1; }
+    c += 64;
+  };
+  auto is_interior = [&](int tile) __attribute__((always_inline)) {
     const int x0 = (tile % ntx) * kG15TX, y0 = (tile / ntx) * kG15TY;
+    return x0 >= kG15R && x0 + kG15TX + kG15R <= w && y0 >= kG15R && y0 + kG15TY + kG15R <= h;
+  };
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
+    const int x0 = (tile % ntx) * kG15TX, y0 = (tile / ntx) * kG15TY;
+    if (is_interior(tile)) {   // block-uniform
+      // (MIX: an interior tile loads its alphas at the start of its own column pass -- a tile ahead they cost 16 registers across the
+      // row pass, which spilled)
+      const float2* p = src + size_t(y0 - kG15R) * w + (x0 - kG15R);
+      const float2* pm = p + size_t(wv) * w + lane;
+#pragma unroll
+      for (int k = 0; k < kG15Main; ++k)
+        if (4 * k + 3 < SH || wv + 4 * k < SH) pre[k] = pm[size_t(4 * k) * w];
+#pragma unroll
+      for (int j = 0; j < kG15Tail; ++j) {
+        int r, c; tail_rc(j, r, c);
+        if (256 * (j + 1) <= kG15TailW * SH || r < SH) pre[kG15Main + j] = p[size_t(r) * w + c];
+      }
+      return;
+    }
     const int rowsNeeded = min(SH, h + kG15R - (y0 - kG15R));   // rows past (h - 1) + 7 are read by no output of this tile
     if (MIX) {
       const int xq = x0 + lane, yq = y0 + wv * 8;
@@ -427,92 +464,107 @@ __global__ __launch_bounds__(256, 3) void k_gauss15_fused(const float2* __restri
     }
 #pragma unroll
     for (int k = 0; k < kG15Pre; ++k) {
-      const int t = threadIdx.x + 256 * k;
-      const int r = t / SW, cidx = t - r * SW;
-      if (t < rowsNeeded * SW) pre[k] = src[size_t(d_reflect101(y0 - kG15R + r, h)) * w + d_reflect101(min(x0 - kG15R + cidx, w - 1 + kG15R), w)];
+      int r, c;
+      if (k < kG15Main) { r = wv + 4 * k; c = lane; } else tail_rc(k - kG15Main, r, c);
+      if (r < rowsNeeded) pre[k] = src[size_t(d_reflect101(y0 - kG15R + r, h)) * w + d_reflect101(min(x0 - kG15R + c, w - 1 + kG15R), w)];
     }
   };
   int tile = blockIdx.x;
   constexpr bool DIRECT = UPS || MED;   // the loader computes its texels: no register prefetch of the next tile
   if (!DIRECT && tile < ntiles) fetch(tile);
   while (tile < ntiles) {
-    const int x0 = (tile % ntx) * kG15TX, y0 = (tile / ntx) * kG15TY;
-    const int rowsNeeded = min(SH, h + kG15R - (y0 - kG15R));
-    // ---- (1) source tile: registers -> LDS ----
-    if (MED) {
-      // the source is the median-filtered plane (medianBlur 5, PixFlow.hpp:338), computed here instead of by its own launch
-      for (int t = threadIdx.x; t < rowsNeeded * SW; t += 256) {
-        const int r = t / SW, cidx = t - r * SW;
-        srct[r * SS + cidx] = d_median5_px(src, w, h, d_reflect101(min(x0 - kG15R + cidx, w - 1 + kG15R), w), d_reflect101(y0 - kG15R + r, h));
-      }
-    } else if (UPS) {
-      for (int t = threadIdx.x; t < rowsNeeded * SW; t += 256) {
-        const int r = t / SW, cidx = t - r * SW;
-        const int yy = d_reflect101(y0 - kG15R + r, h), xx = d_reflect101(min(x0 - kG15R + cidx, w - 1 + kG15R), w);
-        const float2 v = d_upsample_cubic_px(ups.src, ups.sw, ups.sh, xx, yy, ups.scale_x, ups.scale_y, ups.mul);
-        srct[r * SS + cidx] = v;
-        const int oy = r - kG15R, ox = cidx - kG15R;   // the tile's own pixels are unreflected: every pixel of the plane is written once
-        if (oy >= 0 && oy < kG15TY && ox >= 0 && ox < kG15TX && y0 + oy < h && x0 + ox < w) ups.up_out[size_t(y0 + oy) * w + x0 + ox] = v;
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < kG15Pre; ++k) {
-        const int t = threadIdx.x + 256 * k;
-        const int r = t / SW, cidx = t - r * SW;
-        if (t < rowsNeeded * SW) srct[r * SS + cidx] = pre[k];
-      }
-    }
-    __syncthreads();
-    float cf[8];
-#pragma unroll
-    for (int o = 0; o < 8; ++o) cf[o] = coef[o];
     const int next = tile + int(gridDim.x);
-    if (!DIRECT && next < ntiles) fetch(next);
-    // ---- (2) row pass: lane = source row (46 of 64 lanes), wave = 16 output columns; 30 values -> 16 outputs ----
-    if (lane < rowsNeeded) {
-      const float2* sr = srct + lane * SS + wv * 16;
-      float2 v[30];
-#pragma unroll
-      for (int t = 0; t < 30; ++t) v[t] = sr[t];
-      float2* rp = rowp + lane * RS + wv * 16;
-#pragma unroll
-      for (int o = 0; o < 16; ++o) {
-        float sx = g.k[0] * v[o].x, sy = g.k[0] * v[o].y;
-#pragma unroll
-        for (int t = 1; t < 15; ++t) { sx += g.k[t] * v[o + t].x; sy += g.k[t] * v[o + t].y; }
-        rp[o] = make_float2(sx, sy);
-      }
-    }
-    __syncthreads();
-    // ---- (3) column pass: lane = column, wave = 8 output rows; 22 values -> 8 outputs.  The row pass of source row
-    // reflect101(y + d) sits at LDS row (y - y0) + 7 + d ----
-    const int x = x0 + lane;
-    const int oy0 = wv * 8;
-    if (x < w && y0 + oy0 < h) {
-      float2 cv[22];
-#pragma unroll
-      for (int t = 0; t < 22; ++t) cv[t] = (oy0 + t < rowsNeeded) ? rowp[(oy0 + t) * RS + lane] : make_float2(0.f, 0.f);
-#pragma unroll
-      for (int o = 0; o < 8; ++o) {
-        const int y = y0 + oy0 + o;
-        if (y >= h) break;
-        const float2 c = cv[o + kG15R];
-        float sx = g.k[7] * c.x + 0.0f, sy = g.k[7] * c.y + 0.0f;
-#pragma unroll
-        for (int j = 1; j <= 7; ++j) {
-          const float2 a = cv[o + kG15R + j], b = cv[o + kG15R - j];
-          sx += g.k[7 + j] * (a.x + b.x); sy += g.k[7 + j] * (a.y + b.y);
+    auto do_tile = [&](auto interiorFlag) __attribute__((always_inline)) {
+      constexpr bool INT = decltype(interiorFlag)::value;
+      const int x0 = (tile % ntx) * kG15TX, y0 = (tile / ntx) * kG15TY;
+      const int rowsNeeded = INT ? SH : min(SH, h + kG15R - (y0 - kG15R));
+      // ---- (1) source tile: registers -> LDS ----
+      if (MED) {
+        // the source is the median-filtered plane (medianBlur 5, PixFlow.hpp:338), computed here instead of by its own launch
+        for (int t = threadIdx.x; t < rowsNeeded * SW; t += 256) {
+          const int r = t / SW, cidx = t - r * SW;
+          srct[r * SS + cidx] = d_median5_px(src, w, h, d_reflect101(min(x0 - kG15R + cidx, w - 1 + kG15R), w), d_reflect101(y0 - kG15R + r, h));
         }
-        const size_t i = size_t(y) * w + x;
-        if (MIX) {
-          const float2 f = srct[(oy0 + o + kG15R) * SS + lane + kG15R];
-          const float diffusionCoef = DIRECT ? 1.0f - a0[i] * a1[i] : cf[o];
-          dst[i] = make_float2(diffusionCoef * sx + (1.0f - diffusionCoef) * f.x, diffusionCoef * sy + (1.0f - diffusionCoef) * f.y);
-        } else {
-          dst[i] = make_float2(sx, sy);
+      } else if (UPS) {
+        for (int t = threadIdx.x; t < rowsNeeded * SW; t += 256) {
+          const int r = t / SW, cidx = t - r * SW;
+          const int yy = d_reflect101(y0 - kG15R + r, h), xx = d_reflect101(min(x0 - kG15R + cidx, w - 1 + kG15R), w);
+          const float2 v = d_upsample_cubic_px(ups.src, ups.sw, ups.sh, xx, yy, ups.scale_x, ups.scale_y, ups.mul);
+          srct[r * SS + cidx] = v;
+          const int oy = r - kG15R, ox = cidx - kG15R;   // the tile's own pixels are unreflected: every pixel of the plane is written once
+          if (oy >= 0 && oy < kG15TY && ox >= 0 && ox < kG15TX && y0 + oy < h && x0 + ox < w) ups.up_out[size_t(y0 + oy) * w + x0 + ox] = v;
+        }
+      } else {
+        float2* sm = srct + wv * SS + lane;
+#pragma unroll
+        for (int k = 0; k < kG15Main; ++k)
+          if ((INT && 4 * k + 3 < SH) || wv + 4 * k < rowsNeeded) sm[4 * k * SS] = pre[k];
+#pragma unroll
+        for (int j = 0; j < kG15Tail; ++j) {
+          int r, c; tail_rc(j, r, c);
+          if ((INT && 256 * (j + 1) <= kG15TailW * SH) || r < rowsNeeded) srct[r * SS + c] = pre[kG15Main + j];
         }
       }
-    }
+      __syncthreads();
+      float cf[8];
+      if (!INT) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) cf[o] = coef[o];
+      }
+      if (!DIRECT && next < ntiles) fetch(next);
+      // ---- (2) row pass: lane = source row (46 of 64 lanes), wave = 16 output columns; 30 values -> 16 outputs ----
+      if (lane < rowsNeeded) {
+        const float2* sr = srct + lane * SS + wv * 16;
+        float2 v[30];
+#pragma unroll
+        for (int t = 0; t < 30; ++t) v[t] = sr[t];
+        float2* rp = rowp + lane * RS + wv * 16;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+          float sx = g.k[0] * v[o].x, sy = g.k[0] * v[o].y;
+#pragma unroll
+          for (int t = 1; t < 15; ++t) { sx += g.k[t] * v[o + t].x; sy += g.k[t] * v[o + t].y; }
+          rp[o] = make_float2(sx, sy);
+        }
+      }
+      __syncthreads();
+      // ---- (3) column pass: lane = column, wave = 8 output rows; 22 values -> 8 outputs.  The row pass of source row
+      // reflect101(y + d) sits at LDS row (y - y0) + 7 + d ----
+      const int x = x0 + lane;
+      const int oy0 = wv * 8;
+      if (INT || (x < w && y0 + oy0 < h)) {
+        float al0[8], al1[8];
+        if (MIX && INT && !DIRECT) {
+          const size_t i0 = size_t(y0 + oy0) * w + x;
+#pragma unroll
+          for (int o = 0; o < 8; ++o) { al0[o] = a0[i0 + size_t(o) * w]; al1[o] = a1[i0 + size_t(o) * w]; }
+        }
+        float2 cv[22];
+#pragma unroll
+        for (int t = 0; t < 22; ++t) cv[t] = (INT || oy0 + t < rowsNeeded) ? rowp[(oy0 + t) * RS + lane] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+          const int y = y0 + oy0 + o;
+          if (!INT && y >= h) break;
+          const float2 c = cv[o + kG15R];
+          float sx = g.k[7] * c.x + 0.0f, sy = g.k[7] * c.y + 0.0f;
+#pragma unroll
+          for (int j = 1; j <= 7; ++j) {
+            const float2 a = cv[o + kG15R + j], b = cv[o + kG15R - j];
+            sx += g.k[7 + j] * (a.x + b.x); sy += g.k[7 + j] * (a.y + b.y);
+          }
+          const size_t i = size_t(y) * w + x;
+          if (MIX) {
+            const float2 f = srct[(oy0 + o + kG15R) * SS + lane + kG15R];
+            const float diffusionCoef = DIRECT ? 1.0f - a0[i] * a1[i] : (INT ? 1.0f - al0[o] * al1[o] : cf[o]);
+            dst[i] = make_float2(diffusionCoef * sx + (1.0f - diffusionCoef) * f.x, diffusionCoef * sy + (1.0f - diffusionCoef) * f.y);
+          } else {
+            dst[i] = make_float2(sx, sy);
+          }
+        }
+      }
+    };
+    if (!DIRECT && is_interior(tile)) do_tile(G15Flag<true>{}); else do_tile(G15Flag<false>{});
     tile = next;
     if (tile < ntiles) __syncthreads();   // every read of this tile's LDS is done before the next one is stored
   }

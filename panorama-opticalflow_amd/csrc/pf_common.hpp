@@ -82,7 +82,10 @@ __device__ __forceinline__ void d_resize_linear_px(const float* __restrict__ src
 constexpr int kMaxBatch = 16;
 struct Batch { int n = 1; size_t stride = 0; };
 struct ExtPtrs { const void* p[kMaxBatch]; };   // caller-owned buffers of the pairs of a batch (read-only or written, by use)
-#define PF_BOFF(ptr, off) (ptr = reinterpret_cast<decltype(ptr)>(reinterpret_cast<uintptr_t>(ptr) + (off)))
+// (pointer arithmetic on bytes, NOT a round trip through uintptr_t: an inttoptr hides the kernel argument from the compiler's address-space
+// inference and every access through the pointer becomes a FLAT instruction -- counted in lgkmcnt as well, completion order unknown, so
+// each wait on one is s_waitcnt vmcnt(0) lgkmcnt(0).  Rounds 3-4 shipped that: found in round 4, tests/micro/isa_flat_count.sh)
+#define PF_BOFF(ptr, off) (ptr = (decltype(ptr))((char*)(ptr) + (off)))
 
 // ---- launch wrappers (defined in the kernels_*.hip files) ----
 // preprocessing
