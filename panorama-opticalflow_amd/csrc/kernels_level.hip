@@ -628,12 +628,19 @@ __global__ __launch_bounds__(256) void k_median5(const float2* __restrict__ src,
   dst[size_t(y) * w + xp] = m0;
   if (xp + 1 < w) dst[size_t(y) * w + xp + 1] = m1;
 }
-// A block of 1024 threads owns a 128 x 16 output tile.  The tile + its 2-pixel halo (replicate border) is staged in LDS once -- 1.29
+// A block of 256 threads owns a 32 x 16 output tile.  The tile + its 2-pixel halo (replicate border) is staged in LDS once -- 1.41
 // global loads per output instead of 15 through L1 -- and every thread then selects 2 horizontally adjacent outputs of one row
 // from LDS (16-byte reads: the six columns of an output pair are three float4).  Same generated selection network (d_median_pair).
 // Measured per launch beside the other direction's kernels (tests/micro/kern_by_grid.sh): 4950x2000 123 vs 139 us, 4455x1800 112 vs
-// 124, equal at ~2.3 Mpix, slower below (a block's single HBM round trip + barrier in front of the network): levels >= kMedTiledMinPx.
-constexpr int kMedX = 128, kMedY = 16, kMedSX = kMedX + 4, kMedSY = kMedY + 4, kMedT = 64 * kMedY;
+// 124 (1024-thread blocks; they lost below ~2.3 Mpix): levels >= kMedTiledMinPx.
+// Tile shape: until round 4 a block was 1024 threads (128 x 16) -- at 71 VGPRs ONE such block fits a CU, so every block's HBM round trip
+// stood in front of its network with nothing beside it.  Small blocks interleave (profiles/r04_median_tile_ab.txt: median family of a
+// dense pair 3.11 -> 2.78 ms, 8 pairs in flight +1.5 %).
+#ifndef PF_MEDX
+#define PF_MEDX 32
+#define PF_MEDY 16
+#endif
+constexpr int kMedX = PF_MEDX, kMedY = PF_MEDY, kMedSX = kMedX + 4, kMedSY = kMedY + 4, kMedT = (kMedX / 2) * kMedY;
 __global__ __launch_bounds__(kMedT) void k_median5_tiled(const float2* __restrict__ src, float2* __restrict__ dst, int w, int h, size_t bstride) {
   { const size_t bo = size_t(blockIdx.z) * bstride; PF_BOFF(src, bo); PF_BOFF(dst, bo); }
   __shared__ __attribute__((aligned(16))) float2 tile[kMedSY][kMedSX];
@@ -653,8 +660,8 @@ __global__ __launch_bounds__(kMedT) void k_median5_tiled(const float2* __restric
     }
   }
   __syncthreads();
-  const int lx = (threadIdx.x & 63) * 2, xp = x0 + lx;   // outputs xp and xp + 1
-  const int ly = threadIdx.x >> 6, y = y0 + ly;
+  const int lx = (threadIdx.x % (kMedX / 2)) * 2, xp = x0 + lx;   // outputs xp and xp + 1
+  const int ly = threadIdx.x / (kMedX / 2), y = y0 + ly;
   if (xp >= w || y >= h) return;
   float2 col[6][5];   // columns xp-2 .. xp+3, rows y-2 .. y+2
 #pragma unroll
@@ -671,7 +678,11 @@ __global__ __launch_bounds__(kMedT) void k_median5_tiled(const float2* __restric
     if (xp + 1 < w) dst[size_t(y) * w + xp + 1] = m1;
   }
 }
-constexpr long kMedTiledMinPx = 3000000;
+// (threshold re-measured with the small blocks, same file: 3 M -> 20 k pixels; the direct form only keeps the levels of a few blocks)
+#ifndef PF_MED_MINPX
+#define PF_MED_MINPX 20000
+#endif
+constexpr long kMedTiledMinPx = PF_MED_MINPX;
 void launch_median5_form(hipStream_t st, const float* src, float* dst, int w, int h, bool tiled, Batch bt) {
   if (tiled) {
     dim3 grid((w + kMedX - 1) / kMedX, (h + kMedY - 1) / kMedY, bt.n);
