@@ -678,20 +678,18 @@ __device__ __forceinline__ float2 own_gradient_step(float2 f, float e0, float ex
 // ROWS = rows per band (8: latency / wide form, 32: throughput form).  RC: the record carries rC, the current flow after its own gradient
 // step (three energies per pixel: what the 8-lane step needs); !RC (throughput form): it carries C itself and E(C) only -- that step
 // takes the winner's gradient step itself, the current flow's included (one energy per pixel here instead of three).
+// (band, s, r) = the record's band (counted from bandLo), step and row; `inside` = the slot exists (band < nbandsPad, s < nstepsPad).
 template <int ROWS = kRows, bool RC = true>
-__device__ __forceinline__ void d_make_record(size_t tid, size_t total, const float2* __restrict__ g0, const float2* __restrict__ g1,
-                                              const float2* __restrict__ blurred, const uint8_t* __restrict__ gate, const float2* __restrict__ flow, int W,
-                                              int H, int forward, int transposed, int nstepsPad, float rW, int uLo, int uHi, int bandLo, float4& a,
-                                              float4& b, float4& c) {
+__device__ __forceinline__ void d_make_record_at(int band, int s, int r, bool inside, const float2* __restrict__ g0, const float2* __restrict__ g1,
+                                                 const float2* __restrict__ blurred, const uint8_t* __restrict__ gate, const float2* __restrict__ flow, int W,
+                                                 int H, int forward, int transposed, float rW, int uLo, int uHi, int bandLo, float4& a,
+                                                 float4& b, float4& c) {
   const int LS = transposed ? H : W, LB = transposed ? W : H;   // extent along the step axis / across the bands
-  const int r = int(tid % ROWS);
-  const int s = int((tid / ROWS) % nstepsPad);
-  const int band = int(tid / (size_t(ROWS) * nstepsPad));
   const int ia = uLo + s - r, ib = (bandLo + band) * ROWS + r;
   // A pixel that is not updated (gate <= 0) carries E(C) = kKeepEnergy and rC = C: every proposal's energy is >= 0 (or NaN), so
   // the selection keeps rC = C -- the sweep's step needs no "if not gated keep C" of its own (two v_cndmask per step).
   a = make_float4(0.f, 0.f, 0.f, 0.f); b = make_float4(kKeepEnergy, 0.f, 0.f, kKeepEnergy); c = a;
-  if (tid < total && s - r >= 0 && ia < uHi && ia < LS && ib < LB) {
+  if (inside && s - r >= 0 && ia < uHi && ia < LS && ib < LB) {
     const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;   // position in sweep order
     const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
     const size_t idx = size_t(y) * W + x;
@@ -713,6 +711,18 @@ __device__ __forceinline__ void d_make_record(size_t tid, size_t total, const fl
       b.w = (ia > 0) ? e0 : kKeepEnergy;   // E(C) as the proposal from the previous pixel ALONG the step axis sees it: unbeatable at the first pixel of a row (there is none)
     }
   }
+}
+// the same from a linear slot index (row fastest, then step, then band): two 64-bit divisions -- only the lab build's prepass blocks
+// inside the sweep launch (MODE 2) still address their records this way
+template <int ROWS = kRows, bool RC = true>
+__device__ __forceinline__ void d_make_record(size_t tid, size_t total, const float2* __restrict__ g0, const float2* __restrict__ g1,
+                                              const float2* __restrict__ blurred, const uint8_t* __restrict__ gate, const float2* __restrict__ flow, int W,
+                                              int H, int forward, int transposed, int nstepsPad, float rW, int uLo, int uHi, int bandLo, float4& a,
+                                              float4& b, float4& c) {
+  const int r = int(tid % ROWS);
+  const int s = int((tid / ROWS) % nstepsPad);
+  const int band = int(tid / (size_t(ROWS) * nstepsPad));
+  d_make_record_at<ROWS, RC>(band, s, r, tid < total, g0, g1, blurred, gate, flow, W, H, forward, transposed, rW, uLo, uHi, bandLo, a, b, c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -742,9 +752,12 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
   // wave's 64 slots are 8 rows x 8 consecutive columns: 64-byte runs of every input plane.  With 32 rows they would be 32 rows x 2
   // columns (16-byte runs: the throughput form's first prepass ran 1.5x LONGER than the latency form's with a third of the arithmetic),
   // so the block's 8 steps x 32 rows are dealt out column-fastest instead; the LDS stage below puts the records back in slot order.
+  // Grid: x = the blocks of one band (256 / ROWS steps each), y = band -- until round 4 the grid was linear and every thread took its
+  // (band, step, row) out of a 64-bit slot index with two emulated divisions, a third of the kernel's vector instructions.
+  constexpr int kStepsPerBlock = 256 / ROWS;
   const unsigned lt = (ROWS == 32) ? (threadIdx.x & 7) * 32 + (threadIdx.x >> 3) : threadIdx.x;
-  const size_t tid = size_t(blockIdx.x) * blockDim.x + lt;
-  const size_t total = size_t(nbandsPad) * nstepsPad * ROWS;
+  const int band = blockIdx.y, s = int(blockIdx.x) * kStepsPerBlock + int(lt / ROWS), r = int(lt % ROWS);
+  const size_t tid = (size_t(blockIdx.y) * gridDim.x + blockIdx.x) * blockDim.x + lt;   // any numbering of the launch's threads serves top0
   if (top0 != nullptr && tid < size_t(uHi - uLo)) {
     const int ia = uLo + int(tid), ib = bandLo * ROWS - 1;
     const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;
@@ -757,15 +770,17 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
   constexpr int kQuads = RC ? 3 : 2;
   __shared__ float4 stage[256 * kQuads];
   float4 a, b, c;
-  d_make_record<ROWS, RC>(tid, total, g0, g1, blurred, gate, flow, W, H, forward, transposed, nstepsPad, rW, uLo, uHi, bandLo, a, b, c);
+  d_make_record_at<ROWS, RC>(band, s, r, band < nbandsPad && s < nstepsPad, g0, g1, blurred, gate, flow, W, H, forward, transposed, rW, uLo, uHi, bandLo, a, b, c);
   stage[lt * kQuads + 0] = a; stage[lt * kQuads + 1] = b;
   if (kQuads == 3) stage[lt * kQuads + 2] = c;
   __syncthreads();
-  const size_t base = size_t(blockIdx.x) * blockDim.x * kQuads, lim = total * kQuads;   // in float4 units
+  // the block's records are contiguous in the band's stream (the last block of a band may reach past its end: nstepsPad is a multiple of 8, not of 32)
+  const size_t bandBase = size_t(band) * nstepsPad * ROWS * kQuads;   // in float4 units
+  const unsigned inBand = unsigned(blockIdx.x) * 256u * kQuads, limBand = unsigned(nstepsPad) * ROWS * kQuads;
 #pragma unroll
   for (int k = 0; k < kQuads; ++k) {
-    const size_t o = base + size_t(k) * 256 + threadIdx.x;
-    if (o < lim) rec[o] = stage[k * 256 + threadIdx.x];
+    const unsigned o = inBand + unsigned(k) * 256u + threadIdx.x;
+    if (o < limBand) rec[bandBase + o] = stage[k * 256 + threadIdx.x];
   }
 }
 
@@ -1363,7 +1378,6 @@ static bool launch_sweep2_form(hipStream_t st, const SweepArgs& a, float* rec) {
   const int tr = win.tr, uLo = win.uLo, uHi = win.uHi, LSv = win.LSv, bandLo = win.bandLo, nbands = win.nbands;
   const int nwg = win.nwg, nbandsPad = nwg * kWaves, nstepsPad = win.nstepsPad;
   const size_t total = size_t(nbandsPad) * nstepsPad * kRows;
-  const size_t prepThreads = total > size_t(LSv) ? total : size_t(LSv);
   const float rW = (float)(1.0 / (double)(float)a.W), rEps = (float)(1.0 / (double)kGradEpsilon);
   // How the records reach the sweep.  0 (the product): k_sweep_prep in front of the sweep.  Two measured and rejected alternatives
   // exist in the lab build only (-DPF_EXPERIMENTS, SweepArgs::prep_mode; latency form only), both bit-identical: 1 = the loader waves
@@ -1376,7 +1390,7 @@ static bool launch_sweep2_form(hipStream_t st, const SweepArgs& a, float* rec) {
   constexpr int mode = 0;
 #endif
   if (mode == 0)
-    hipExtLaunchKernelGGL((k_sweep_prep<kRows, true>), dim3((unsigned)((prepThreads + 255) / 256), 1, a.bt.n), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate, a.flow,
+    hipExtLaunchKernelGGL((k_sweep_prep<kRows, true>), dim3((unsigned)((nstepsPad + 256 / kRows - 1) / (256 / kRows)), (unsigned)nbandsPad, a.bt.n), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate, a.flow,
                           a.W, a.H, a.forward, tr, nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo,
                           bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride);
   hipEvent_t evs = mode == 0 ? nullptr : a.ev_start;   // without a prepass kernel the sweep launch carries both events

@@ -523,10 +523,8 @@ static bool launch_sweep_t(hipStream_t st, const SweepArgs& a, float* rec) {
   if (win.empty) return false;
   const int tr = win.tr, uLo = win.uLo, uHi = win.uHi, LSv = win.LSv, bandLo = win.bandLo, nbands = win.nbands;
   const int nwg = win.nwg, nbandsPad = nwg * tWaves, nstepsPad = win.nstepsPad;
-  const size_t total = size_t(nbandsPad) * nstepsPad * tRows;
-  const size_t prepThreads = total > size_t(LSv) ? total : size_t(LSv);
   const float rW = (float)(1.0 / (double)(float)a.W), rEps = (float)(1.0 / (double)kGradEpsilon);
-  hipExtLaunchKernelGGL((k_sweep_prep<tRows, false>), dim3((unsigned)((prepThreads + 255) / 256), 1, a.bt.n), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate,
+  hipExtLaunchKernelGGL((k_sweep_prep<tRows, false>), dim3((unsigned)((nstepsPad + 256 / tRows - 1) / (256 / tRows)), (unsigned)nbandsPad, a.bt.n), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate,
                         a.flow, a.W, a.H, a.forward, tr, nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo,
                         bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride);
   const long long budget = 200000000ll + 1000ll * 50ll * (long long)(nstepsPad + 40 * nbands);
