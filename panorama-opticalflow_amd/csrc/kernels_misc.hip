@@ -171,13 +171,29 @@ __device__ __forceinline__ uchar4 d_novel_view_point(const uchar4* __restrict__ 
   int srcx = int(x + flowDir.x * t);  // fp64, truncation toward zero (OpticalFlow.cpp:17)
   if (srcx > cols - 1) srcx = srcx - cols;
   if (srcx < 0) srcx = srcx + cols;
-  srcx %= cols; if (srcx < 0) srcx += cols;  // latent single-wrap hazard defined as a true modulo
+  // latent single-wrap hazard defined as a true modulo -- behind a test: a flow longer than the image is wide practically never
+  // happens, and the emulated integer division cost every pixel ~30 instructions twice
+  if (unsigned(srcx) >= unsigned(cols)) { srcx %= cols; if (srcx < 0) srcx += cols; }
   int srcy = int(y + flowDir.y * t);
   if (srcy > rows - 1) srcy = rows - 1;
   if (srcy < 0) srcy = 0;
   return src[size_t(srcy) * cols + srcx];
 }
 __device__ __forceinline__ float d_lerp(float x0, float x1, float alpha) { return x0 * (1.0f - alpha) + x1 * alpha; }  // util.hpp:93-101
+
+// Two of the blend's per-pixel values only take a few hundred different arguments: the de-ghosting coefficient tanhf(colorDiff * 10)
+// with colorDiff = n / 255.0f, n = sum of three byte differences (0..765), and alpha = a / 255.0f, a = 0..255.  Both are tabulated once
+// per device with the very expressions the kernel used to evaluate per pixel (tanhf_exact: libm_exact.hpp) -- the same bits, and the
+// piecewise tanhf (divergent branches, an IEEE division) and three more IEEE divisions leave the per-pixel path.
+__device__ float g_blend_tanh[766];
+__device__ float g_blend_alpha[256];
+__global__ void k_blend_tables() {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const float kColorDiffCoef = 10.0f;
+  if (n < 766) { const float colorDiff = n / 255.0f; g_blend_tanh[n] = pf_libm::tanhf_exact(colorDiff * kColorDiffCoef); }
+  if (n < 256) g_blend_alpha[n] = n / 255.0f;
+}
+void launch_blend_tables(hipStream_t st) { hipLaunchKernelGGL(k_blend_tables, dim3(3), dim3(256), 0, st); }
 
 __device__ __forceinline__ void d_blend_px(const uchar4* __restrict__ L, const uchar4* __restrict__ R, const float2* __restrict__ flowLR,
                                            const float2* __restrict__ flowRL, const float* __restrict__ blend, int cols, int rows,
@@ -193,14 +209,14 @@ __device__ __forceinline__ void d_blend_px(const uchar4* __restrict__ L, const u
   if (colorL.w == 0 || colorR.w == 0) {
     o = make_uchar4(0, 0, 0, 0);
   } else {
-    const float kColorDiffCoef = 10.0f, kSoftmaxSharpness = 10.0f, kFlowMagCoef = 100.0f;
+    const float kSoftmaxSharpness = 10.0f, kFlowMagCoef = 100.0f;
     const float flowMagLR = sqrtf(fLR.x * fLR.x + fLR.y * fLR.y) / float(cols);
     const float flowMagRL = sqrtf(fRL.x * fRL.x + fRL.y * fRL.y) / float(cols);
-    const float colorDiff = (abs(int(colorL.x) - int(colorR.x)) + abs(int(colorL.y) - int(colorR.y)) + abs(int(colorL.z) - int(colorR.z))) / 255.0f;
+    const int colorDiffN = abs(int(colorL.x) - int(colorR.x)) + abs(int(colorL.y) - int(colorR.y)) + abs(int(colorL.z) - int(colorR.z));   // colorDiff = N / 255.0f
     // tanhf / exp with the host libm's roundings (libm_exact.hpp): where the two warped colours agree, c*wL + c*wR sits within
     // an ulp of the integer c and a last-place difference in either function flips the truncated byte
-    const float deghostCoef = pf_libm::tanhf_exact(colorDiff * kColorDiffCoef);
-    const float alphaL = colorL.w / 255.0f, alphaR = colorR.w / 255.0f;
+    const float deghostCoef = g_blend_tanh[colorDiffN];               // = tanhf(colorDiff * kColorDiffCoef)
+    const float alphaL = g_blend_alpha[colorL.w], alphaR = g_blend_alpha[colorR.w];   // = w / 255.0f
     const double expL = pf_libm::exp_exact(kSoftmaxSharpness * blendL * alphaL * (1.0 + kFlowMagCoef * flowMagRL), pf_libm::kExpTab);
     const double expR = pf_libm::exp_exact(kSoftmaxSharpness * blendR * alphaR * (1.0 + kFlowMagCoef * flowMagLR), pf_libm::kExpTab);
     const double sumExp = expL + expR + 0.00001;

@@ -754,6 +754,9 @@ pf_ctx* create_ctx(const pf_config& cfg, bool lane) {
       return nullptr;
     }
   }
+  // the blend's two small tables (kernels_misc.hip): device globals, the same values from every context
+  launch_blend_tables(c->s_main);
+  if (hipStreamSynchronize(c->s_main) != hipSuccess) { fail(nullptr, PF_ERR_DEVICE, "device %d: the blend tables could not be initialised", device); pf_destroy(c); return nullptr; }
   c->g5 = make_gauss(5, 0.25); c->g3_05 = make_gauss(3, 0.5); c->g3_1 = make_gauss(3, 1.0); c->g15 = make_gauss(15, 8.0);
   // Pre-sizing: every buffer a bidirectional solve / a stitch step on max_cols x max_rows needs is
   // allocated now, so that the first call does not pay ~40 hipMallocs.  0 x 0 = allocate lazily (the arena only grows).

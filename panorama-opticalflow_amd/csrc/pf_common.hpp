@@ -163,6 +163,7 @@ bool launch_sweep_relax(hipStream_t st, const SweepArgs& a);   // lab build only
 void launch_adjust_initial_flow(hipStream_t st, const float* i0, const float* i1, const float* a0, const float* a1, int w, int h, int hint,
                                 int max_pct, float* i1eq_tmp, float* flow, Batch bt = Batch());
 // blend
+void launch_blend_tables(hipStream_t st);   // once per device before the first blend (create_ctx)
 void launch_blend(hipStream_t st, const uint8_t* L, const uint8_t* R, const float* flowLR, const float* flowRL, const float* blend, int cols,
                   int rows, uint8_t* out);
 struct BlendPtrs { const uint8_t* L[kMaxBatch]; const uint8_t* R[kMaxBatch]; const float* fLR[kMaxBatch]; const float* fRL[kMaxBatch]; const float* blend[kMaxBatch]; uint8_t* out[kMaxBatch]; };
