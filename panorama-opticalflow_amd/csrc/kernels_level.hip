@@ -64,6 +64,40 @@ __device__ __forceinline__ float2 d_gradient_px_interior(const float* __restrict
   float oy = k0 * ty[1] + 0.0f; oy += k1 * (ty[2] + ty[0]);
   return make_float2(ox, oy);
 }
+// Four horizontally adjacent interior pixels (x .. x + 3, all with 2 <= x, x + 3 < w - 2, 2 <= y < h - 2): the 5 x 8 neighbourhood is
+// loaded once (36 values instead of 4 x 21) and the per-pixel expressions of d_gradient_px_interior are written out with the column
+// offset q -- the central differences two neighbours share are the same subtraction of the same operands, so computing them once
+// changes no bit.
+__device__ __forceinline__ void d_gradient_quad_interior(const float* __restrict__ img, int w, int x, int y, const Gauss& g, float2 (&o)[4]) {
+  const float k0 = g.k[1], k1 = g.k[2];
+  const float* c = img + size_t(y) * w + x;
+  float v[5][8];   // v[r][q] = I(y - 2 + r, x - 2 + q); rows 0 and 4 only need columns 1..6
+#pragma unroll
+  for (int r = 0; r < 5; ++r)
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (!((r == 0 || r == 4) && (q == 0 || q == 7))) v[r][q] = c[(r - 2) * w + (q - 2)];
+  float dx[3][6], dy[3][6];   // central differences at rows y - 1 .. y + 1, columns x - 1 .. x + 4
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      dx[j][i] = v[j + 1][i + 2] - v[j + 1][i];       // I(yy, xx + 1) - I(yy, xx - 1)
+      dy[j][i] = v[j + 2][i + 1] - v[j][i + 1];       // I(yy + 1, xx) - I(yy - 1, xx)
+    }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float tx[3], ty[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      tx[j] = dx[j][q + 1] * k0 + (dx[j][q] + dx[j][q + 2]) * k1;
+      ty[j] = dy[j][q + 1] * k0 + (dy[j][q] + dy[j][q + 2]) * k1;
+    }
+    float ox = k0 * tx[1] + 0.0f; ox += k1 * (tx[2] + tx[0]);
+    float oy = k0 * ty[1] + 0.0f; oy += k1 * (ty[2] + ty[0]);
+    o[q] = make_float2(ox, oy);
+  }
+}
 __device__ __forceinline__ float2 d_gradient_any(const float* __restrict__ img, int w, int h, int x, int y, const Gauss& g) {
   return (x >= 2 && x < w - 2 && y >= 2 && y < h - 2) ? d_gradient_px_interior(img, w, x, y, g) : d_gradient_px(img, w, h, x, y, g);
 }
@@ -80,19 +114,33 @@ __global__ __launch_bounds__(256) void k_gradients_all(const float* __restrict__
   // elements [first, total) of the pyramid plane; grid-stride, so that a launch can be made with few blocks on purpose.  The level
   // is searched once per block and chunk (scalar instructions on the kernel arguments); only a chunk that runs into the next level
   // makes its threads step on.
-  for (unsigned base = first + blockIdx.x * blockDim.x; base < total; base += gridDim.x * blockDim.x) {
-    const unsigned i = base + threadIdx.x;
+  // A thread takes FOUR consecutive plane elements (level offsets and `first` are multiples of 64: a group never straddles levels):
+  // inside a row and away from the border they are one d_gradient_quad_interior and two 16-byte stores, otherwise four single pixels.
+  for (unsigned base = first + blockIdx.x * (blockDim.x * 4); base < total; base += gridDim.x * (blockDim.x * 4)) {
+    const unsigned i = base + 4 * threadIdx.x;
     if (i >= total) continue;
     int lo = 0, hi = t.n - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (base >= t.off[mid]) lo = mid; else hi = mid - 1; }
     while (lo + 1 < t.n && i >= t.off[lo + 1]) ++lo;
     const int w = t.w[lo], h = t.h[lo];
-    const unsigned local = i - t.off[lo];
-    if (local >= unsigned(w) * unsigned(h)) continue;   // padding between levels
+    const unsigned local = i - t.off[lo], npx = unsigned(w) * unsigned(h);
+    if (local >= npx) continue;   // padding between levels
     const int y = int(local / unsigned(w)), x = int(local - unsigned(y) * unsigned(w));
     const float* img = (blockIdx.y ? img1 : img0) + t.off[lo];
     float2* out = (blockIdx.y ? g1 : g0) + t.off[lo];
-    out[local] = d_gradient_any(img, w, h, x, y, g);
+    if (x >= 2 && x + 3 < w - 2 && y >= 2 && y < h - 2) {
+      float2 o[4];
+      d_gradient_quad_interior(img, w, x, y, g, o);
+      float4* o4 = reinterpret_cast<float4*>(out + local);   // local is a multiple of 4: 32-byte aligned
+      o4[0] = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+      o4[1] = make_float4(o[2].x, o[2].y, o[3].x, o[3].y);
+    } else {
+      int xx = x, yy = y;
+      for (int q = 0; q < 4 && local + q < npx; ++q) {
+        out[local + q] = d_gradient_any(img, w, h, xx, yy, g);
+        if (++xx == w) { xx = 0; ++yy; }
+      }
+    }
   }
 }
 void launch_gradients(hipStream_t st, const float* img, int w, int h, float* gxy, const Gauss& g3) {
@@ -104,7 +152,7 @@ void launch_gradients(hipStream_t st, const float* img, int w, int h, float* gxy
 void launch_gradients_all(hipStream_t st, const float* pyr0, const float* pyr1, float* grad0, float* grad1, const LevelTable& t, size_t first,
                           size_t total, const Gauss& g3, int max_blocks, Batch bt) {
   if (total <= first) return;
-  size_t blocks = (total - first + 255) / 256;
+  size_t blocks = (total - first + 1023) / 1024;   // four elements per thread
   if (max_blocks > 0 && blocks > size_t(max_blocks)) blocks = size_t(max_blocks);
   hipLaunchKernelGGL(k_gradients_all, dim3((unsigned)blocks, 2, bt.n), dim3(256), 0, st, pyr0, pyr1, reinterpret_cast<float2*>(grad0),
                      reinterpret_cast<float2*>(grad1), t, (unsigned)first, (unsigned)total, g3, bt.stride);
