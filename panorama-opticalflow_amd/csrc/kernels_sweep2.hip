@@ -72,8 +72,14 @@ struct SwGeom {
 };
 using SwLatency = SwGeom<4, 1>;
 using SwWide = SwGeom<8, 2>;
-constexpr int kWCp = kWC + 1; // row stride of the window: ring column 0 is stored a second time behind column 63, so that the
-                              // right-hand texel of a bilinear footprint is always the NEXT slot (no second ring wrap on the address chain)
+#ifndef PF_WCP_EXTRA
+#define PF_WCP_EXTRA 3
+#endif
+constexpr int kWCp = kWC + PF_WCP_EXTRA; // row stride of the window: ring column 0 is stored a second time behind column 63, so that the
+                              // right-hand texel of a bilinear footprint is always the NEXT slot (no second ring wrap on the address chain).
+                              // 67, not 65: row r of a band sits at column s - r, so with a stride of 65 float2 the gathers of all 8 rows of a
+                              // step (equal flows) fall on the SAME LDS banks (64 r float2 apart); 67 puts them 4 banks apart (a texel pair is
+                              // 4 banks wide).  profiles/r04_sweep_helpers_ab.txt
 // Every wait is bounded by WALL-CLOCK time, not by a spin count: the deadline (kernel entry + a budget the host scales with
 // the launch: 2 s + 1000x the expected duration) sits in LDS and is only looked at every 1024 polls.  A band that is merely
 // slow -- several contexts oversubscribing the GPU, a predecessor workgroup not scheduled yet -- therefore never raises
@@ -89,6 +95,15 @@ constexpr int kWCp = kWC + 1; // row stride of the window: ring column 0 is stor
 #define PF_MARGIN_IN 0
 #endif
 #define PF_MARGIN(top) ((top) == 2 ? PF_MARGIN_X : PF_MARGIN_IN)   // extra columns to fall behind after catching up with the producer (measured: 0 inside a workgroup, 1 across)
+#endif
+#ifndef PF_LOADER_IDLE
+#define PF_LOADER_IDLE 8  // > 0: the loader's ring-full iteration is a short s_sleep of this length instead of a pass through its predicated-off body
+#endif
+#ifndef PF_DRAIN_CHUNK
+#define PF_DRAIN_CHUNK 1  // 1: the drainer writes whole 8-step chunks instead of whatever has been produced
+#endif
+#ifndef PF_DRAIN_SLEEP
+#define PF_DRAIN_SLEEP 8  // drainer: s_sleep between two looks at the bands' step counters when no chunk was complete
 #endif
 #ifndef PF_PUB_SLEEP
 #define PF_PUB_SLEEP 1    // publisher wave: s_sleep between two looks at the last band's step counter
@@ -1084,6 +1099,15 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
     }
     for (;;) {
       const int oh = first ? 0 : ld_cnt(&sm.outHead[w]);
+#if PF_LOADER_IDLE
+      // ring full (the usual state: the loader runs kRS steps ahead): a SHORT idle iteration -- the body below costs a few hundred
+      // predicated-off instructions per pass, issued on the compute wave's own SIMD
+      if (!first && rh + kChunk - oh > kRS) {
+        __builtin_amdgcn_s_sleep(PF_LOADER_IDLE);
+        if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        continue;
+      }
+#endif
       float4 va[kLoadAhead], vb[kLoadAhead], vc[kLoadAhead];
       float2 wv[kLoadAhead][4]; int ws[kLoadAhead][4]; bool wok[kLoadAhead][4]; bool ld[kLoadAhead];
       float2 pv[4][4]; int ps[4][4]; bool pk[4][4];   // first round only: batches 0..3 (0 and 1 lie before the window: they exist when the window does not start at the image border)
@@ -1192,7 +1216,11 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
           int ot = sm.outTail[w];
           const int oh = ld_cnt(&sm.outHead[w]);
           int n = oh - ot; n = n > 8 ? 8 : n;
+#if PF_DRAIN_CHUNK
+          if (n == 8 || (n > 0 && oh >= nsteps)) {   // whole chunks only (one full-wave store per band and chunk; the result ring holds four)
+#else
           if (n > 0) {
+#endif
             const int j = lane >> 3, r = lane & 7, t = ot + j;
             if (j < n) {
               const float2 val = sm.out[w][t % kOS][r];
@@ -1214,7 +1242,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
       if (done) break;
       if (progress) idle = 0;
       else {
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(PF_DRAIN_SLEEP);
         if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
     }

@@ -362,6 +362,13 @@ __global__ __launch_bounds__(TGeom<RG>::kThreads) void k_sweep_t(const float4* _
       const int oh = first ? 0 : ld_cnt(&sm.outHead[w]);
       // LDS records: room in the 16-step ring.  RG: the window batch loaded with chunk rh / 8 overwrites the one the band left with chunk rh / 8 - 4
       const bool ld = rh < nsteps && (rh + kChunk - oh <= (RG ? 32 : tRS));
+#if PF_LOADER_IDLE
+      if (!first && !ld) {   // ring full (the usual state): a short idle iteration instead of a pass through the predicated-off body (see the latency form)
+        __builtin_amdgcn_s_sleep(PF_LOADER_IDLE);
+        if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { give_up(); break; }
+        continue;
+      }
+#endif
       float4 q[kQ];
       float2 wv[kKT]; int ws[kKT]; bool wok[kKT];
 #pragma unroll
@@ -428,7 +435,11 @@ __global__ __launch_bounds__(TGeom<RG>::kThreads) void k_sweep_t(const float4* _
           int ot = sm.outTail[w];
           const int oh = ld_cnt(&sm.outHead[w]);
           int n = oh - ot; n = n > 8 ? 8 : n;
+#if PF_DRAIN_CHUNK
+          if (n == 8 || (n > 0 && oh >= nsteps)) {   // whole chunks: all 64 lanes of the four stores at work, an eighth of the passes
+#else
           if (n > 0) {
+#endif
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int i = lane + 64 * u, j = i & 7, r = i >> 3, t = ot + j;   // a store covers 8 rows x 8 consecutive columns (64-byte runs)
@@ -453,7 +464,7 @@ __global__ __launch_bounds__(TGeom<RG>::kThreads) void k_sweep_t(const float4* _
       if (done) break;
       if (progress) idle = 0;
       else {
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(PF_DRAIN_SLEEP);
         if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { give_up(); break; }
       }
     }

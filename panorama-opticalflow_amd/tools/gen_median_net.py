@@ -13,9 +13,15 @@ Network (per channel; min/max exchanges only, no data-dependent control flow):
      two windows share only ranks 8..13 can be either window's median (an element with rank r in the shared set has rank r .. r+5
      in a window);
   3. per output: merge those six with the output's own fifth column (0 or 5) and take rank 6 of the 11.
+     Rank 6 of sorted six s8..s13 and a sorted column c1..c5 needs no merge: the k-th smallest of two sorted lists is
+     max over i + j = k - 1 of min(a[i+1], b[j+1]), here max(s8, min(s9,c5), min(s10,c4), min(s11,c3), min(s12,c2), min(s13,c1)):
+     five v_min + two v_max3 + one v_max.
 Everything the two outputs do not depend on is removed by a backward liveness pass (an exchange of which only the minimum or only
-the maximum is used costs one instruction instead of two): 180 instructions per channel for two outputs, against ~345 for the
+the maximum is used costs one instruction instead of two): 176 instructions per channel for two outputs, against ~345 for the
 hand-written "forgetful selection" it replaces (kernels_level.hip, rounds 1-3).
+
+(A 2 x 2 quad network -- a column's rows 1-4 sorted once for both output rows, 77.5 instead of 88 instructions per output and channel --
+was generated, verified and measured in round 4: no gain at 36 live float2 inputs per thread, profiles/r04_median_tile_ab.txt.)
 NaN: v_min / v_max return the other operand, v_med3 with a NaN operand returns the minimum of the other two -- a NaN acts as a
 duplicate of a finite neighbour, the result is a finite member of the window (tests/test_gpu_hygiene.py defines exactly that).
 
@@ -51,6 +57,18 @@ class Net:
         a, b, c, d, e = v
         run = [self._op3("min3", a, b, c), self._op3("med3", a, b, c), self._op3("max3", a, b, c)]
         return self.insert(self.insert(run, d), e)
+    def select_mid(self, mid6, col):
+        """rank 6 of the sorted six mid6 = s8..s13 and the sorted five col (see the module docstring)"""
+        terms = [mid6[0]] + [self._op("min", mid6[1 + j], col[4 - j]) for j in range(5)]
+        a = self._op3("max3", terms[0], terms[1], terms[2]); b = self._op3("max3", terms[3], terms[4], terms[5])
+        return self._op("max", a, b)
+    def pair_from_sorted(self, cols):
+        """the two medians (columns 0-4, columns 1-5) from six SORTED columns of five"""
+        s12 = self.merge(cols[1], cols[2])
+        s34 = self.merge(cols[3], cols[4])
+        shared = self.merge(s12, s34)
+        mid6 = shared[7:13]                       # ranks 8..13 of the 20 shared values
+        return self.select_mid(mid6, cols[0]), self.select_mid(mid6, cols[5])
     def merge(self, A, B):
         """Batcher's (m, n) odd-even merge of two ascending sequences of value ids (Knuth 5.3.4)."""
         if not A: return list(B)
@@ -71,13 +89,7 @@ class Net:
 def build():
     net = Net(30)
     cols = [net.sort5([c * 5 + r for r in range(5)]) for c in range(6)]
-    s12 = net.merge(cols[1], cols[2])
-    s34 = net.merge(cols[3], cols[4])
-    shared = net.merge(s12, s34)
-    mid6 = shared[7:13]                       # ranks 8..13 of the 20 shared values
-    out0 = net.merge(mid6, cols[0])[5]        # rank 6 of 11
-    out1 = net.merge(mid6, cols[5])[5]
-    return net, (out0, out1)
+    return net, net.pair_from_sorted(cols)
 
 
 def prune(net, outs):

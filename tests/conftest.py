@@ -42,7 +42,21 @@ def synth():
     return load_pkg_module("synth")
 
 
+def _torch_hip_first():
+    """The PyTorch-ROCm wheel bundles its own libamdhip64; libpanoflow.so links /opt/rocm's.  Both runtimes live in one process, and
+    torch's only finds the GPU if it is initialised BEFORE the system one (seen on the GPU box when a -k selection ran the
+    numpy-only stage tests first: 'No HIP GPUs are available' in the first torch test after them).  Tests that hand torch tensors to the
+    library therefore start torch's runtime before the library's first context, whatever the test order."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+
+
 @pytest.fixture(scope="session")
 def pf():
     """ctypes binding of the product C-ABI (include/panoflow.h)."""
+    _torch_hip_first()
     return load_pkg_module("pyabi")
