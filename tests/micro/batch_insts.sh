@@ -29,3 +29,4 @@ for k, v in sorted(fam.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0)):
     for c in cols: tot[c] += v.get(c, 0)
 print("%-34s" % "total" + "".join("%14.1f" % (tot[c] / 8 / 1e6) for c in cols))
 PY
+rm -rf $D   # the raw counter files are tens of MB: gpurun only copies back 64 MiB

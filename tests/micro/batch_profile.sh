@@ -18,3 +18,4 @@ if [ "$PMC" = "1" ]; then
   done
 fi
 python tests/micro/batch_summary.py $D $R $COLS $ROWS
+rm -rf $D

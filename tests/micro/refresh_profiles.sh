@@ -45,3 +45,4 @@ for r in rows[:12]:
     print("%-60s calls %6s total_ms %10.3f avg_us %10.2f pct %6s" % (r['Name'][:60], r['Calls'], float(r['TotalDurationNs'])/1e6, float(r['AverageNs'])/1e3, r['Percentage']))
 PY
 cat gpurun_out/${R}_bench_line.json | cut -c1-400
+rm -rf gpurun_out/prof_$R gpurun_out/pmcb_*   # raw traces: tens of MB (gpurun copies back 64 MiB at most)
