@@ -237,8 +237,14 @@ __global__ __launch_bounds__(256) void k_gate_bbox_all(const float* __restrict__
     if ((threadIdx.x & 63) == 0 && mxx >= 0) { atomicMin(&sbox[0], mnx); atomicMin(&sbox[1], mny); atomicMax(&sbox[2], mxx); atomicMax(&sbox[3], mxy); }
     __syncthreads();
     if (threadIdx.x == 0 && sbox[2] >= 0) {
-      atomicMin(&work[4 * lvl + 0], sbox[0]); atomicMin(&work[4 * lvl + 1], sbox[1]);
-      atomicMax(&work[4 * lvl + 2], sbox[2]); atomicMax(&work[4 * lvl + 3], sbox[3]);
+      // Look before the atomic: all but the first few blocks of a level lie inside the box found so far, and thousands of atomics on
+      // the same four words serialise in L2 (they were most of this kernel's 250 us on a dense pair).  The box only grows, so a stale
+      // value read here can cause a superfluous atomic, never a missing one.
+      int* wl = &work[4 * lvl];
+      if (sbox[0] < __hip_atomic_load(&wl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&wl[0], sbox[0]);
+      if (sbox[1] < __hip_atomic_load(&wl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&wl[1], sbox[1]);
+      if (sbox[2] > __hip_atomic_load(&wl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&wl[2], sbox[2]);
+      if (sbox[3] > __hip_atomic_load(&wl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&wl[3], sbox[3]);
     }
     __syncthreads();
     mnx = 0x7fffffff; mny = 0x7fffffff; mxx = -1; mxy = -1;
