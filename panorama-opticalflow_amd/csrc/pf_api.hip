@@ -477,14 +477,17 @@ int solve_n(pf_ctx* c, int nb, const uint8_t* const* d_img0, const uint8_t* cons
     launch_fill_u32(sm, reinterpret_cast<unsigned*>(sb.prepcnt[d]), sb.pc_total, 0u, bt);
   }
   HIPCHK(c, hipEventRecord(c->ev_pre, sm));
-  // Fine levels in two launches behind the coarse ones: levels [split2, split) at full width (needed first, a quarter of the fine
-  // pixels), then the finest levels [0, split2) as a NARROW launch -- it runs beside the sweeps of ~30 coarser levels and is not
-  // needed for milliseconds; at full width it took every wave slot of the chip and slowed the first sweeps several times over.
+  // Fine levels in two launches behind the coarse ones: levels [split2, split) (needed first, a quarter of the fine pixels), then the
+  // finest levels [0, split2).  For a lone pair BOTH are NARROW launches: they run beside the sweeps of ~30 coarser levels and are not
+  // needed for milliseconds, while at full width they take every wave slot of the chip -- and a sweep workgroup needs 11 free wave
+  // slots and 115 KB of LDS on ONE CU: the first sweep of the first direction used to wait ~150 us for the full-width launch of
+  // [split2, split) to drain (kernel timeline, tests/micro/pair_timeline.py), and the late direction, which starts k levels behind the
+  // first and ends the call, with it (dense pair 46.23 -> 46.11 ms, profiles/r04_sweep_helpers_ab.txt 8).
   // (a batch keeps every CU busy anyway -- there is nothing to hide a narrow launch behind, and at 64 blocks per image it would run
   // for the whole solve: full width, pf_config::full_width_batch_gradients)
   const int fineBlocks = (nb > 1 && c->cfg.full_width_batch_gradients) ? 0 : c->cfg.fine_gradient_blocks;
   const int split2 = split > 4 ? 4 : 0;
-  if (have_table && split > 0) { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], table, g.off[split2], g.off[split], c->g3_05, 0, bt); }
+  if (have_table && split > 0) { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], table, g.off[split2], g.off[split], c->g3_05, fineBlocks, bt); }
   HIPCHK(c, hipEventRecord(c->ev_fine, sm));
   if (have_table && split2 > 0) { PROF(c, sm, "gradients"); launch_gradients_all(sm, pyrI[0], pyrI[1], grad[0], grad[1], table, 0, g.off[split2], c->g3_05, fineBlocks, bt); }
   HIPCHK(c, hipEventRecord(c->ev_fine2, sm));
