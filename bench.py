@@ -148,6 +148,78 @@ def fixture_verdict(np, cols, rows, alg, seed, L, R, blend, f0, f1, strip):
                          "strip_sha256": want[2]}
 
 
+def config5_strong(torch, np, pf, synth, shard, dist, pfd, local_rank, dev, rank, world, cols, rows, args, pair0):
+    """BASELINE configs[4] as STRONG scaling (an extra key, never `value`): `--pairs-total` (8) fixture pairs -- seeds 1234 ... 1241, the
+    pairs tests/golden/dense_9000x4000[_s<seed>].npz hold the oracle's SHA-256 for -- sharded round-robin over the ranks (pair i on rank
+    i mod N: CPU/main.cpp:70,82, pairs are independent), each rank's share as ONE batch in flight (pf_novel_view_batch_dev), every strip
+    then gathered into rank 0's HBM.  Timed: barrier -> batch call -> gathers -> wait -> barrier, max over ranks, median of 3 after a
+    warm-up.  Off the clock every rank checks the flows + strip of its own pairs against their fixtures (verdicts all-reduced) and rank 0
+    checks every gathered strip against the SHA-256 its producer's fixture holds.  At N = 1 this is the `pairs_9000x4000` figure on the
+    fixture seeds, validated."""
+    import hashlib
+    P = args.pairs_total
+    mine = shard.pairs_for_rank(P, rank, world)
+    per_rank = (P + world - 1) // world
+    pairs = [pair0 if i == rank else synth.make_pair(cols, rows, 1234 + i, dev)[:3] for i in mine]   # (this rank's timed pair IS pair `rank`)
+    strips = [torch.empty((rows, cols, 4), dtype=torch.uint8, device=dev) for _ in mine]
+    fl0 = [torch.empty((rows, cols, 2), dtype=torch.float32, device=dev) for _ in mine]
+    fl1 = [torch.empty((rows, cols, 2), dtype=torch.float32, device=dev) for _ in mine]
+    # rank 0: one receive area per round of the round-robin (slot r of round j = pair j * world + r)
+    recv = [torch.empty((world, rows, cols, 4), dtype=torch.uint8, device=dev) for _ in range(per_rank)] if (pfd and rank == 0) else []
+    dummy = torch.zeros((rows, cols, 4), dtype=torch.uint8, device=dev) if (pfd and len(mine) < per_rank) else None
+    cb = pf.Context(local_rank)
+    torch.cuda.synchronize()
+    nbytes = rows * cols * 4
+
+    def fence():
+        if pfd:
+            pfd.wait(); pfd.barrier()
+        elif dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def once():
+        if mine:
+            cb.novel_view_batch_dev([p[0].data_ptr() for p in pairs], [p[1].data_ptr() for p in pairs], cols, rows, 0, [p[2].data_ptr() for p in pairs],
+                                    [o.data_ptr() for o in strips], [f.data_ptr() for f in fl0], [f.data_ptr() for f in fl1], in_flight=len(mine))
+        if pfd:   # every rank takes part in every round (a rank without a pair in the last round sends a dummy strip)
+            for j in range(per_rank):
+                src = strips[j] if j < len(mine) else dummy
+                pfd.gather_async(src.data_ptr(), recv[j].data_ptr() if rank == 0 else 0, nbytes)
+
+    once(); fence()
+    ts = []
+    for _ in range(3):
+        fence(); t0 = time.perf_counter(); once(); fence(); dt = time.perf_counter() - t0
+        ts.append(pfd.max(dt) if pfd else (shard.max_over_ranks(dt, dev) if dist is not None else dt))
+    t = statistics.median(ts)
+    # ---- validation, off the clock ----
+    ok = True; have = True
+    for k, i in enumerate(mine):
+        v, _ = fixture_verdict(np, cols, rows, args.alg, 1234 + i, pairs[k][0], pairs[k][1], pairs[k][2], fl0[k], fl1[k], strips[k])
+        have = have and v is not None
+        ok = ok and bool(v)
+    if dist is not None:
+        code = torch.tensor([2 if not have else (1 if ok else 0)], device=dev)
+        dist.all_reduce(code, op=dist.ReduceOp.MIN)
+        have = int(code.item()) != 2; ok = int(code.item()) == 1
+    slots_ok = None
+    if pfd and rank == 0 and have:
+        slots_ok = True
+        for i in range(P):
+            fxr = os.path.join(ROOT, "tests", "golden", "dense_%dx%d%s.npz" % (cols, rows, "" if i == 0 else "_s%d" % (1234 + i)))
+            want = str(np.load(fxr)["sha_outputs"][2])
+            slots_ok = slots_ok and hashlib.sha256(recv[i // world][i % world].cpu().numpy().tobytes()).hexdigest() == want
+    cb.close()
+    del pairs, strips, fl0, fl1, recv
+    torch.cuda.empty_cache()
+    return {"value": round(P * cols * rows / 1e6 / t, 3), "unit": "Mpix/s", "scaling": "strong", "pairs_total": P, "ranks": world, "in_flight_per_rank": per_rank,
+            "seconds": round(t, 4), "ms_per_pair": round(1000 * t / P, 3), "runs": 3, "warmup": 1, "statistic": "median of max-over-ranks",
+            "fixture_ok": (ok if have else None), "gathered_strips_equal_fixtures": slots_ok,
+            "gather": "pf_dist_gather_async, %d round(s), inside the timed region" % per_rank if pfd else "none (single rank)",
+            "workload": "BASELINE configs[4] as strong scaling: the %d oracle-fixture pairs (seeds 1234..%d), pair i on rank i mod N, each rank's share as one batch in flight" % (P, 1233 + P)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,6 +231,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the 2000x4000 strip / config-4 chain / throughput / lone-band step-time legs")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--pairs-total", type=int, default=8, help="extra key config5_strong (never `value`): BASELINE configs[4] read as STRONG scaling -- this many fixture pairs "
+                    "(seeds 1234...) in total, sharded round-robin over the ranks, each rank's share as ONE batch in flight, all strips gathered to rank 0; 0 = skip")
     ap.add_argument("--concurrent", type=int, default=1, help="independent pairs in flight per GPU (one context + host thread each); 1 = the BASELINE config")
     args = ap.parse_args()
 
@@ -304,6 +378,9 @@ def main():
     fence()
     prof_all = ctx.profile()
     ctx.profile_reset()
+    strong = None
+    if args.pairs_total > 0 and (cols, rows, args.alg) == (9000, 4000, "pixflow_low") and args.concurrent <= 1 and args.pairs_total <= 8:
+        strong = config5_strong(torch, np, pf, synth, shard, dist if (world > 1 or force_dist) else None, pfd, local_rank, dev, rank, world, cols, rows, args, (L, R, blend))
     if rank == 0:
         mpix = cols * rows / 1e6
         npairs = world * max(1, args.concurrent)
@@ -349,6 +426,8 @@ def main():
             res["roofline"] = {"bound": "hbm", "kernel": "k_sweep_prep+k_sweep2", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None}
             sweep_ms_per_dir = None
         ach_path = b_alg * args.steps / dt / 1e9
+        if strong is not None:
+            res["config5_strong"] = strong
         res["roofline_path"] = {"bound": "hbm", "achieved": round(ach_path, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach_path / 8000.0, 6),
                                 "algorithmic_bytes_per_pair": b_alg}
         res["kernels_ms_per_step"] = {k: round(v[0], 3) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}

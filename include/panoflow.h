@@ -88,6 +88,13 @@ int pf_selftest_packed_chains(pf_ctx* ctx);
 pf_ctx* pf_create_cfg(const pf_config* cfg);
 void pf_destroy(pf_ctx* ctx);
 const char* pf_last_error(const pf_ctx* ctx);  /* ctx may be NULL (creation errors) */
+/* Conditions that cost PERFORMANCE, never results: the last warning raised on this context ("" if none) and how many were raised.
+ * Today there is one: a call that drives more HIP streams than the HIP runtime has hardware queues (pf_novel_view_batch_dev needs
+ * 3 x lanes + 2, pf_stitch_step 5; the runtime sizes its pool from GPU_MAX_HW_QUEUES -- default 4 -- when the process makes its first
+ * HIP call) runs correctly but with streams sharing queues.  The library reads GPU_MAX_HW_QUEUES only to report this; it reads no
+ * other environment variable.  pf_profile_get lists the count as an entry named "warnings". */
+const char* pf_last_warning(const pf_ctx* ctx);
+int pf_warning_count(const pf_ctx* ctx);
 const char* pf_version(void);
 
 /* makeOpticalFlowByName, CPU/PixFlow.hpp:459-500: "pixflow_low" -> 0, "pixflow_search_20" -> 20,
@@ -188,7 +195,7 @@ int pf_novel_view_dev(pf_ctx* ctx, const uint8_t* d_l, const uint8_t* d_r, int c
  * pair are a dependency chain that occupies ~1/4 of the CUs): batches of pairs that share every kernel launch, on one or more
  * lanes of streams (pf_config::batch_pairs).  Arrays of n_pairs device pointers; d_flow_* may be NULL (or hold NULL entries).
  * Same results as n_pairs calls of pf_novel_view_dev.  Needs GPU_MAX_HW_QUEUES >= 3 * lanes + 2 in the environment before the
- * first HIP call, or the lanes' streams share hardware queues. */
+ * first HIP call, or the lanes' streams share hardware queues (then pf_last_warning says so). */
 int pf_novel_view_batch_dev(pf_ctx* ctx, int n_pairs, const uint8_t* const* d_l, const uint8_t* const* d_r, int cols, int rows,
                             int max_percentage, const float* const* d_blend, uint8_t* const* d_out, float* const* d_flow_l2r,
                             float* const* d_flow_r2l, int in_flight);

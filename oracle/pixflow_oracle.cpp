@@ -17,6 +17,11 @@
 // Build: g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared  (see oracle/Makefile).
 //   -ffp-contract=off: the reference's build line (README.md:53, plain g++/nvcc host, baseline
 //   x86-64) has no FMA, and the sweeps make strict '<' decisions on nearly-equal floats.
+//
+// SENSITIVITY VARIANTS (tests/golden/oracle_sensitivity.py only; never defined by oracle/Makefile, the default build has none of
+// them): -DORC_VAR_GAUSS_SYMM (k > 5 Gaussian row pass as centre + symmetric pairs, the order a vectorised OpenCV row filter may use),
+// -DORC_VAR_BOX_FLOAT (box-filter sliding sums in float instead of double), -DORC_VAR_LIBM_ULP (exp / tanhf results moved one ulp up),
+// and the compiler flags -mfma -ffp-contract=fast.  They measure how far a real OpenCV build COULD sit from this restatement.
 // =============================================================================================
 #include <algorithm>
 #include <cmath>
@@ -232,8 +237,13 @@ static void gaussian_blur_f32(const ImgF& src, ImgF& dst, int ksize, double sigm
           s = src.at(y, x, c) * kc[0];
           for (int j = 1; j <= r; ++j) s = s + (src.at(y, reflect101(x - j, w), c) + src.at(y, reflect101(x + j, w), c)) * kc[j];
         } else {
+#ifdef ORC_VAR_GAUSS_SYMM
+          s = src.at(y, x, c) * kc[0];
+          for (int j = 1; j <= r; ++j) s = s + (src.at(y, reflect101(x - j, w), c) + src.at(y, reflect101(x + j, w), c)) * kc[j];
+#else
           s = k[0] * src.at(y, reflect101(x - r, w), c);
           for (int j = 1; j < ksize; ++j) s += k[j] * src.at(y, reflect101(x - r + j, w), c);
+#endif
         }
         tmp.at(y, x, c) = s;
       }
@@ -282,26 +292,31 @@ static void median5(const ImgF& src, ImgF& dst) {
 // [OpenCV smooth.cpp] blur()/boxFilter normalised, CV_32F: RowSum<float,double> + ColumnSum<double,float>
 // (sliding sums in double), anchor k/2, BORDER_REFLECT_101 relative to the WHOLE image (ROI not
 // isolated).  Blurs the roi [x0,x0+rw) x [y0,y0+rh) of img "in place" reading a snapshot of img.
+#ifdef ORC_VAR_BOX_FLOAT
+typedef float box_acc_t;
+#else
+typedef double box_acc_t;
+#endif
 static void box_blur_roi(ImgF& img, int x0, int y0, int rw, int rh, int k) {
   const int W = img.w, H = img.h, a = k / 2;
-  std::vector<double> rows(size_t(rh + k - 1) * rw);  // row sums for source rows y0-a .. y0-a+rh+k-2
+  std::vector<box_acc_t> rows(size_t(rh + k - 1) * rw);  // row sums for source rows y0-a .. y0-a+rh+k-2
   for (int j = 0; j < rh + k - 1; ++j) {
     const int sy = reflect101(y0 - a + j, H);
-    double s = 0;
-    for (int i = 0; i < k; ++i) s += (double)img.at(sy, reflect101(x0 - a + i, W));
+    box_acc_t s = 0;
+    for (int i = 0; i < k; ++i) s += (box_acc_t)img.at(sy, reflect101(x0 - a + i, W));
     rows[size_t(j) * rw] = s;
     for (int x = 1; x < rw; ++x) {
-      s += (double)img.at(sy, reflect101(x0 - a + x - 1 + k, W)) - (double)img.at(sy, reflect101(x0 - a + x - 1, W));
+      s += (box_acc_t)img.at(sy, reflect101(x0 - a + x - 1 + k, W)) - (box_acc_t)img.at(sy, reflect101(x0 - a + x - 1, W));
       rows[size_t(j) * rw + x] = s;
     }
   }
-  const double scale = 1. / ((double)k * k);
-  std::vector<double> sum(rw, 0.0);
+  const box_acc_t scale = box_acc_t(1. / ((double)k * k));
+  std::vector<box_acc_t> sum(rw, 0.0);
   for (int j = 0; j < k - 1; ++j)
     for (int x = 0; x < rw; ++x) sum[x] += rows[size_t(j) * rw + x];
   for (int y = 0; y < rh; ++y)
     for (int x = 0; x < rw; ++x) {
-      const double s0 = sum[x] + rows[size_t(y + k - 1) * rw + x];
+      const box_acc_t s0 = sum[x] + rows[size_t(y + k - 1) * rw + x];
       img.at(y0 + y, x0 + x) = (float)(s0 * scale);
       sum[x] = s0 - rows[size_t(y) * rw + x];
     }
@@ -636,6 +651,10 @@ static void combineNovelViews(const ImgU8& imageL, const ImgU8& imageR, const Im
       const float flowMagRL = sqrtf(fRLx * fRLx + fRLy * fRLy) / float(imageL.w);
       const float colorDiff =
           (std::abs(colorL[0] - colorR[0]) + std::abs(colorL[1] - colorR[1]) + std::abs(colorL[2] - colorR[2])) / 255.0f;
+#ifdef ORC_VAR_LIBM_ULP
+      auto tanhf = [](float v) { return std::nextafterf(::tanhf(v), 2.0f); };
+      auto exp = [](double v) { return std::nextafter(::exp(v), 1e300); };
+#endif
       const float deghostCoef = tanhf(colorDiff * kColorDiffCoef);
       const float alphaL = colorL[3] / 255.0f, alphaR = colorR[3] / 255.0f;
       const double expL = exp(kSoftmaxSharpness * blendL * alphaL * (1.0 + kFlowMagCoef * flowMagRL));

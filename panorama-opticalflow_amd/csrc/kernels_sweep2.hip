@@ -115,6 +115,11 @@ constexpr int kWCp = kWC + PF_WCP_EXTRA; // row stride of the window: ring colum
 #define PF_STR(x) PF_STR2(x)   // ~0.2 s of polling: a stuck band raises ctrl[1] instead of hanging the GPU
 
 struct F2x2 { float a, b, c, d; } __attribute__((aligned(8)));
+#ifdef PF_SWEEP_STATS
+// diagnostics build only (var_libs/lib_stats.so): [0] wave-steps of the latency form, [1] those with >= 1 lane outside the LDS gather window
+// (the whole wave then takes the HBM path), [2] / [3] the same for the throughput form (a step counts once if either gather round left the window)
+__device__ unsigned long long g_sweep_stats[4];
+#endif
 
 // errorFunction (PixFlow.hpp:427-456); identical operation order to kernels_sweep.hip / the oracle.
 __device__ __forceinline__ float d_error2(const float2* __restrict__ g1, int W, float wm2, float hm2, float fW, int x, int y, float i0x, float i0y,
@@ -675,8 +680,11 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
 #ifdef PF_SWEEP_STATS
   if (lane == 0) {
     atomicAdd(&sm.statHits, statHits); atomicAdd(&sm.statSpins, statSpins);
+    atomicAdd(&g_sweep_stats[0], (unsigned long long)nsteps); atomicAdd(&g_sweep_stats[1], (unsigned long long)statOOW);
+#ifdef PF_SWEEP_STATS_PRINT
     if (band < 8 || band % 32 == 1 || (!hasNext && !publishes)) printf("band %d xcc %d: %lld cycles, %lld in chunk-start waits, %d edge waits, %d spins, nsteps %d, IEEE-redo steps %d, out-of-window steps %d, slow chunk starts %d (%d spins; first check failed on rec %d tail %d pub %d next %d), step8 at %lld, end at %lld; since kernel entry: band start %lld, first chunk %lld, end %lld (10ns)\n", band, (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF),
            (long long)__builtin_readcyclecounter() - statT0, statWait, statHits, statSpins, nsteps, statRedo, statOOW, statSlowChunks, statChunkSpins, statFailRec, statFailTail, statFailPub, statFailNext, statR8, (long long)wall_clock64(), statB - sm.statEntry, statC0 - sm.statEntry, (long long)wall_clock64() - sm.statEntry);
+#endif
   }
 #endif
   return !dead;
@@ -1031,7 +1039,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
     else if (top == 2) ok = compute_band<G, 2, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
     else ok = compute_band<G, 0, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
     if (!ok) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#ifdef PF_SWEEP_STATS
+#ifdef PF_SWEEP_STATS_PRINT   // (stage entry only: ctrl[2..3] belong to the next sweep in a whole solve)
     if (lane == 0) { atomicAdd(&ctrl[2], atomicExch(&sm.statHits, 0)); atomicAdd(&ctrl[3], atomicExch(&sm.statSpins, 0)); }
 #endif
     return;
@@ -1366,6 +1374,17 @@ int sweep_pk_probe(hipStream_t st, unsigned* bad) {
 #endif
 }
 
+#ifdef PF_SWEEP_STATS
+}  // namespace pf
+// diagnostics build only: read (and optionally clear) the out-of-window counters
+extern "C" __attribute__((visibility("default"))) int pf_debug_sweep_stats(unsigned long long* out4, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(pf::g_sweep_stats), 32) != hipSuccess) return -1;
+  if (reset) { const unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pf::g_sweep_stats), z, 32) != hipSuccess) return -1; }
+  return 0;
+}
+namespace pf {
+#endif
 #include "kernels_sweep_t.inl"   // the throughput form (32 rows per wave, 2 lanes per pixel): k_sweep_t, launch_sweep_t
 
 // ---- host side ----

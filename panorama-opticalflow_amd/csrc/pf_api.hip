@@ -45,6 +45,7 @@ struct pf_ctx {
   hipEvent_t ev_fine2 = nullptr;  // ... of the finest levels (narrow launch)
   hipEvent_t ev_fine = nullptr;   // gradients of the fine levels done (the directions start on the coarse ones before that)
   std::string err;
+  std::string warn; int warn_count = 0;   // pf_last_warning / pf_warning_count: conditions that cost performance, never results
   std::map<std::string, DevBuf> bufs;  // named grow-only arena: everything a solve needs stays resident
   Gauss g5, g3_05, g3_1, g15;
   int prof = 0;   // 0 off, 1 every kernel family, 2 only the dominant family (the sweeps): fewer events in a timed region
@@ -82,6 +83,19 @@ int fail(pf_ctx* c, int code, const char* fmt, ...) {
   if (c) c->err = buf;
   g_err = buf;
   return code;
+}
+// A call that drives `needed` HIP streams at once on a runtime that maps streams onto fewer hardware queues runs them partly one after the
+// other -- correct, slower, and silent.  The runtime sizes its queue pool from GPU_MAX_HW_QUEUES (default 4) when it is initialised; the
+// library cannot change that any more, but it can say so.  (The only environment variable this library looks at, and only to report.)
+void check_hw_queues(pf_ctx* c, int needed, const char* what) {
+  const char* e = getenv("GPU_MAX_HW_QUEUES");
+  const int queues = e ? atoi(e) : 4;
+  if (queues <= 0 || needed <= queues) return;
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s drives %d HIP streams, but the HIP runtime maps streams onto %d hardware queues (GPU_MAX_HW_QUEUES %s): streams share queues "
+           "and their kernels serialise; set GPU_MAX_HW_QUEUES >= %d in the environment before the first HIP call of the process", what, needed, queues,
+           e ? "as set" : "is unset: the runtime's default", needed);
+  c->warn = buf; c->warn_count += 1;
 }
 #define HIPCHK(c, expr)                                                                                   \
   do {                                                                                                    \
@@ -736,30 +750,36 @@ pf_ctx* create_ctx(const pf_config& cfg, bool lane) {
   if (!ok) { fail(nullptr, PF_ERR_DEVICE, "stream/event creation failed"); delete c; return nullptr; }
   c->cfg = cfg;
   {
-    // Once per device and process: the sweep's asm-block packed chains (csrc/exact_forms.hpp) against the compiler-scheduled forms
-    // of the same arithmetic, on THIS device.  A mismatch means the hardware assumption behind them does not hold here: refuse,
-    // rather than compute wrong flows (a -DPF_SAFE_PK build has no such blocks and passes trivially).
-    static std::mutex probe_mu;
-    static std::map<int, int> probe_result;
-    std::lock_guard<std::mutex> lk(probe_mu);
-    auto it = probe_result.find(device);
-    if (it == probe_result.end()) {
+    // Once per device and process, under one mutex: (i) the sweep's asm-block packed chains (csrc/exact_forms.hpp) against the
+    // compiler-scheduled forms of the same arithmetic, on THIS device -- a mismatch means the hardware assumption behind them does not
+    // hold here: refuse, rather than compute wrong flows (a -DPF_SAFE_PK build has no such blocks and passes trivially); (ii) the
+    // blend's two small tables (kernels_misc.hip: device globals, the same values for every context -- written once, so that no later
+    // context rewrites them under a blend another context has in flight).  Only SUCCESS is cached: a probe that could not run
+    // (a transient allocation / launch failure) is tried again by the next pf_create.
+    struct DeviceInit { bool probed = false; bool tables = false; };
+    static std::mutex init_mu;
+    static std::map<int, DeviceInit> init_done;
+    std::lock_guard<std::mutex> lk(init_mu);
+    DeviceInit& di = init_done[device];
+    if (!di.probed) {
       unsigned* scratch = nullptr;
       int r = -1;
       if (hipMalloc((void**)&scratch, 256) == hipSuccess) { r = sweep_pk_probe(c->s_main, scratch); hipFree(scratch); }
-      it = probe_result.emplace(device, r).first;
+      if (r != 0) {
+        fail(nullptr, PF_ERR_DEVICE, r < 0 ? "the packed-fp32 probe could not run on device %d"
+                                             : "device %d: the sweep's asm-block packed-fp32 chains do not reproduce the compiler-scheduled forms (%d threads differ); rebuild with -DPF_SAFE_PK",
+             device, r);
+        pf_destroy(c);
+        return nullptr;
+      }
+      di.probed = true;
     }
-    if (it->second != 0) {
-      fail(nullptr, PF_ERR_DEVICE, it->second < 0 ? "the packed-fp32 probe could not run on device %d"
-                                                   : "device %d: the sweep's asm-block packed-fp32 chains do not reproduce the compiler-scheduled forms (%d threads differ); rebuild with -DPF_SAFE_PK",
-           device, it->second);
-      pf_destroy(c);
-      return nullptr;
+    if (!di.tables) {
+      launch_blend_tables(c->s_main);
+      if (hipStreamSynchronize(c->s_main) != hipSuccess) { fail(nullptr, PF_ERR_DEVICE, "device %d: the blend tables could not be initialised", device); pf_destroy(c); return nullptr; }
+      di.tables = true;
     }
   }
-  // the blend's two small tables (kernels_misc.hip): device globals, the same values from every context
-  launch_blend_tables(c->s_main);
-  if (hipStreamSynchronize(c->s_main) != hipSuccess) { fail(nullptr, PF_ERR_DEVICE, "device %d: the blend tables could not be initialised", device); pf_destroy(c); return nullptr; }
   c->g5 = make_gauss(5, 0.25); c->g3_05 = make_gauss(3, 0.5); c->g3_1 = make_gauss(3, 1.0); c->g15 = make_gauss(15, 8.0);
   // Pre-sizing: every buffer a bidirectional solve / a stitch step on max_cols x max_rows needs is
   // allocated now, so that the first call does not pay ~40 hipMallocs.  0 x 0 = allocate lazily (the arena only grows).
@@ -837,6 +857,8 @@ void pf_destroy(pf_ctx* c) {
 }
 
 const char* pf_last_error(const pf_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+const char* pf_last_warning(const pf_ctx* c) { return c ? c->warn.c_str() : ""; }
+int pf_warning_count(const pf_ctx* c) { return c ? c->warn_count : 0; }
 
 int pf_max_percentage_by_name(const char* name) {
   if (name && strcmp(name, "pixflow_low") == 0) return 0;
@@ -994,6 +1016,7 @@ int pf_novel_view_batch_dev(pf_ctx* c, int n_pairs, const uint8_t* const* d_l, c
   if (in_flight > n_pairs) in_flight = n_pairs > 0 ? n_pairs : 1;
   int nlanes = 1, per_batch = 1;
   batch_split(c, in_flight, nlanes, per_batch);
+  check_hw_queues(c, 3 * nlanes + 2, "pf_novel_view_batch_dev");   // three streams per lane + this context's blend-ramp and copy streams
   while ((int)c->lanes.size() < nlanes - 1) {
     pf_config lc = c->cfg; lc.max_cols = per_batch > 1 ? 0 : cols; lc.max_rows = per_batch > 1 ? 0 : rows;   // a batching lane lives in its slabs: nothing to pre-size
     pf_ctx* l = create_ctx(lc, true);
@@ -1271,6 +1294,7 @@ int pf_stitch_step(pf_ctx* c, const uint8_t* l, const uint8_t* r, int cols, int 
   if (!l) return fail(c, PF_ERR_ARG, "null pointer");
   if (int e = check_dims(c, cols, rows, cols / 20)) return e;
   if (step < size_t(cols) * 4 || (out && ostep < size_t(cols) * 4)) return fail(c, PF_ERR_ARG, "row step too small");
+  check_hw_queues(c, 5, "pf_stitch_step");   // front end, two flow directions, blend ramp, prefetch copy
   const size_t n = size_t(cols) * rows;
   uint8_t* dl = (uint8_t*)ensure(c, "ch_l", n * 4); uint8_t* dr = (uint8_t*)ensure(c, "ch_r", n * 4); uint8_t* dfin = (uint8_t*)ensure(c, "ch_final", n * 4);
   uint8_t* dm = (uint8_t*)ensure(c, "st_map", n); uint8_t* dol = (uint8_t*)ensure(c, "st_ovl", n * 4); uint8_t* dor = (uint8_t*)ensure(c, "st_ovr", n * 4);
@@ -1443,7 +1467,7 @@ int pf_stage_sweep(pf_ctx* c, const float* g0, const float* g1, const float* blu
   HIPCHK(c, hipMemcpyAsync(hc, ctrl, 16, hipMemcpyDeviceToHost, sm));
   if (int e = stage_down(c, flow, df, n * 8)) return e;
   if (hc[1]) return fail(c, PF_ERR_TIMEOUT, "sweep band timed out");
-#ifdef PF_SWEEP_STATS
+#ifdef PF_SWEEP_STATS_PRINT
   fprintf(stderr, "[panoflow] sweep %dx%d: edge waits %d, spin iterations %d\n", w, h, hc[2], hc[3]);
 #endif
   return 0;
@@ -1531,8 +1555,15 @@ int pf_stage_blend_smooth(pf_ctx* c, float* blend, const float* md, int cols, in
 // ---- profiling ----
 int pf_profile_enable(pf_ctx* c, int on) { if (!c) return PF_ERR_ARG; c->prof = on < 0 ? 0 : (on > 2 ? 1 : on); return 0; }
 int pf_profile_reset(pf_ctx* c) { if (!c) return PF_ERR_ARG; for (auto& t : c->prof_tot) t = ProfEntry(); return 0; }
-int pf_profile_count(pf_ctx* c) { return c ? (int)c->prof_names.size() : 0; }
+// (a context that has raised warnings lists them as one more entry, "warnings": 0 ms, launches = their number)
+int pf_profile_count(pf_ctx* c) { return c ? (int)c->prof_names.size() + (c->warn_count > 0 ? 1 : 0) : 0; }
 int pf_profile_get(pf_ctx* c, int idx, char* name, int cap, double* ms, int* launches) {
+  if (c && c->warn_count > 0 && idx == (int)c->prof_names.size()) {
+    if (name && cap > 0) { strncpy(name, "warnings", cap - 1); name[cap - 1] = 0; }
+    if (ms) *ms = 0.0;
+    if (launches) *launches = c->warn_count;
+    return 0;
+  }
   if (!c || idx < 0 || idx >= (int)c->prof_names.size()) return PF_ERR_ARG;
   if (name && cap > 0) { strncpy(name, c->prof_names[idx].c_str(), cap - 1); name[cap - 1] = 0; }
   if (ms) *ms = c->prof_tot[idx].ms;

@@ -57,6 +57,9 @@ def lib(exp=False):
         _lib.pf_last_error.restype = C.c_char_p
         _lib.pf_last_error.argtypes = [C.c_void_p]
         _lib.pf_version.restype = C.c_char_p
+        _lib.pf_last_warning.restype = C.c_char_p
+        _lib.pf_last_warning.argtypes = [C.c_void_p]
+        _lib.pf_warning_count.argtypes = [C.c_void_p]
         _lib.pf_dev_alloc.restype = C.c_void_p
         _lib.pf_dev_alloc.argtypes = [C.c_void_p, C.c_size_t]
         _lib.pf_dev_free.argtypes = [C.c_void_p, C.c_void_p]
@@ -80,7 +83,7 @@ def lib(exp=False):
 
 
 EXPORTS = [
-    "pf_device_count", "pf_create", "pf_config_init", "pf_create_cfg", "pf_destroy", "pf_last_error", "pf_version", "pf_max_percentage_by_name",
+    "pf_device_count", "pf_create", "pf_config_init", "pf_create_cfg", "pf_destroy", "pf_last_error", "pf_last_warning", "pf_warning_count", "pf_version", "pf_max_percentage_by_name",
     "pf_flow", "pf_flow_bidir", "pf_blend", "pf_novel_view", "pf_stitch_prepare", "pf_stitch_match", "pf_stitch_generate_blend", "pf_stitch_raw_blend", "pf_stitch_gather", "pf_stitch_step", "pf_stitch_prefetch",
     "pf_dev_alloc", "pf_dev_free", "pf_host_alloc", "pf_host_free", "pf_upload", "pf_download", "pf_sync", "pf_checksum_dev", "pf_selftest_packed_chains",
     "pf_flow_bidir_dev", "pf_blend_dev", "pf_novel_view_dev", "pf_novel_view_batch_dev",
@@ -427,6 +430,10 @@ class Context:
     def last_swept_steps(self):
         """dependent wavefront steps of one direction of the last solve (windows of gated pixels)"""
         return int(self.l.pf_last_swept_steps(self.h))
+
+    def last_warning(self):
+        """(text of the last performance warning raised on this context or "", how many were raised)  -- include/panoflow.h"""
+        return self.l.pf_last_warning(self.h).decode(), int(self.l.pf_warning_count(self.h))
 
     # ---- profiling ----
     def profile_enable(self, on=True):

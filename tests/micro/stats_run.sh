@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-band counters of the sweep kernel (needs var_libs/lib_stats.so = a -DPF_SWEEP_STATS build): stats_run.sh WxH
+# per-band counters of the sweep kernel (needs var_libs/lib_stats.so = a -DPF_SWEEP_STATS -DPF_SWEEP_STATS_PRINT build): stats_run.sh WxH
 cd $GRAFT_REPO_ROOT
 cp panorama-opticalflow_amd/libpanoflow.so /tmp/lib_orig.so
 cp var_libs/lib_stats.so panorama-opticalflow_amd/libpanoflow.so

@@ -86,3 +86,9 @@ def test_bench_forced_dist_path_validates_itself():
     assert a["fixture_ok"] is True and b["fixture_ok"] is True
     assert "pf_dist_" in b["config"]["final_gather"] and "every rank's slot equals its oracle fixture's strip: True" in b["config"]["final_gather"]
     assert b["value"] > 0.8 * a["value"]
+    # config 5 read as STRONG scaling (round-4 review, next #5): the eight fixture pairs as one batch, every pair's flows + strip held to its
+    # oracle fixture; with the forced RCCL path additionally gathered (8 rounds of one rank) and every gathered strip checked by SHA-256
+    for ln in (a, b):
+        st = ln["config5_strong"]
+        assert st["scaling"] == "strong" and st["pairs_total"] == 8 and st["in_flight_per_rank"] == 8 and st["fixture_ok"] is True and st["value"] > 0
+    assert a["config5_strong"]["gathered_strips_equal_fixtures"] is None and b["config5_strong"]["gathered_strips_equal_fixtures"] is True

@@ -186,3 +186,44 @@ def test_generate_blend_reads_the_current_map(ctx, orc, synth):
     assert np.array_equal(emp, ed)
     bl2, md2 = ctx.stitch_generate_blend(ed)
     assert np.array_equal(bl2, ebl) and np.array_equal(md2, emd) and not np.array_equal(bl2, bl)
+
+
+def test_missing_hardware_queues_raise_a_warning():
+    """The throughput mode needs GPU_MAX_HW_QUEUES >= 3 x lanes + 2 in the environment before the first HIP call (include/panoflow.h);
+    a caller that forgets gets correct results from serialised streams.  That must not be silent (round-4 review, weak #7): a fresh
+    process WITHOUT the variable runs a batch (32 in flight = two lanes = 8 streams > the runtime's default 4 queues), gets the same
+    strips as one-at-a-time calls, and finds the condition in pf_last_warning / pf_warning_count / the profile's "warnings" entry; the
+    same process with the variable set high enough raises nothing."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import os, sys, numpy as np, torch
+        sys.path.insert(0, os.path.join(%r, "tests"))
+        from conftest import load_pkg_module
+        pf = load_pkg_module("pyabi"); synth = load_pkg_module("synth")
+        dev = torch.device("cuda", 0)
+        cols, rows, n = 96, 80, 18
+        pairs = [synth.make_pair(cols, rows, 40 + i, dev)[:3] for i in range(n)]
+        outs = [torch.zeros((rows, cols, 4), dtype=torch.uint8, device=dev) for _ in range(n)]
+        c = pf.Context(0)
+        assert c.last_warning() == ("", 0)
+        c.novel_view_batch_dev([p[0].data_ptr() for p in pairs], [p[1].data_ptr() for p in pairs], cols, rows, 0, [p[2].data_ptr() for p in pairs],
+                               [o.data_ptr() for o in outs], None, None, in_flight=32)
+        one = torch.zeros_like(outs[0])
+        c.novel_view_dev(pairs[7][0].data_ptr(), pairs[7][1].data_ptr(), cols, rows, 0, pairs[7][2].data_ptr(), one.data_ptr())
+        assert torch.equal(one, outs[7])
+        msg, cnt = c.last_warning()
+        print("WARN", cnt, msg)
+        print("PROF", c.profile().get("warnings"))
+    ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    def run(env_queues):
+        env = dict(os.environ); env.pop("GPU_MAX_HW_QUEUES", None)
+        if env_queues: env["GPU_MAX_HW_QUEUES"] = env_queues
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout
+    out = run(None)
+    warn = [l for l in out.splitlines() if l.startswith("WARN")][0]
+    assert warn.split()[1] == "1" and "GPU_MAX_HW_QUEUES" in warn and "8 HIP streams" in warn and ">= 8" in warn, warn
+    assert "PROF (0.0, 1)" in out, out
+    out = run("16")
+    assert [l for l in out.splitlines() if l.startswith("WARN")][0].split()[1] == "0", out
