@@ -1475,6 +1475,12 @@ bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
   // measured-and-rejected forms, lab build only (profiles/r04_wide_sweep.txt, r04_throughput_form.txt): the latency step with two compute
   // waves per SIMD, and the throughput form with loader-staged records (three bands per workgroup)
   if (wide == 3 && !a.sparse) return launch_sweep_t<false>(st, a, rec);
+  // 4 = the throughput form with the FUSED prepass (round 5, profiles/r05_fused_prepass.txt): three bands per workgroup, the loader waves
+  // compute the records (no k_sweep_prep launch, no record stream through HBM); bands along y keep the record-stream form
+  if (wide == 4 && !a.sparse) {
+    const SweepWindow wt = make_sweep_window(a.W, a.H, a.forward, a.ax0, a.ay0, a.ax1, a.ay1, tRows, TGeom<false>::kWaves, kChunk);
+    return wt.tr ? launch_sweep_t<true>(st, a, rec) : launch_sweep_t<false, true>(st, a, rec);
+  }
   if (wide == 1) return launch_sweep2_form<SwWide>(st, a, rec);
 #endif
   return launch_sweep2_form<SwLatency>(st, a, rec);

@@ -289,13 +289,33 @@ __device__ __forceinline__ bool compute_band_t(SmemTF<RG>& sm, const float2* __r
 }
 }  // namespace
 
-template <bool RG, bool TR, bool FWD>
-__global__ __launch_bounds__(TGeom<RG>::kThreads) void k_sweep_t(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
+// FU (with !RG): FUSED PREPASS -- the band's loader wave computes the 32-byte records itself (the expressions of k_sweep_prep<32, false>:
+// d_make_record_at) while it runs ahead of the wavefront and writes them straight into the LDS ring: no prepass launch, and the record
+// stream's round trip through HBM (32 B written + 32 B read back per level-pixel and sweep) is gone.  A pixel's own flow C is read before
+// its step is computed and overwritten (by the drainer) only afterwards, so reading it from the plane being updated is safe.
+// Wave roles.  Waves of a workgroup land on SIMD (wave % 4).  Record-stream forms: waves [0, n) compute, [n, 2n) load, then publisher, poller,
+// drainer.  FUSED form (n = 3, 12 waves): its loaders carry a third of a band's instructions (one energy per pixel), and a loader that shares
+// a SIMD with a compute wave slows that band -- and, bands being chained, the sweep -- by what it issues (first measurement: 0.71 instead of
+// 0.46 us per step).  So the three compute waves get SIMDs 0-2, ALL three loaders SIMD 3 (waves 3, 7, 11), the light helpers waves 4-6;
+// waves 8-10 exit at once.
+template <bool RG, bool FU> struct TRoles {
+  static constexpr int n = TGeom<RG>::kWaves;
+  static constexpr int kThreads = FU ? 64 * 12 : TGeom<RG>::kThreads;
+  __device__ static int loader_of(int wave) { return FU ? ((wave & 3) == 3 ? (wave >> 2) : -1) : ((wave >= n && wave < 2 * n) ? wave - n : -1); }
+  __device__ static bool publisher(int wave) { return wave == (FU ? 4 : 2 * n); }
+  __device__ static bool poller(int wave) { return wave == (FU ? 5 : 2 * n + 1); }
+  __device__ static bool drainer(int wave) { return wave == (FU ? 6 : 2 * n + 2); }
+};
+template <bool RG, bool FU, bool TR, bool FWD>
+__global__ __launch_bounds__((TRoles<RG, FU>::kThreads)) void k_sweep_t(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
                                                       unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H, int nstepsPad, int nbands,
-                                                      float rW, float rEps, int uLo, int LSv, int bandLo, long long budgetTicks, size_t bstride) {
+                                                      float rW, float rEps, int uLo, int LSv, int bandLo, long long budgetTicks, size_t bstride,
+                                                      const float2* __restrict__ g0, const float2* __restrict__ blurred, const uint8_t* __restrict__ gate) {
+  static_assert(!FU || !RG, "the fused prepass fills the loader-staged record ring");
   {
     const size_t bo = size_t(blockIdx.z) * bstride;
     PF_BOFF(rec, bo); PF_BOFF(g1, bo); PF_BOFF(flow, bo); PF_BOFF(boundary, bo); PF_BOFF(ctrl, bo);
+    if (FU) { PF_BOFF(g0, bo); PF_BOFF(blurred, bo); PF_BOFF(gate, bo); }
   }
   constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0, tWaves = TGeom<RG>::kWaves;
   __shared__ SmemTF<RG> sm;
@@ -333,12 +353,13 @@ __global__ __launch_bounds__(TGeom<RG>::kThreads) void k_sweep_t(const float4* _
     return;
   }
   __builtin_amdgcn_s_setprio(1);
-  if (wave < 2 * tWaves) {
+  using Roles = TRoles<RG, FU>;
+  if (Roles::loader_of(wave) >= 0) {
     // ======================= loader of band w: records + skewed gather window HBM -> LDS =======================
     // Window batch b = the ring slots d in [8b - 8, 8b) (d = u - uLo + window row), 8 x 49 texels: row a holds u = uLo + d - a.  A band working
     // on chunk j reads d in [8j - 6, 8j + 31] = batches j .. j+4: batch j+4 is loaded with chunk j (batches 0..3 in the first round) and
     // overwrites batch j-4, which the band left when it finished chunk j-4 (the 16-step record ring asks for more: chunk j-2).
-    const int w = wave - tWaves;
+    const int w = Roles::loader_of(wave);
     if (w >= nact) return;
     constexpr int kKT = (8 * tWA + 63) / 64;   // window texels per lane and batch (7)
     int ta[kKT], td[kKT]; bool tvalid[kKT];
@@ -369,6 +390,33 @@ __global__ __launch_bounds__(TGeom<RG>::kThreads) void k_sweep_t(const float4* _
     };
     const float4* recw = rec + size_t(band0 + w) * nstepsPad * (tRows * 2);
     constexpr int kQ = 8 * tRows * 2 / 64;   // a chunk's records: 512 float4, 8 per lane, the ring's layout is the stream's
+    // ---- fused prepass (FU): this lane computes the records of row fr, steps rh + fj0 .. + 3 of every chunk = four CONSECUTIVE pixels of one
+    // image row when the bands step along x (32-byte runs of every input plane).  Their inputs are requested one round ahead.
+    const int fr = lane >> 1, fj0 = (lane & 1) * 4;
+    struct FusedIn { float2 f, g, bl; int gate; } fin_[4];   // (what was loaded; the geometry is recomputed where it is used: registers are what this wave is short of)
+    const int fib = (bandLo + band0 + w) * tRows + fr;
+    const float fwm2 = float(W) - 2.0f, fhm2 = float(H) - 2.0f, ffW = float(W);
+    typedef __attribute__((address_space(3))) const float2 lds_cf2;
+    lds_cf2* lwin = (lds_cf2*)&sm.win[w][0][0];
+    const int lob = v0;
+    auto fused_geom = [&](int r0, int i, int& x, int& y, int& ia) -> bool {
+      const int sstep = r0 + fj0 + i;
+      ia = uLo + sstep - fr;
+      const bool valid = sstep - fr >= 0 && ia < uLo + LSv && ia < LS && fib < LB;
+      const int cxs = TR ? fib : ia, cys = TR ? ia : fib;   // position in sweep order
+      x = valid ? (FWD ? cxs : W - 1 - cxs) : 0; y = valid ? (FWD ? cys : H - 1 - cys) : 0;
+      return valid;
+    };
+    auto fetch_inputs = [&](int r0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int x, y, ia;
+        fused_geom(r0, i, x, y, ia);
+        const int idx = y * W + x;
+        fin_[i].f = flow[idx]; fin_[i].gate = gate[idx]; fin_[i].g = g0[idx]; fin_[i].bl = blurred[idx];
+      }
+    };
+    if (FU) fetch_inputs(0);
     int rh = 0, idle = 0;
     bool first = true;
     for (;;) {
@@ -387,12 +435,15 @@ __global__ __launch_bounds__(TGeom<RG>::kThreads) void k_sweep_t(const float4* _
 #pragma unroll
       for (int k = 0; k < kKT; ++k) { wv[k] = make_float2(0.f, 0.f); ws[k] = 0; wok[k] = false; }
       if (ld) {
-        if (!RG) {
+        if (!RG && !FU) {
           const float4* src = recw + size_t(rh) * (tRows * 2);
 #pragma unroll
           for (int k = 0; k < kQ; ++k) q[k] = src[lane + 64 * k];
         }
-        const int b = rh / kChunk + 4;
+        // FU: one batch further ahead -- this round's records are computed from batches <= rh / 8 + 4, which earlier rounds have stored,
+        // while this round's window loads are still in flight (the loader-staged ring keeps the loader at most two chunks ahead of the
+        // band, so batch j + 5 only overwrites batch j - 3, which chunk j - 3 -- finished -- was the last to read)
+        const int b = rh / kChunk + (FU ? 5 : 4);
 #pragma unroll
         for (int k = 0; k < kKT; ++k) {
           const float2* p = win_addr(b, k, ws[k]);
@@ -401,9 +452,22 @@ __global__ __launch_bounds__(TGeom<RG>::kThreads) void k_sweep_t(const float4* _
         }
       }
       if (first) {
-        float2 pv[4][kKT]; int ps[4][kKT]; bool pk[4][kKT];
+        constexpr int kFirst = FU ? 5 : 4;
+        if (FU) {
+          // one batch at a time (five round trips, once per band, all loaders at the same time): five batches in flight would cost the fused
+          // loader 140 registers it does not have (three waves per SIMD: 168) and put spills into its steady-state loop
+#pragma unroll 1
+          for (int b = 0; b < kFirst; ++b) {
+            float2 pv1[kKT]; int ps1[kKT]; bool pk1[kKT];
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+            for (int k = 0; k < kKT; ++k) { pv1[k] = make_float2(0.f, 0.f); const float2* p = win_addr(b, k, ps1[k]); pk1[k] = p != nullptr; if (pk1[k]) pv1[k] = *p; }
+#pragma unroll
+            for (int k = 0; k < kKT; ++k) if (pk1[k]) win_store(ps1[k], pv1[k]);
+          }
+        } else {
+        float2 pv[kFirst][kKT]; int ps[kFirst][kKT]; bool pk[kFirst][kKT];
+#pragma unroll
+        for (int b = 0; b < kFirst; ++b)
 #pragma unroll
           for (int k = 0; k < kKT; ++k) {
             pv[b][k] = make_float2(0.f, 0.f);
@@ -412,22 +476,44 @@ __global__ __launch_bounds__(TGeom<RG>::kThreads) void k_sweep_t(const float4* _
             if (pk[b][k]) pv[b][k] = *p;
           }
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < kFirst; ++b)
 #pragma unroll
           for (int k = 0; k < kKT; ++k) if (pk[b][k]) win_store(ps[b][k], pv[b][k]);
+        }
         first = false;
       }
       if (ld) {
-        if (!RG) {
+        if (!RG && !FU) {
           float4* d4 = &sm.rec[RG ? 0 : w][RG ? 0 : rh % tRS][0][0];
 #pragma unroll
           for (int k = 0; k < kQ; ++k) d4[lane + 64 * k] = q[k];
+        }
+        if (FU) {
+          // this lane's four records of the chunk from the inputs requested a round ago.  E(C) with the sweep's own d_error_fast: its
+          // texels come from the band's LDS window (batches <= rh / 8 + 4 are in place), its range guard is checked per record and the
+          // IEEE form (d_error2g: the prepass kernel's) takes over outside it -- the same bits either way (exact_forms.hpp)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            int px, py, pia;
+            const bool valid = fused_geom(rh, i, px, py, pia);
+            const bool on = valid && fin_[i].gate != 0;
+            const float2 f = fin_[i].f, g = fin_[i].g, bl = fin_[i].bl;
+            int em; float vm;
+            float e0 = d_error_fast<TR, FWD, tWA, kWCPT, true>(g1, lwin, lob, W, H, fwm2, fhm2, ffW, rW, f2p{float(px), float(py)}, g.x, g.y, bl.x, bl.y,
+                                                                f2p{on ? f.x : 0.f, on ? f.y : 0.f}, em, vm);
+            if (__builtin_expect(__any(on && (em < -94 || !(vm <= 0x1p100f))), 0))
+              e0 = d_error2g(g1, W, fwm2, fhm2, ffW, rW, px, py, g.x, g.y, bl.x, bl.y, on ? f.x : 0.f, on ? f.y : 0.f);
+            float4* d4 = &sm.rec[RG ? 0 : w][RG ? 0 : (rh + fj0 + i) % tRS][fr][0];
+            d4[0] = on ? make_float4(g.x, g.y, bl.x, bl.y) : make_float4(0.f, 0.f, 0.f, 0.f);
+            d4[1] = make_float4(on ? e0 : kKeepEnergy, valid ? f.x : 0.f, valid ? f.y : 0.f, (on && pia > 0) ? e0 : kKeepEnergy);
+          }
         }
 #pragma unroll
         for (int k = 0; k < kKT; ++k) if (wok[k]) win_store(ws[k], wv[k]);
         rh += kChunk;
         st_cnt(&sm.recHead[w], rh);
         idle = 0;
+        if (FU && rh < nsteps) fetch_inputs(rh);
       }
       if (rh >= nsteps) break;
       if (!ld) {
@@ -437,7 +523,7 @@ __global__ __launch_bounds__(TGeom<RG>::kThreads) void k_sweep_t(const float4* _
     }
     return;
   }
-  if (wave == 2 * tWaves + 2) {
+  if (Roles::drainer(wave)) {
     // ======================= drainer: results LDS ring -> flow plane =======================
     int idle = 0;
     for (;;) {
@@ -483,7 +569,7 @@ __global__ __launch_bounds__(TGeom<RG>::kThreads) void k_sweep_t(const float4* _
     }
     return;
   }
-  if (wave == 2 * tWaves) {
+  if (Roles::publisher(wave)) {
     // ======================= publisher: last row of the workgroup -> granules in HBM =======================
     if (!publishes) return;
     unsigned long long* bnd_out = boundary + size_t(wg + 1) * LSv;
@@ -512,14 +598,24 @@ __global__ __launch_bounds__(TGeom<RG>::kThreads) void k_sweep_t(const float4* _
   }
   // ======================= poller: previous workgroup's granules HBM -> LDS ring =======================
   {
-    if ((wg == 0 && !staticTop) || wave != 2 * tWaves + 1) return;
+    if ((wg == 0 && !staticTop) || !Roles::poller(wave)) return;
     const unsigned long long* bnd_in = boundary + size_t(wg) * LSv;
     int bh = 0, idle = 0;
     while (bh < LSv) {
       const int oh0 = ld_cnt(&sm.outHead[0]);
       if (bh + 64 - oh0 <= kBS) {
         unsigned long long g = kNotReady;
-        if (bh + lane < LSv) g = __hip_atomic_load(bnd_in + bh + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bh + lane < LSv) {
+          if (FU && wg == 0) {
+            // (wg == 0 only gets here with a static top row) the row above the window never changes during this sweep: read from the plane itself
+            const int ia = uLo + bh + lane, ibt = bandLo * tRows - 1;
+            const int cxs = TR ? ibt : ia, cys = TR ? ia : ibt;
+            const int x = FWD ? cxs : W - 1 - cxs, y = FWD ? cys : H - 1 - cys;
+            g = pack2(flow[size_t(y) * W + x]);
+          } else {
+            g = __hip_atomic_load(bnd_in + bh + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
         const bool ready = (g != kNotReady) || (bh + lane >= LSv);
         const unsigned long long m = __ballot(ready);
         const int n = (m == ~0ull) ? 64 : __builtin_ctzll(~m);
@@ -540,7 +636,7 @@ __global__ __launch_bounds__(TGeom<RG>::kThreads) void k_sweep_t(const float4* _
 }
 
 // host side of the throughput form
-template <bool RG>
+template <bool RG, bool FU = false>
 static bool launch_sweep_t(hipStream_t st, const SweepArgs& a, float* rec) {
   constexpr int tWaves = TGeom<RG>::kWaves;
   const SweepWindow win = make_sweep_window(a.W, a.H, a.forward, a.ax0, a.ay0, a.ax1, a.ay1, tRows, tWaves, kChunk);
@@ -548,13 +644,15 @@ static bool launch_sweep_t(hipStream_t st, const SweepArgs& a, float* rec) {
   const int tr = win.tr, uLo = win.uLo, uHi = win.uHi, LSv = win.LSv, bandLo = win.bandLo, nbands = win.nbands;
   const int nwg = win.nwg, nbandsPad = nwg * tWaves, nstepsPad = win.nstepsPad;
   const float rW = (float)(1.0 / (double)(float)a.W), rEps = (float)(1.0 / (double)kGradEpsilon);
-  hipExtLaunchKernelGGL((k_sweep_prep<tRows, false>), dim3((unsigned)((nstepsPad + 256 / tRows - 1) / (256 / tRows)), (unsigned)nbandsPad, a.bt.n), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate,
-                        a.flow, a.W, a.H, a.forward, tr, nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo,
-                        bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride);
+  if (!FU)
+    hipExtLaunchKernelGGL((k_sweep_prep<tRows, false>), dim3((unsigned)((nstepsPad + 256 / tRows - 1) / (256 / tRows)), (unsigned)nbandsPad, a.bt.n), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate,
+                          a.flow, a.W, a.H, a.forward, tr, nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo,
+                          bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride);
+  hipEvent_t evs = FU ? a.ev_start : nullptr;   // without a prepass kernel the sweep launch carries both events
   const long long budget = 200000000ll + 1000ll * 50ll * (long long)(nstepsPad + 40 * nbands);
-  const dim3 grid(nwg, 1, a.bt.n), block(TGeom<RG>::kThreads);
-  const float4* r4 = reinterpret_cast<const float4*>(rec);
-#define PF_LAUNCH_SWEEP_T(TRV, FWV) hipExtLaunchKernelGGL((k_sweep_t<RG, TRV, FWV>), grid, block, 0, st, nullptr, a.ev_stop, 0, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.bt.stride)
+  const dim3 grid(nwg, 1, a.bt.n), block(TRoles<RG, FU>::kThreads);
+  const float4* r4 = FU ? nullptr : reinterpret_cast<const float4*>(rec);
+#define PF_LAUNCH_SWEEP_T(TRV, FWV) hipExtLaunchKernelGGL((k_sweep_t<RG, FU, TRV, FWV>), grid, block, 0, st, evs, a.ev_stop, 0, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.bt.stride, a.g0, a.blurred, a.gate)
   if (tr) { if (a.forward) PF_LAUNCH_SWEEP_T(true, true); else PF_LAUNCH_SWEEP_T(true, false); }
   else { if (a.forward) PF_LAUNCH_SWEEP_T(false, true); else PF_LAUNCH_SWEEP_T(false, false); }
 #undef PF_LAUNCH_SWEEP_T

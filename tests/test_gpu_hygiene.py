@@ -196,9 +196,11 @@ def test_missing_hardware_queues_raise_a_warning():
     same process with the variable set high enough raises nothing."""
     import os, subprocess, sys, textwrap
     code = textwrap.dedent('''
-        import os, sys, numpy as np, torch
-        sys.path.insert(0, os.path.join(%r, "tests"))
-        from conftest import load_pkg_module
+        import importlib.util, os, sys, numpy as np, torch
+        def load_pkg_module(name):   # (not through tests/conftest.py: importing it sets GPU_MAX_HW_QUEUES)
+            spec = importlib.util.spec_from_file_location("pano_amd_" + name, os.path.join(%r, "panorama-opticalflow_amd", name + ".py"))
+            mod = importlib.util.module_from_spec(spec); sys.modules["pano_amd_" + name] = mod; spec.loader.exec_module(mod)
+            return mod
         pf = load_pkg_module("pyabi"); synth = load_pkg_module("synth")
         dev = torch.device("cuda", 0)
         cols, rows, n = 96, 80, 18
