@@ -46,6 +46,7 @@ constexpr float kKeepEnergy = -1.0f;   // below every real energy: E(C), E(C+dx)
 constexpr int kChunk = 8;    // steps streamed per helper iteration and wave
 constexpr int kRad = 8;      // LDS window of the gathered plane: +-kRad texels around the band
 constexpr int kWC = 64;      // window ring along the step axis (columns)
+constexpr int kWRing = 32;   // FOLLOW: window ring across the band (rows)
 // Two workgroup shapes of the SAME step (compute_band is one function; every test holds both to the same bits):
 //  * SwLatency -- ONE pair: 4 compute waves (one per SIMD: alone on its SIMD a wave is offered an issue slot every ~5.5 cycles,
 //    and the step's dependency chain cannot use a second wave) + 4 loaders + publisher + poller + drainer = 704 threads, 113 KB of
@@ -66,6 +67,11 @@ struct SwGeom {
   static constexpr int kLoadAhead = BPW == 1 ? 3 : 1;   // chunks per band the loader fetches in one round when the ring has room
   static constexpr int kOS = 32;                 // result ring (steps)
   static constexpr int kWA = BPW * kRows + 2 * kRad + 1;   // window extent across the band(s): 25 / 33
+  // FOLLOW (latency form, round 5): the gather window is a TORUS -- 64 ring columns along the step axis as before, and kWRing = 32 ring
+  // rows across the band -- addressed by the texel's ABSOLUTE sweep-order coordinates, and its loader centres it on pixel + (rounded
+  // blurred flow of the chunk) instead of on the pixel.  See the loader in k_sweep2.  The wide form (lab build) keeps the fixed window.
+  static constexpr bool kFollow = BPW == 1;
+  static constexpr int kWRows = kFollow ? 32 + 1 : kWA;    // rows of LDS per window (torus: ring row 0 again behind row 31)
   static constexpr int kWavesTotal = NW + kLoaders + 3;    // + publisher, poller, drainer
   static constexpr int kThreads = 64 * kWavesTotal;
   static constexpr int kScratch = BPW == 1 ? NW : 1;       // scratch areas for the non-publishing lanes (write-only: may be shared)
@@ -116,8 +122,9 @@ constexpr int kWCp = kWC + PF_WCP_EXTRA; // row stride of the window: ring colum
 
 struct F2x2 { float a, b, c, d; } __attribute__((aligned(8)));
 #ifdef PF_SWEEP_STATS
-// diagnostics build only (var_libs/lib_stats.so): [0] wave-steps of the latency form, [1] those with >= 1 lane outside the LDS gather window
-// (the whole wave then takes the HBM path), [2] / [3] the same for the throughput form (a step counts once if either gather round left the window)
+// diagnostics build only (var_libs/lib_stats.so): [0] wave-steps of the latency form, [1] its gather rounds (one per step) in which >= 1 lane of a
+// pixel that is updated left the LDS gather window (the whole wave then takes the HBM path), [2] / [3] the same for the throughput form (two
+// gather rounds per step)
 __device__ unsigned long long g_sweep_stats[4];
 #endif
 
@@ -210,10 +217,14 @@ __device__ __forceinline__ float dpp_shl0(float src) {
 // SKEW (throughput form, 32 rows per band): the window ring is indexed by u + (window row) instead of u -- at any step all 32 rows of a
 // band then touch the same ~31 ring slots although their pixels are 32 columns apart (a ring of 64 serves; unskewed it would take 128).
 // Moving one window row down also moves one slot on, and the first TWO ring columns are stored again behind column 63 (kWCPT).
-template <bool TR, bool FWD, int kWA, int WCP = kWCp, bool SKEW = false>
+// FOLLOW: the window is a torus addressed by the texel's absolute coordinates and centred by its loader on pc = the pixel + an integer offset
+// (the rounded blurred flow of the chunk, kept with the record): resident are the texels of [pc - 8, pc + 8] in both axes, so the test is on
+// the sample position against pc -- a flow of any size whose sample falls within 7 of the centre is served from LDS.  A pixel that is not updated carries pc = NaN: its (discarded) evaluations never
+// send the wave through the HBM path -- they read a valid LDS slot with whatever it holds ("not > 7" is true for a NaN distance).
+template <bool TR, bool FWD, int kWA, int WCP = kWCp, bool SKEW = false, bool FOLLOW = false>
 __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __attribute__((address_space(3))) const float2* win, int ob, int W, int H, float wm2, float hm2,
                                               float fW, float rW, f2p pos, float i0x, float i0y, float bx, float by, f2p fd,
-                                              int& emin, float& vmax) {
+                                              int& emin, float& vmax, f2p pc = f2p{0.f, 0.f}) {
   // ---- A ----  (pos = the pixel's (x, y), fd = the candidate flow: packed fp32 wherever both components take the same operation)
   const float fdx = fd.x, fdy = fd.y;
   const f2p match = pos + fd;
@@ -224,7 +235,15 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   // |flow| <= kRad-1 in both components keeps the four texels inside the window: the clamps only move (cx,cy) towards the
   // pixel, and int(c), int(c)+1 then lie within [f-7, f+8].  Tested on the flow itself (known at the start of the step),
   // not on the clamped position: one max + one compare, off the address chain.  (NaN flows compare false -> HBM path.)
-  const bool inwin = __builtin_fmaxf(fabsf(fdx), fabsf(fdy)) <= float(kRad - 1);
+  bool inwin;
+  if (FOLLOW) {
+    // The loader keeps every window centre INSIDE the image (it clamps the chunk's offset), so the test may be made on the sample position
+    // before the clamp to the image -- off the address chain, beside it: a sample within 7 of a centre in [0, W - 1] that the clamp moves
+    // to 0 or W - 2 is still within 7 of it.  The subtraction is exact to well under a texel, and the window holds one texel more than the test
+    // admits on either side ([pc - 8, pc + 8]): a difference that rounds onto +-7 is covered.
+    const f2p dm = match - pc;
+    inwin = !(__builtin_fmaxf(fabsf(dm.x), fabsf(dm.y)) > float(kRad - 1));   // (NaN centre = a pixel that is not updated: "inside")
+  } else inwin = __builtin_fmaxf(fabsf(fdx), fabsf(fdy)) <= float(kRad - 1);
   // sweep-order coordinates of texel (x0,y0): u along the step axis, v across the bands
   // The 2x2 footprint in sweep order is (v0, v0 + sg) x (u0, u0 + sg), sg = +1 forward / -1 backward.  Addressed from its LOWER
   // corner (vlo, ulo) it is two adjacent slots in two adjacent window rows -- the slot after ring column 63 holds column 0 again
@@ -232,7 +251,7 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   const int cxl = FWD ? x0 : W - 2 - x0, cyl = FWD ? y0 : H - 2 - y0;
   const int ulo = TR ? cyl : cxl, vlo = TR ? cxl : cyl;
   // out-of-window lanes are clamped to a valid window row (they read garbage that the HBM path below overwrites)
-  const int alo = min(max(vlo - ob, 0), kWA - 2);
+  const int alo = FOLLOW ? ((vlo - ob) & (kWRing - 1)) : min(max(vlo - ob, 0), kWA - 2);   // FOLLOW: ring row of the absolute texel row (always a valid slot)
   auto q = [&](int dr, int dc) { return (FWD ? dr : 1 - dr) * (WCP + (SKEW ? 1 : 0)) + (FWD ? dc : 1 - dc); };   // texel (v0 + sg*dr, u0 + sg*dc), relative to the corner
   const int o00 = q(0, 0);                            // texel (x0, y0)
   const int o10 = TR ? q(1, 0) : q(0, 1);             // texel (x0+1, y0)
@@ -255,6 +274,9 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   // wave-uniform test first: the common "every lane inside the window" case costs a compare + one scalar branch, not an exec-mask
   // save / restore around an empty block (two instructions of ~150 per step; a step is issue-bound, profiles/r03_sweep_step_isa.txt)
   if (__builtin_expect(__any(!inwin), 0)) {
+#ifdef PF_SWEEP_STATS
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_sweep_stats[SKEW ? 3 : 1], 1ull);   // gather rounds of a wave that left the LDS window
+#endif
     if (!inwin) {
       const float2* p = g1 + (y0 * W + x0);
       t00 = p[0]; t10 = p[1]; t01 = p[W]; t11 = p[W + 1];
@@ -365,7 +387,7 @@ struct SmemT {
   float4 rec[G::kWaves][G::kRS][kRows][G::kRQ];
   float2 recxy[G::kRQ == 3 ? 1 : G::kWaves][G::kRQ == 3 ? 1 : G::kRS][kRows];   // wide form: the records' (x, y)
   float2 out[G::kWaves][G::kOS][kRows];
-  float2 win[G::kLoaders][G::kWA][kWCp];  // (I1x,I1y) texels around each band (pair of bands), sweep-order coordinates, ring along the step axis (+ column 0 again)
+  float2 win[G::kLoaders][G::kWRows][kWCp];  // (I1x,I1y) texels around each band (pair of bands), sweep-order coordinates, ring along the step axis (+ column 0 again)
   float2 scratch[G::kScratch][128];       // where lanes 1-7 of a group "store" in the publishing step (lane + 8 * step-in-chunk)
   unsigned long long bnd[kBS];            // granules of the previous workgroup's last row (poller -> wave 0), valid below bndHead
   int recHead[G::kWaves];   // steps of records available to wave w        (stream helper -> compute)
@@ -467,7 +489,8 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
   // flow-control counters for the NEXT chunk, read one chunk ahead (they only grow, a stale value is conservative)
   int fcRec = 0, fcTail = 0, fcPub = 0, fcNext = 0;
   float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;   // this step's record (read one step ahead)
-  float2 rc = make_float2(0.f, 0.f);                          // only the first half of the record's third quad is used
+  float2 rc = make_float2(0.f, 0.f);                          // the record's third quad: the pixel's (x, y) ...
+  float2 rp = make_float2(0.f, 0.f);                          // ... and, FOLLOW, the centre of its gather window (x + ox, y + oy), written by the loader
   for (int s0 = 0; s0 < nsteps; s0 += kChunk) {
     // ---- once per 8 steps: records of the chunk present, result-ring slots of the chunk free ----
     if (dead) return false;
@@ -505,7 +528,8 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
         // record was already there, which the one-chunk-old counter just confirmed unless we had to wait.
         const float4* rp0 = &sm.rec[w][s0 % kRS][r][0];
         ra = rp0[0]; rb = rp0[1]; rc = (G::kRQ == 3) ? *reinterpret_cast<const float2*>(rp0 + 2) : sm.recxy[G::kRQ == 3 ? 0 : w][G::kRQ == 3 ? 0 : s0 % kRS][r];
-        asm volatile("" : "+v"(ra.x), "+v"(ra.y), "+v"(ra.z), "+v"(ra.w), "+v"(rb.x), "+v"(rb.y), "+v"(rb.z), "+v"(rb.w), "+v"(rc.x), "+v"(rc.y));
+        if (G::kFollow) rp = *(reinterpret_cast<const float2*>(rp0 + 2) + 1);
+        asm volatile("" : "+v"(ra.x), "+v"(ra.y), "+v"(ra.z), "+v"(ra.w), "+v"(rb.x), "+v"(rb.y), "+v"(rb.z), "+v"(rb.w), "+v"(rc.x), "+v"(rc.y), "+v"(rp.x), "+v"(rp.y));
       }
     }
     // read the counters again for the next chunk; the loads complete in the shadow of this chunk's steps
@@ -604,7 +628,7 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
       // previous pixel along the step axis = own result of the previous step; previous pixel across = DPP/ring.
       // Reference order is always "previous column, then previous row" (PixFlow.hpp:319-320 / :332-333).
       float2 fin = rC;   // (a step in which no pixel of the wave is updated: rC = C everywhere)
-      float4 na, nb; float2 nc;
+      float4 na, nb; float2 nc, np_ = rp;
       int hN = 0; unsigned long long tvN = tv;
       // next step's inputs (LDS): records (unconditional: past the chunk it reads a slot that is reloaded at the chunk
       // start anyway), producer counter, then the top value.  Issued behind the gather inside the evaluation below.
@@ -623,17 +647,16 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
       const bool okL = transposed ? hasCross : hasAlong, okT = transposed ? hasAlong : hasCross;
       const float2 cand = cnd;
       int emin; float vmax;
-#ifdef PF_SWEEP_STATS
-      if (__any(!(__builtin_fmaxf(fabsf(cand.x + addx), fabsf(cand.y + addy)) <= float(kRad - 1)))) ++statOOW;
-#endif
       const f2p fdv = f2p{cand.x, cand.y} + f2p{addx, addy};
-      float e = d_error_fast<TR, FWD, kWA>(g1, win, ob, W, H, wm2, hm2, fW, rW, posv, ra.x, ra.y, ra.z, ra.w, fdv, emin, vmax);
+      float e = d_error_fast<TR, FWD, kWA, kWCp, false, G::kFollow>(g1, win, ob, W, H, wm2, hm2, fW, rW, posv, ra.x, ra.y, ra.z, ra.w, fdv, emin, vmax, f2p{rp.x, rp.y});
       { // Only what the step uses is loaded: a loaded register nothing reads is handed out again by the register allocator at once,
         // and the hardware must then wait for the load in flight before the new value may be written (s_waitcnt right behind the
         // loads, ~50 cycles per step).  Transposed sweeps do not use Ea, the fourth float of the second quad.
         typedef float f3v __attribute__((ext_vector_type(3)));
-        const f4v q0 = rpn[0]; const f2w q2 = *xyn;
-        na = make_float4(q0.x, q0.y, q0.z, q0.w); nc = make_float2(q2.x, q2.y);
+        const f4v q0 = rpn[0];
+        if (G::kFollow) { const f4v q2 = rpn[2]; nc = make_float2(q2.x, q2.y); np_ = make_float2(q2.z, q2.w); }
+        else { const f2w q2 = *xyn; nc = make_float2(q2.x, q2.y); }
+        na = make_float4(q0.x, q0.y, q0.z, q0.w);
         if (transposed) { const f3v q1 = *(__attribute__((address_space(3))) const f3v*)(rpn + 1); nb = make_float4(q1.x, q1.y, q1.z, 0.f); }
         else { const f4v q1 = rpn[1]; nb = make_float4(q1.x, q1.y, q1.z, q1.w); } }
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -655,8 +678,10 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
         // and the hardware must then wait for the load in flight before the new value may be written (s_waitcnt right behind the
         // loads, ~50 cycles per step).  Transposed sweeps do not use Ea, the fourth float of the second quad.
         typedef float f3v __attribute__((ext_vector_type(3)));
-        const f4v q0 = rpn[0]; const f2w q2 = *xyn;
-        na = make_float4(q0.x, q0.y, q0.z, q0.w); nc = make_float2(q2.x, q2.y);
+        const f4v q0 = rpn[0];
+        if (G::kFollow) { const f4v q2 = rpn[2]; nc = make_float2(q2.x, q2.y); np_ = make_float2(q2.z, q2.w); }
+        else { const f2w q2 = *xyn; nc = make_float2(q2.x, q2.y); }
+        na = make_float4(q0.x, q0.y, q0.z, q0.w);
         if (transposed) { const f3v q1 = *(__attribute__((address_space(3))) const f3v*)(rpn + 1); nb = make_float4(q1.x, q1.y, q1.z, 0.f); }
         else { const f4v q1 = rpn[1]; nb = make_float4(q1.x, q1.y, q1.z, q1.w); } }
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -674,13 +699,13 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
       asm volatile("" ::: "memory");   // after the result (LDS operations of one wave execute in issue order)
       __hip_atomic_store(cntp, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       asm volatile("" : "+v"(cntp));
-      ra = na; rb = nb; rc = nc;
+      ra = na; rb = nb; rc = nc; rp = np_;
     }
   }
 #ifdef PF_SWEEP_STATS
   if (lane == 0) {
     atomicAdd(&sm.statHits, statHits); atomicAdd(&sm.statSpins, statSpins);
-    atomicAdd(&g_sweep_stats[0], (unsigned long long)nsteps); atomicAdd(&g_sweep_stats[1], (unsigned long long)statOOW);
+    atomicAdd(&g_sweep_stats[0], (unsigned long long)nsteps);   // ([1] is counted where it happens: d_error_fast)
 #ifdef PF_SWEEP_STATS_PRINT
     if (band < 8 || band % 32 == 1 || (!hasNext && !publishes)) printf("band %d xcc %d: %lld cycles, %lld in chunk-start waits, %d edge waits, %d spins, nsteps %d, IEEE-redo steps %d, out-of-window steps %d, slow chunk starts %d (%d spins; first check failed on rec %d tail %d pub %d next %d), step8 at %lld, end at %lld; since kernel entry: band start %lld, first chunk %lld, end %lld (10ns)\n", band, (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF),
            (long long)__builtin_readcyclecounter() - statT0, statWait, statHits, statSpins, nsteps, statRedo, statOOW, statSlowChunks, statChunkSpins, statFailRec, statFailTail, statFailPub, statFailNext, statR8, (long long)wall_clock64(), statB - sm.statEntry, statC0 - sm.statEntry, (long long)wall_clock64() - sm.statEntry);
@@ -711,7 +736,9 @@ __device__ __forceinline__ void d_make_record_at(int band, int s, int r, bool in
   const int ia = uLo + s - r, ib = (bandLo + band) * ROWS + r;
   // A pixel that is not updated (gate <= 0) carries E(C) = kKeepEnergy and rC = C: every proposal's energy is >= 0 (or NaN), so
   // the selection keeps rC = C -- the sweep's step needs no "if not gated keep C" of its own (two v_cndmask per step).
-  a = make_float4(0.f, 0.f, 0.f, 0.f); b = make_float4(kKeepEnergy, 0.f, 0.f, kKeepEnergy); c = a;
+  // (third quad: (x, y) and -- for the latency form's flow-following window -- z = w = 0 for a pixel that is updated, NaN otherwise: the sweep's
+  // loader adds the window centre x + ox, y + oy there, and a NaN centre means "never leaves the window", see d_error_fast<FOLLOW>)
+  a = make_float4(0.f, 0.f, 0.f, 0.f); b = make_float4(kKeepEnergy, 0.f, 0.f, kKeepEnergy); c = make_float4(0.f, 0.f, __builtin_nanf(""), __builtin_nanf(""));
   if (inside && s - r >= 0 && ia < uHi && ia < LS && ib < LB) {
     const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;   // position in sweep order
     const int x = forward ? cx : W - 1 - cx, y = forward ? cy : H - 1 - cy;
@@ -723,6 +750,7 @@ __device__ __forceinline__ void d_make_record_at(int band, int s, int r, bool in
       const float2 g = g0[idx], bl = blurred[idx];
       const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
       a = make_float4(g.x, g.y, bl.x, bl.y);
+      c.z = 0.f; c.w = 0.f;
       const float e0 = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x, f.y);
       b.x = e0;
       if (RC) {
@@ -1056,34 +1084,89 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
   }
   if constexpr (G::kBPW == 1) if (wave >= kWaves && wave < 2 * kWaves) {
     // ======================= loader of compute wave w: records + gather window HBM -> LDS, up to kRS steps ahead =======================
-    // Window batch b = the 8 texel columns (along the step axis) [8b-16, 8b-8) x kWA texels across the band.
-    // A compute wave working on chunk j (steps 8j..8j+7) reads columns [8j-15, 8j+16], i.e. batches j..j+4,
-    // so chunk j is published only after batch j+4 has landed (batches 0..3 in the first round, batch j+4 with chunk j).
+    // THE WINDOW FOLLOWS THE FLOW (round 5).  Until round 4 the window held the texels within +-8 of the band's pixels, so a proposal
+    // was served from LDS only while |flow| <= 7 -- every larger one sent its whole wave to HBM (x8 displacement: 63 % of the steps, dense
+    // pair 46 -> 68 ms).  Now the window of chunk j (steps 8j .. 8j + 7) is centred on pixel + o(j), o(j) = the blurred flow at the chunk's
+    // centre pixel rounded to integers (the flow is median-filtered and diffused at every level: inside 8 rows x 15 columns it stays
+    // within a pixel or two of that), moving by at most one texel per chunk and axis:
+    //   * the LDS window is a TORUS addressed by the texel's absolute sweep-order coordinates: slot = ((v - ob) & 31) * stride + (u & 63)
+    //     (ring row 0 again behind row 31, ring column 0 again behind column 63: a 2 x 2 footprint never wraps);
+    //   * chunk j needs columns [uLo + 8j - 15 + ou, uLo + 8j + 15 + ou] x rows [vb - 8 + ov, vb + 15 + ov] ((ou, ov) = o(j) in sweep order):
+    //     the loader keeps a column front and loads the 7 / 8 / 9 new columns of the chunk's 24 rows (8 + the change of ou), and, when ov
+    //     moved, the ONE new row over the columns already present; what it overwrites (column - 64, row -+ 32) left every active chunk's
+    //     rectangle long ago (the loader is at most 4 chunks ahead: 31 + 24 + 3 columns < 64, 24 + 3 rows < 32);
+    //   * the pixel's window centre (x + ox, y + oy) travels with its record (third quad, z / w: patched in here), so the step's test is
+    //     |clamped sample - centre| <= 7 (d_error_fast<FOLLOW>): same texels as the HBM path => same bits, whatever the offsets are.
     // One loader per compute wave: its in-order memory queue holds nothing but this band's loads, and a round
     // (issue up to kLoadAhead chunks, wait once, registers -> LDS, publish) costs one HBM round trip.
     const int w = wave - kWaves;
     if (w >= nact) return;
-    // texel t = lane + 64k (k = 0..3) of a batch: position c along the step axis, a across the band -- loop invariant
-    int tc[4], ta[4]; bool tvalid[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int t = lane + 64 * k;
-      tc[k] = TR ? t / kWA : (t & 7); ta[k] = TR ? t % kWA : (t >> 3); tvalid[k] = t < 8 * kWA;
-    }
     float2* winw = &sm.win[w][0][0];
-    auto win_addr = [&](int b, int k, int& slot) -> const float2* {   // texel k of this lane in batch b
-      const int u = uLo + 8 * b - 16 + tc[k], v = (bandLo + band0 + w) * kRows - kRad + ta[k];   // absolute sweep-order texel
-      slot = ta[k] * kWCp + (u & (kWC - 1));
-      if (!tvalid[k] || u < 0 || u >= LS || v < 0 || v >= LB) return nullptr;
+    const int vb = (bandLo + band0 + w) * kRows;   // the band's first row (column, transposed) in sweep order
+    const int ob = vb - kRad;                      // origin of the ring rows (compute_band's `ob`)
+    auto tex_ptr = [&](int u, int v) -> const float2* {   // texel (u, v) in sweep order; nullptr outside the image (never sampled: samples are clamped)
+      if (u < 0 || u >= LS || v < 0 || v >= LB) return nullptr;
       const int cxc = TR ? v : u, cyc = TR ? u : v;
       const int x = FWD ? cxc : W - 1 - cxc, y = FWD ? cyc : H - 1 - cyc;
       return g1 + (y * W + x);
     };
-    // ring column 0 also goes to the slot behind column 63 (kWCp); tc/ta are loop invariant, a batch is 8 consecutive columns:
-    // texel k of this lane lands on ring column 0 in the batches with (uLo + 8b - 16 + tc[k]) % 64 == 0
-    auto win_store = [&](int slot, float2 v) {
-      winw[slot] = v;
-      if (slot % kWCp == 0) winw[slot + kWC] = v;
+    auto win_store = [&](int u, int v, float2 val) {
+      const int rr = (v - ob) & (kWRing - 1), cc = u & (kWC - 1);
+      float2* q = winw + rr * kWCp + cc;
+      q[0] = val;
+      if (cc == 0) q[kWC] = val;
+      if (rr == 0) { q[kWRing * kWCp] = val; if (cc == 0) q[kWRing * kWCp + kWC] = val; }
+    };
+    // the same for the block of new columns, whose duplicates are rare per texel (1 in 64 / 1 in 32): wave-uniform guards around them
+    // (dupc: the block's columns contain ring column 0; dupr: its rows contain ring row 0) keep the usual store at two address instructions + one write
+    auto win_store_block = [&](int u, int v, float2 val, bool dupc, bool dupr) {
+      const int rr = (v - ob) & (kWRing - 1), cc = u & (kWC - 1);
+      float2* q = winw + rr * kWCp + cc;
+      q[0] = val;
+      if (dupc) { if (cc == 0) q[kWC] = val; }
+      if (dupr) { if (rr == 0) { q[kWRing * kWCp] = val; if (cc == 0) q[kWRing * kWCp + kWC] = val; } }
+    };
+    // image index of texel (u, v) = iC + iA * u + iB * v (mirrored for the backward sweep): the block's addresses are one wave-uniform base + a
+    // per-lane constant, and a block that lies inside the image (nearly all do) needs no bounds tests
+    const int iA = TR ? (FWD ? W : -W) : (FWD ? 1 : -1), iB = TR ? (FWD ? 1 : -1) : (FWD ? W : -W), iC = FWD ? 0 : W * H - 1;
+    // a block of 8 columns x 24 rows: texel t = lane + 64 k (k < 3), dealt out so that a wave's loads run along memory
+    constexpr int kRectRows = kRows + 2 * kRad;   // 24
+    int tdc[3], tdr[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const int t = lane + 64 * k; tdc[k] = TR ? t / kRectRows : (t & 7); tdr[k] = TR ? t % kRectRows : (t >> 3); }
+    int tio[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tio[k] = iA * tdc[k] + iB * tdr[k];
+    // rounded blurred flow at the centre pixel of chunk (obase + lane): one gather serves 64 chunks
+    // (kept as integers: everything per chunk below is wave-uniform integer arithmetic, i.e. work for the scalar unit, not for the vector
+    // pipe this wave shares with its band's compute wave)
+    int ocx = 0, ocy = 0; int obase = -(1 << 20);
+    auto refill_offsets = [&](int jb) {
+      obase = jb;
+      int ia = uLo + 8 * (jb + lane) + 3 - kRows / 2;
+      ia = ia < uLo ? uLo : ia; ia = ia > uLo + LSv - 1 ? uLo + LSv - 1 : ia; ia = ia > LS - 1 ? LS - 1 : ia; ia = ia < 0 ? 0 : ia;
+      int ibc = vb + kRows / 2; ibc = ibc > LB - 1 ? LB - 1 : ibc;
+      const int cxc = TR ? ibc : ia, cyc = TR ? ia : ibc;
+      const int x = FWD ? cxc : W - 1 - cxc, y = FWD ? cyc : H - 1 - cyc;
+      const float2 bl = blurred[y * W + x];
+      const float rx = __builtin_rintf(bl.x), ry = __builtin_rintf(bl.y);
+      ocx = (fabsf(rx) < 1.0e6f) ? int(rx) : 0;   // NaN / inf / absurd: no offset
+      ocy = (fabsf(ry) < 1.0e6f) ? int(ry) : 0;
+    };
+    // image-axis offset (ox, oy) -> sweep order (mirrored for the backward sweep), cut back so that EVERY window centre of chunk j lies inside
+    // the image (d_error_fast<FOLLOW> tests the sample before its clamp to the image): the chunk's pixels sit in columns [uLo + 8j - 7,
+    // uLo + 8j + 7] (clipped to the image) and rows [vb, vb + 7].  The cut only binds at the image borders; there the offset may move by more
+    // than one texel per chunk, towards the pixels: columns that are present.
+    auto sweep_offsets = [&](int j, int& ox, int& oy, int& ou, int& ov) {
+      ou = TR ? (FWD ? oy : -oy) : (FWD ? ox : -ox);
+      ov = TR ? (FWD ? ox : -ox) : (FWD ? oy : -oy);
+      int plo = uLo + 8 * j - (kRows - 1), phi = uLo + 8 * j + (kChunk - 1);
+      plo = plo < 0 ? 0 : (plo > LS - 1 ? LS - 1 : plo); phi = phi < 0 ? 0 : (phi > LS - 1 ? LS - 1 : phi);
+      const int vhi = vb + kRows - 1 > LB - 1 ? LB - 1 : vb + kRows - 1;
+      ou = ou < -plo ? -plo : ou; ou = ou > LS - 1 - phi ? LS - 1 - phi : ou;
+      ov = ov < -vb ? -vb : ov; ov = ov > LB - 1 - vhi ? LB - 1 - vhi : ov;
+      const int sx = TR ? ov : ou, sy = TR ? ou : ov;   // back to image axes
+      ox = FWD ? sx : -sx; oy = FWD ? sy : -sy;
     };
     constexpr bool fused = MODE == 1;
     const float4* recw = fused ? nullptr : rec + size_t(band0 + w) * nstepsPad * (kRows * 3);
@@ -1092,8 +1175,12 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
     // fused prepass: this lane's slot inside a chunk is (step offset lane >> 3, row lane & 7)
     const int lj = lane >> 3, lr = lane & 7;
     const int lib = (bandLo + band0 + w) * kRows + lr;       // position across the bands (absolute)
+    // record stream: lane i of a chunk's three loads holds quads i, i + 64, i + 128 of its 192; quad q is part q % 3 of record q / 3 -- the
+    // third part (x, y, -, -) gets the window centre (x + ox, y + oy) in z / w
+    bool isC[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) isC[k] = (lane + 64 * k) % 3 == 2;
     int rh = 0, idle = 0;
-    bool first = true;
     if (MODE == 2) {
       // the records of this workgroup's four bands are complete when its counter has reached their number: ONE word polled
       // relaxed, ONE agent acquire after the match (drops this CU's stale L1 lines), then plain loads (G16 R1)
@@ -1105,6 +1192,30 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
+    // ---- chunk 0's whole rectangle (31 columns x 24 rows, four blocks in one round trip) ----
+    int pox, poy; int front, pov;
+    {
+      refill_offsets(0);
+      pox = __builtin_amdgcn_readfirstlane(ocx); poy = __builtin_amdgcn_readfirstlane(ocy);
+      int ou, ov; sweep_offsets(0, pox, poy, ou, ov);
+      const int c0 = uLo - 15 + ou, c1 = uLo + 16 + ou, r0 = vb - kRad + ov;
+      float2 pv[4][3]; int pu[4][3], pvv[4][3]; bool pk[4][3];
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          pu[b][k] = c0 + 8 * b + tdc[k]; pvv[b][k] = r0 + tdr[k];
+          const float2* q = pu[b][k] < c1 ? tex_ptr(pu[b][k], pvv[b][k]) : nullptr;
+          pk[b][k] = q != nullptr; pv[b][k] = make_float2(0.f, 0.f);
+          if (pk[b][k]) pv[b][k] = *q;
+        }
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if (pk[b][k]) win_store(pu[b][k], pvv[b][k], pv[b][k]);
+      front = c1; pov = ov;
+    }
+    bool first = true;
     for (;;) {
       const int oh = first ? 0 : ld_cnt(&sm.outHead[w]);
 #if PF_LOADER_IDLE
@@ -1116,23 +1227,26 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
         continue;
       }
 #endif
-      float4 va[kLoadAhead], vb[kLoadAhead], vc[kLoadAhead];
-      float2 wv[kLoadAhead][4]; int ws[kLoadAhead][4]; bool wok[kLoadAhead][4]; bool ld[kLoadAhead];
-      float2 pv[4][4]; int ps[4][4]; bool pk[4][4];   // first round only: batches 0..3 (0 and 1 lie before the window: they exist when the window does not start at the image border)
+      first = false;
+      float4 va[kLoadAhead], vb4[kLoadAhead], vc[kLoadAhead];
+      bool ld[kLoadAhead];
+      float cox[kLoadAhead], coy[kLoadAhead]; bool cdupc[kLoadAhead], cdupr[kLoadAhead];
+      // window work of a chunk: the block of new columns (3 texels per lane), a ninth column (lanes 0-23), one new row (one texel per lane)
+      float2 wv[kLoadAhead][5]; int wu[kLoadAhead][5], wvv[kLoadAhead][5]; bool wok[kLoadAhead][5];
       // fused prepass, phase 1: the inputs of up to kLoadAhead chunks are requested together (one round trip)
       float2 qf[kLoadAhead], qg[kLoadAhead], qb[kLoadAhead]; int qgate[kLoadAhead], qx[kLoadAhead], qy[kLoadAhead], ia_of[kLoadAhead]; bool qvalid[kLoadAhead];
 #pragma unroll
       for (int c = 0; c < kLoadAhead; ++c) {
         const int r0 = rh + c * kChunk;
-        va[c] = z4; vb[c] = z4; vc[c] = z4;
+        va[c] = z4; vb4[c] = z4; vc[c] = z4; cox[c] = 0.f; coy[c] = 0.f; cdupc[c] = true; cdupr[c] = true;
         ld[c] = r0 < nsteps && (r0 + kChunk - oh <= kRS);
         qf[c] = make_float2(0.f, 0.f); qg[c] = qf[c]; qb[c] = qf[c]; qgate[c] = 0; qx[c] = 0; qy[c] = 0; ia_of[c] = 0; qvalid[c] = false;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { wv[c][k] = make_float2(0.f, 0.f); ws[c][k] = 0; wok[c][k] = false; }
+        for (int k = 0; k < 5; ++k) { wv[c][k] = make_float2(0.f, 0.f); wu[c][k] = 0; wvv[c][k] = 0; wok[c][k] = false; }
         if (ld[c]) {
           if (!fused) {
             const float4* src = recw + size_t(r0) * (kRows * 3);
-            va[c] = src[lane]; vb[c] = src[lane + 64]; vc[c] = src[lane + 128];
+            va[c] = src[lane]; vb4[c] = src[lane + 64]; vc[c] = src[lane + 128];
           } else {
             const int sstep = r0 + lj, ia = uLo + sstep - lr;
             ia_of[c] = ia;
@@ -1142,13 +1256,47 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
             const int idx = qy[c] * W + qx[c];
             qf[c] = flow[idx]; qgate[c] = gate[idx]; qg[c] = g0[idx]; qb[c] = blurred[idx];
           }
-          const int b = r0 / kChunk + 4;
+          // ---- the chunk's window: offset (at most one texel from the previous chunk's), new columns, new row ----
+          const int j = r0 / kChunk;
+          if (j - obase >= 64 || j < obase) refill_offsets(j);
+          int tx = __builtin_amdgcn_readlane(ocx, j - obase), ty = __builtin_amdgcn_readlane(ocy, j - obase);
+          tx = tx < pox - 1 ? pox - 1 : (tx > pox + 1 ? pox + 1 : tx);
+          ty = ty < poy - 1 ? poy - 1 : (ty > poy + 1 ? poy + 1 : ty);
+          int ou, ov; sweep_offsets(j, tx, ty, ou, ov);
+          const int need_lo = uLo + 8 * j - 15 + ou, need_front = uLo + 8 * j + 16 + ou, row0 = vb - kRad + ov;
+          int n = need_front - front; n = n < 0 ? 0 : n;   // 7 / 8 / 9 (0 for chunk 0, whose rectangle is in place)
+          if (front >= 0 && front + 8 <= LS && row0 >= 0 && row0 + kRectRows <= LB) {   // (wave-uniform) the block lies inside the image
+            const int ibase = iC + iA * front + iB * row0;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float2* q = win_addr(b, k, ws[c][k]);
-            wok[c][k] = q != nullptr;
-            if (wok[c][k]) wv[c][k] = *q;
+            for (int k = 0; k < 3; ++k) {
+              wu[c][k] = front + tdc[k]; wvv[c][k] = row0 + tdr[k];
+              wok[c][k] = tdc[k] < n;
+              if (wok[c][k]) wv[c][k] = g1[ibase + tio[k]];
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              wu[c][k] = front + tdc[k]; wvv[c][k] = row0 + tdr[k];
+              const float2* q = (tdc[k] < n) ? tex_ptr(wu[c][k], wvv[c][k]) : nullptr;
+              wok[c][k] = q != nullptr;
+              if (wok[c][k]) wv[c][k] = *q;
+            }
           }
+          cdupc[c] = ((front & (kWC - 1)) + 8 > kWC) || (front & (kWC - 1)) == 0;
+          cdupr[c] = ((row0 - ob) & (kWRing - 1)) + kRectRows > kWRing || ((row0 - ob) & (kWRing - 1)) == 0;
+          if (n > 8) {   // the ninth column (wave-uniform: the offset along the step axis grew)
+            wu[c][3] = front + 8; wvv[c][3] = row0 + lane;
+            const float2* q = lane < kRectRows ? tex_ptr(wu[c][3], wvv[c][3]) : nullptr;
+            wok[c][3] = q != nullptr;
+            if (wok[c][3]) wv[c][3] = *q;
+          }
+          if (ov != pov) {   // the row that entered the rectangle, over the columns that are already there (wave-uniform: the offset across moved)
+            wu[c][4] = need_lo + lane; wvv[c][4] = ov > pov ? row0 + kRectRows - 1 : row0;
+            const float2* q = wu[c][4] < front ? tex_ptr(wu[c][4], wvv[c][4]) : nullptr;
+            wok[c][4] = q != nullptr;
+            if (wok[c][4]) wv[c][4] = *q;
+          }
+          front = need_front > front ? need_front : front; pov = ov; pox = tx; poy = ty; cox[c] = float(tx); coy[c] = float(ty);
         }
       }
       // fused prepass, phase 2: own-flow terms E(C), E(C+dx), E(C+dy) -- the expressions of k_sweep_prep -- straight into the record
@@ -1167,37 +1315,25 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
             const float2 fv = make_float2(qvalid[c] ? f.x : 0.f, qvalid[c] ? f.y : 0.f);
             const float2 rc0 = on ? own_gradient_step(f, e0, e1, e2) : fv;
             dst[1] = make_float4(on ? e0 : kKeepEnergy, rc0.x, rc0.y, (on && ia_of[c] > 0) ? e0 : kKeepEnergy);
-            dst[2] = make_float4(float(qx[c]), float(qy[c]), 0.f, 0.f);
+            dst[2] = make_float4(float(qx[c]), float(qy[c]), on ? float(qx[c]) + cox[c] : __builtin_nanf(""), on ? float(qy[c]) + coy[c] : __builtin_nanf(""));
           }
         }
-      }
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          pv[b][k] = make_float2(0.f, 0.f); ps[b][k] = 0; pk[b][k] = false;
-          if (first) {
-            const float2* q = win_addr(b, k, ps[b][k]);
-            pk[b][k] = q != nullptr;
-            if (pk[b][k]) pv[b][k] = *q;
-          }
-        }
-      if (first) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (pk[b][k]) win_store(ps[b][k], pv[b][k]);
-        first = false;
       }
       bool progress = false;
 #pragma unroll
       for (int c = 0; c < kLoadAhead; ++c) {
         if (ld[c]) {
           float4* dst = &sm.rec[w][rh % kRS][0][0];
-          if (!fused) { dst[lane] = va[c]; dst[lane + 64] = vb[c]; dst[lane + 128] = vc[c]; }
+          if (!fused) {
+            float4 v3[3] = {va[c], vb4[c], vc[c]};
 #pragma unroll
-          for (int k = 0; k < 4; ++k) if (wok[c][k]) win_store(ws[c][k], wv[c][k]);
+            for (int k = 0; k < 3; ++k) if (isC[k]) { v3[k].z = (v3[k].x + cox[c]) + v3[k].z; v3[k].w = (v3[k].y + coy[c]) + v3[k].w; }   // (+ 0, or + NaN where the pixel is not updated)
+            dst[lane] = v3[0]; dst[lane + 64] = v3[1]; dst[lane + 128] = v3[2];
+          }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) if (wok[c][k]) win_store_block(wu[c][k], wvv[c][k], wv[c][k], cdupc[c], cdupr[c]);
+          if (__any(wok[c][3])) { if (wok[c][3]) win_store(wu[c][3], wvv[c][3], wv[c][3]); }
+          if (__any(wok[c][4])) { if (wok[c][4]) win_store(wu[c][4], wvv[c][4], wv[c][4]); }
           rh += kChunk;
           st_cnt(&sm.recHead[w], rh);
           progress = true;

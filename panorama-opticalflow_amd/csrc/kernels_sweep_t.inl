@@ -138,9 +138,6 @@ __device__ __forceinline__ bool compute_band_t(SmemTF<RG>& sm, const float2* __r
   unsigned long long tv = 0;
   int fcRec = 0, fcTail = 0, fcPub = 0, fcNext = 0;
   float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
-#ifdef PF_SWEEP_STATS
-  int statOOW = 0;
-#endif
   // the pixel's image coordinates: the position across the bands is fixed, the position along the step axis advances by one per
   // step (sweep order; mirrored for the backward sweep); exact small integers in fp32
   const float acrossPos = forward ? float(ib) : float((transposed ? W : H) - 1 - ib);
@@ -243,9 +240,6 @@ __device__ __forceinline__ bool compute_band_t(SmemTF<RG>& sm, const float2* __r
       const float eCL = transposed ? eC : eCa;
       const bool okL = transposed ? hasCross : hasAlong, okT = transposed ? hasAlong : hasCross;
       int emin; float vmax;
-#ifdef PF_SWEEP_STATS
-      const float2 statP1 = role ? across : prev;
-#endif
       float2 fin = t_step<true, TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, rEps, posv, ra, eC, C, eCL, okL, okT, prev, across, role, emin, vmax);
       // next step's inputs (LDS), behind the second gather round
       float4 na, nb; int hN = 0; unsigned long long tvN = tv;
@@ -265,10 +259,6 @@ __device__ __forceinline__ bool compute_band_t(SmemTF<RG>& sm, const float2* __r
         // an operand left the range where the fast forms are exact: the whole wave redoes the step with IEEE sqrt and division
         fin = t_step<false, TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, rEps, posv, ra, eC, C, eCL, okL, okT, prev, across, role, emin, vmax);
       }
-#ifdef PF_SWEEP_STATS
-      // round 1's candidate, and the result as a stand-in for round 2's (the winner, one gradient step away)
-      if (__any(!(__builtin_fmaxf(fabsf(statP1.x), fabsf(statP1.y)) <= float(kRad - 1)) || !(__builtin_fmaxf(fabsf(fin.x), fabsf(fin.y)) <= float(kRad - 1)))) ++statOOW;
-#endif
       fin.x = gated ? fin.x : C.x; fin.y = gated ? fin.y : C.y;   // a pixel that is not updated keeps its flow (PixFlow.hpp:317); slots without a pixel carry C = 0
       if (TOP != 0) {
         waitTop = __any(s + 1 + kBias >= hN);
@@ -283,7 +273,7 @@ __device__ __forceinline__ bool compute_band_t(SmemTF<RG>& sm, const float2* __r
     }
   }
 #ifdef PF_SWEEP_STATS
-  if (lane == 0) { atomicAdd(&g_sweep_stats[2], (unsigned long long)nsteps); atomicAdd(&g_sweep_stats[3], (unsigned long long)statOOW); }
+  if (lane == 0) atomicAdd(&g_sweep_stats[2], (unsigned long long)nsteps);   // ([3] is counted where it happens: d_error_fast)
 #endif
   return !dead;
 }
