@@ -67,9 +67,8 @@ typedef struct pf_config {
                                reference's own order without speculation (two gather rounds per step), bands of 32 rows -- less than half the VALU
                                instructions per pixel, what a batch that oversubscribes the chip wants.  -1 (default) = throughput form for the launches of a
                                batch that oversubscribe the chip (sweep_wide_threshold), latency form otherwise.  Same bits in every form.
-                               (1 = the latency step with two compute waves per SIMD, 3 = the throughput form with loader-staged records, 4 = the
-                               throughput form with the prepass FUSED into its loader waves (no k_sweep_prep launch, no record stream through HBM):
-                               measured and rejected, lab build only -- libpanoflow.so answers PF_ERR_ARG.) */
+                               (1 = the latency step with two compute waves per SIMD: measured and rejected, lab build only -- libpanoflow.so answers
+                               PF_ERR_ARG.  The throughput form's loader-staged and fused-prepass record paths of rounds 4 / 5 are gone: profiles/.) */
   int sweep_wide_threshold; /* sweep_wide = -1: a launch takes the throughput form when (sweeps running at the same time: pairs of the batch x 2
                                directions x lanes) x (its latency-form workgroups) exceeds this (512: two rounds of the chip) */
   int sweep_throughput_transposed; /* sweep_wide = -1: sweeps whose bands step along y (windows taller than wide, e.g. 2000x4000 strips) may take the

@@ -47,6 +47,8 @@ constexpr int kChunk = 8;    // steps streamed per helper iteration and wave
 constexpr int kRad = 8;      // LDS window of the gathered plane: +-kRad texels around the band
 constexpr int kWC = 64;      // window ring along the step axis (columns)
 constexpr int kWRing = 32;   // FOLLOW: window ring across the band (rows)
+constexpr int kRadT = 6;     // throughput form: its window reaches +-kRadT texels around pixel + offset (the test admits kRadT - 1): with the window following
+                             // the flow a narrower one serves, and its skewed ring then has room for the loader to run three chunks ahead
 // Two workgroup shapes of the SAME step (compute_band is one function; every test holds both to the same bits):
 //  * SwLatency -- ONE pair: 4 compute waves (one per SIMD: alone on its SIMD a wave is offered an issue slot every ~5.5 cycles,
 //    and the step's dependency chain cannot use a second wave) + 4 loaders + publisher + poller + drainer = 704 threads, 113 KB of
@@ -221,10 +223,15 @@ __device__ __forceinline__ float dpp_shl0(float src) {
 // (the rounded blurred flow of the chunk, kept with the record): resident are the texels of [pc - 8, pc + 8] in both axes, so the test is on
 // the sample position against pc -- a flow of any size whose sample falls within 7 of the centre is served from LDS.  A pixel that is not updated carries pc = NaN: its (discarded) evaluations never
 // send the wave through the HBM path -- they read a valid LDS slot with whatever it holds ("not > 7" is true for a NaN distance).
-template <bool TR, bool FWD, int kWA, int WCP = kWCp, bool SKEW = false, bool FOLLOW = false>
+// FOLLOW = 2 (throughput form): the same torus in skewed coordinates -- ring row = the texel's row mod kWA (52; `ob` = a multiple of 52 chosen by
+// the loader per chunk so that the chunk's rows fall in [ob, ob + 104): one conditional subtraction), ring column = (u + v) & 63; pc = the
+// chunk's OFFSET (wave-uniform, image axes) and the test is on the flow relative to it, |fd - pc| <= kRadT - 1 = 5 (the window holds [centre - 6,
+// centre + 6], so a difference that rounds onto +-5 is covered; centres are kept inside the image by the loader); `live` = the pixel is
+// updated -- one that is not never sends the wave to HBM.
+template <bool TR, bool FWD, int kWA, int WCP = kWCp, bool SKEW = false, int FOLLOW = 0>
 __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __attribute__((address_space(3))) const float2* win, int ob, int W, int H, float wm2, float hm2,
                                               float fW, float rW, f2p pos, float i0x, float i0y, float bx, float by, f2p fd,
-                                              int& emin, float& vmax, f2p pc = f2p{0.f, 0.f}) {
+                                              int& emin, float& vmax, f2p pc = f2p{0.f, 0.f}, bool live = true) {
   // ---- A ----  (pos = the pixel's (x, y), fd = the candidate flow: packed fp32 wherever both components take the same operation)
   const float fdx = fd.x, fdy = fd.y;
   const f2p match = pos + fd;
@@ -236,7 +243,10 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   // pixel, and int(c), int(c)+1 then lie within [f-7, f+8].  Tested on the flow itself (known at the start of the step),
   // not on the clamped position: one max + one compare, off the address chain.  (NaN flows compare false -> HBM path.)
   bool inwin;
-  if (FOLLOW) {
+  if (FOLLOW == 2) {
+    const f2p dm = fd - pc;
+    inwin = !(__builtin_fmaxf(fabsf(dm.x), fabsf(dm.y)) > float(kRadT - 1)) || !live;
+  } else if (FOLLOW == 1) {
     // The loader keeps every window centre INSIDE the image (it clamps the chunk's offset), so the test may be made on the sample position
     // before the clamp to the image -- off the address chain, beside it: a sample within 7 of a centre in [0, W - 1] that the clamp moves
     // to 0 or W - 2 is still within 7 of it.  The subtraction is exact to well under a texel, and the window holds one texel more than the test
@@ -251,7 +261,10 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   const int cxl = FWD ? x0 : W - 2 - x0, cyl = FWD ? y0 : H - 2 - y0;
   const int ulo = TR ? cyl : cxl, vlo = TR ? cxl : cyl;
   // out-of-window lanes are clamped to a valid window row (they read garbage that the HBM path below overwrites)
-  const int alo = FOLLOW ? ((vlo - ob) & (kWRing - 1)) : min(max(vlo - ob, 0), kWA - 2);   // FOLLOW: ring row of the absolute texel row (always a valid slot)
+  int alo;   // ring / window row of texel row vlo (always a valid slot)
+  if (FOLLOW == 2) { const unsigned a = unsigned(vlo - ob); alo = int(min(min(a, a - unsigned(kWA)), unsigned(kWA))); }   // a in [0, 2 * 52) -> a mod 52; anything else (a lane outside the window): row 52
+  else if (FOLLOW == 1) alo = (vlo - ob) & (kWRing - 1);
+  else alo = min(max(vlo - ob, 0), kWA - 2);
   auto q = [&](int dr, int dc) { return (FWD ? dr : 1 - dr) * (WCP + (SKEW ? 1 : 0)) + (FWD ? dc : 1 - dc); };   // texel (v0 + sg*dr, u0 + sg*dc), relative to the corner
   const int o00 = q(0, 0);                            // texel (x0, y0)
   const int o10 = TR ? q(1, 0) : q(0, 1);             // texel (x0+1, y0)
@@ -263,7 +276,7 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   typedef __attribute__((address_space(3))) const f2v lds_f2;
   // explicit LDS address space: ds_read2_b64, never a flat access.  The corner's byte address as (ring column << 3) + window, then
   // + row * stride in one 24-bit multiply-add: five instructions from (x0, y0) to the address.
-  unsigned ringCol = unsigned((SKEW ? ulo + alo : ulo) & (kWC - 1));
+  unsigned ringCol = unsigned((SKEW ? ulo + (FOLLOW == 2 ? vlo : alo) : ulo) & (kWC - 1));
   asm("" : "+v"(ringCol));   // (x & 63) << 3 + base as v_and + v_lshl_add, not the canonical v_lshl + v_and + v_add
   const unsigned cornerCol = (ringCol << 3) + (unsigned)(size_t)win;
   unsigned cornerAddr;   // = alo * row stride + cornerCol; written out because the compiler turns it into v_mul_u32_u24 + v_add3_u32 (one more)
@@ -271,20 +284,6 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   lds_f2* win3 = (lds_f2*)(size_t)cornerAddr;
   const f2v w00 = win3[o00], w10 = win3[o10], w01 = win3[o01], w11 = win3[o11];
   float2 t00 = make_float2(w00.x, w00.y), t10 = make_float2(w10.x, w10.y), t01 = make_float2(w01.x, w01.y), t11 = make_float2(w11.x, w11.y);
-  // wave-uniform test first: the common "every lane inside the window" case costs a compare + one scalar branch, not an exec-mask
-  // save / restore around an empty block (two instructions of ~150 per step; a step is issue-bound, profiles/r03_sweep_step_isa.txt)
-  if (__builtin_expect(__any(!inwin), 0)) {
-#ifdef PF_SWEEP_STATS
-    if ((threadIdx.x & 63) == 0) atomicAdd(&g_sweep_stats[SKEW ? 3 : 1], 1ull);   // gather rounds of a wave that left the LDS window
-#endif
-    if (!inwin) {
-      const float2* p = g1 + (y0 * W + x0);
-      t00 = p[0]; t10 = p[1]; t01 = p[W]; t11 = p[W + 1];
-    }
-    // (throughput form: its compute wave has record loads in flight; the wait for these four must sit INSIDE this cold branch, or the
-    // in-order memory counter would make every step wait for the newest record request)
-    if (SKEW) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): a real instruction, so that the compiler's counter tracking knows nothing is pending at the join
-  }
   __builtin_amdgcn_sched_barrier(0);
   // ---- B ----
   const float xR = __builtin_amdgcn_fractf(cx), yR = __builtin_amdgcn_fractf(cy);   // cx, cy >= 0: exactly cx - float(int(cx))
@@ -299,6 +298,22 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   const float rv = reg.x, rh = reg.y;
   emin = min(min(__builtin_amdgcn_frexp_expf(s2), __builtin_amdgcn_frexp_expf(av)), __builtin_amdgcn_frexp_expf(ah));   // 0 for a zero operand
   vmax = __builtin_fmaxf(__builtin_fmaxf(s2, av), ah);
+  // The window test is taken HERE, behind phase B, not right behind the texel reads (round 5): the wave cannot issue past the branch before
+  // the test's result is there, and with the flow-following window the test hangs on one more (packed) subtraction -- behind B its latency is
+  // covered.  Wave-uniform test first: the common "every lane inside the window" case costs a compare + one scalar branch, not an exec-mask
+  // save / restore around an empty block (two instructions of ~150 per step; a step is issue-bound, profiles/r03_sweep_step_isa.txt)
+  if (__builtin_expect(__any(!inwin), 0)) {
+#ifdef PF_SWEEP_STATS
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_sweep_stats[SKEW ? 3 : 1], 1ull);   // gather rounds of a wave that left the LDS window
+#endif
+    if (!inwin) {
+      const float2* p = g1 + (y0 * W + x0);
+      t00 = p[0]; t10 = p[1]; t01 = p[W]; t11 = p[W + 1];
+    }
+    // (throughput form: its compute wave has record loads in flight; the wait for these four must sit INSIDE this cold branch, or the
+    // in-order memory counter would make every step wait for the newest record request)
+    if (SKEW) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): a real instruction, so that the compiler's counter tracking knows nothing is pending at the join
+  }
   __builtin_amdgcn_sched_barrier(0);
   // ---- C ----
   float i1x, i1y;
@@ -648,7 +663,7 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
       const float2 cand = cnd;
       int emin; float vmax;
       const f2p fdv = f2p{cand.x, cand.y} + f2p{addx, addy};
-      float e = d_error_fast<TR, FWD, kWA, kWCp, false, G::kFollow>(g1, win, ob, W, H, wm2, hm2, fW, rW, posv, ra.x, ra.y, ra.z, ra.w, fdv, emin, vmax, f2p{rp.x, rp.y});
+      float e = d_error_fast<TR, FWD, kWA, kWCp, false, G::kFollow ? 1 : 0>(g1, win, ob, W, H, wm2, hm2, fW, rW, posv, ra.x, ra.y, ra.z, ra.w, fdv, emin, vmax, f2p{rp.x, rp.y});
       { // Only what the step uses is loaded: a loaded register nothing reads is handed out again by the register allocator at once,
         // and the hardware must then wait for the load in flight before the new value may be written (s_waitcnt right behind the
         // loads, ~50 cycles per step).  Transposed sweeps do not use Ea, the fourth float of the second quad.
@@ -1230,7 +1245,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
       first = false;
       float4 va[kLoadAhead], vb4[kLoadAhead], vc[kLoadAhead];
       bool ld[kLoadAhead];
-      float cox[kLoadAhead], coy[kLoadAhead]; bool cdupc[kLoadAhead], cdupr[kLoadAhead];
+      float cox[kLoadAhead], coy[kLoadAhead]; bool cdupc[kLoadAhead], cdupr[kLoadAhead], cwhole[kLoadAhead];
       // window work of a chunk: the block of new columns (3 texels per lane), a ninth column (lanes 0-23), one new row (one texel per lane)
       float2 wv[kLoadAhead][5]; int wu[kLoadAhead][5], wvv[kLoadAhead][5]; bool wok[kLoadAhead][5];
       // fused prepass, phase 1: the inputs of up to kLoadAhead chunks are requested together (one round trip)
@@ -1238,7 +1253,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
 #pragma unroll
       for (int c = 0; c < kLoadAhead; ++c) {
         const int r0 = rh + c * kChunk;
-        va[c] = z4; vb4[c] = z4; vc[c] = z4; cox[c] = 0.f; coy[c] = 0.f; cdupc[c] = true; cdupr[c] = true;
+        va[c] = z4; vb4[c] = z4; vc[c] = z4; cox[c] = 0.f; coy[c] = 0.f; cdupc[c] = true; cdupr[c] = true; cwhole[c] = false;
         ld[c] = r0 < nsteps && (r0 + kChunk - oh <= kRS);
         qf[c] = make_float2(0.f, 0.f); qg[c] = qf[c]; qb[c] = qf[c]; qgate[c] = 0; qx[c] = 0; qy[c] = 0; ia_of[c] = 0; qvalid[c] = false;
 #pragma unroll
@@ -1265,7 +1280,13 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
           int ou, ov; sweep_offsets(j, tx, ty, ou, ov);
           const int need_lo = uLo + 8 * j - 15 + ou, need_front = uLo + 8 * j + 16 + ou, row0 = vb - kRad + ov;
           int n = need_front - front; n = n < 0 ? 0 : n;   // 7 / 8 / 9 (0 for chunk 0, whose rectangle is in place)
-          if (front >= 0 && front + 8 <= LS && row0 >= 0 && row0 + kRectRows <= LB) {   // (wave-uniform) the block lies inside the image
+          const bool inside = front >= 0 && front + 8 <= LS && row0 >= 0 && row0 + kRectRows <= LB;   // (wave-uniform) the block lies inside the image
+          cwhole[c] = inside && n == 8;
+          if (cwhole[c]) {   // the usual block -- eight new columns, inside the image: unconditional loads and stores (no exec-mask work per texel)
+            const int ibase = iC + iA * front + iB * row0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { wu[c][k] = front + tdc[k]; wvv[c][k] = row0 + tdr[k]; wok[c][k] = true; wv[c][k] = g1[ibase + tio[k]]; }
+          } else if (inside) {
             const int ibase = iC + iA * front + iB * row0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -1331,7 +1352,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
             dst[lane] = v3[0]; dst[lane + 64] = v3[1]; dst[lane + 128] = v3[2];
           }
 #pragma unroll
-          for (int k = 0; k < 3; ++k) if (wok[c][k]) win_store_block(wu[c][k], wvv[c][k], wv[c][k], cdupc[c], cdupr[c]);
+          for (int k = 0; k < 3; ++k) if (cwhole[c] || wok[c][k]) win_store_block(wu[c][k], wvv[c][k], wv[c][k], cdupc[c], cdupr[c]);
           if (__any(wok[c][3])) { if (wok[c][3]) win_store(wu[c][3], wvv[c][3], wv[c][3]); }
           if (__any(wok[c][4])) { if (wok[c][4]) win_store(wu[c][4], wvv[c][4], wv[c][4]); }
           rh += kChunk;
@@ -1606,17 +1627,9 @@ bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
     const SweepWindow win = make_sweep_window(a.W, a.H, a.forward, a.ax0, a.ay0, a.ax1, a.ay1, kRows, SwLatency::kWaves, kChunk);
     wide = (!win.empty && long(win.nwg) * a.concurrent_sweeps > long(a.wide_threshold_wgs) && !a.sparse && (!win.tr || a.wide_tr)) ? 2 : 0;
   }
-  if (wide == 2 && !a.sparse) return launch_sweep_t<true>(st, a, rec);
+  if (wide == 2 && !a.sparse) return launch_sweep_t(st, a, rec);
 #ifdef PF_EXPERIMENTS
-  // measured-and-rejected forms, lab build only (profiles/r04_wide_sweep.txt, r04_throughput_form.txt): the latency step with two compute
-  // waves per SIMD, and the throughput form with loader-staged records (three bands per workgroup)
-  if (wide == 3 && !a.sparse) return launch_sweep_t<false>(st, a, rec);
-  // 4 = the throughput form with the FUSED prepass (round 5, profiles/r05_fused_prepass.txt): three bands per workgroup, the loader waves
-  // compute the records (no k_sweep_prep launch, no record stream through HBM); bands along y keep the record-stream form
-  if (wide == 4 && !a.sparse) {
-    const SweepWindow wt = make_sweep_window(a.W, a.H, a.forward, a.ax0, a.ay0, a.ax1, a.ay1, tRows, TGeom<false>::kWaves, kChunk);
-    return wt.tr ? launch_sweep_t<true>(st, a, rec) : launch_sweep_t<false, true>(st, a, rec);
-  }
+  // measured-and-rejected form, lab build only (profiles/r04_wide_sweep.txt): the latency step with two compute waves per SIMD
   if (wide == 1) return launch_sweep2_form<SwWide>(st, a, rec);
 #endif
   return launch_sweep2_form<SwLatency>(st, a, rec);

@@ -22,38 +22,41 @@
 // ring slot = (u + window row) & 63, because the 32 pixels of a step lie on an anti-diagonal 32 columns wide -- in (u + row) they all sit
 // within 31 slots of each other (d_error_fast<.., SKEW>).  Dense sweeps only (no variant that skips ungated anti-diagonals); sparse
 // and small launches keep the latency form.
+// Round 5: ONE record path (the prepass kernel's record stream fetched by LDS-DMA; the loader-staged ring and the fused prepass of rounds 4 / 5
+// were measured, rejected and removed: profiles/r04_throughput_form.txt, r05_fused_prepass.txt), and the gather window FOLLOWS THE FLOW like
+// the latency form's (kernels_sweep2.hip, loader of k_sweep2): a torus in (skew slot D = u + v, row v), centred per chunk on the pixels +
+// the rounded blurred flow of the chunk's centre pixel.
 namespace {
 constexpr int tRows = 32;                       // rows per compute wave
-// Two ways the records reach a compute wave (template parameter RG of everything below):
-//   RG = false: through an LDS ring filled by the band's loader wave, like the latency form -- 46 KB of LDS per band: THREE bands per workgroup;
-//   RG = true : the compute wave requests its own records six steps ahead with LDS-DMA (global_load_lds_dwordx4: one instruction copies a
-//               step's 32 records = 1 KB straight into an 8-step LDS ring, no registers, no loader; its completion is counted by hand with
-//               s_waitcnt vmcnt -- the compiler does not track it, and with a register destination its conservative vmcnt(0) at every
-//               loop / branch join drained the queue twice per chunk: measured, 0.54 instead of 0.47 us per step) -- 38 KB per band:
-//               FOUR bands (128 rows) per workgroup, one compute wave on every SIMD, and a batch's level-0 launches (8 pairs x 2 directions x
-//               16 workgroups = 256) fit the chip in ONE round instead of 1.3.
-template <bool RG> struct TGeom { static constexpr int kWaves = RG ? 4 : 3; static constexpr int kThreads = 64 * (2 * kWaves + 3); };
-constexpr int tPre = 6;                         // RG: steps a record is requested ahead of its use
-constexpr int tRSG = 8;                         // RG: record ring (steps): tPre in flight + the one being read + one being overwritten
-constexpr int tRS = 16;                         // record ring (steps)
+// The records reach a compute wave by LDS-DMA: it requests its own records six steps ahead (global_load_lds_dwordx4: one instruction copies a
+// step's 32 records = 1 KB straight into an 8-step LDS ring, no registers, no loader; its completion is counted by hand with s_waitcnt vmcnt --
+// the compiler does not track it, and with a register destination its conservative vmcnt(0) at every loop / branch join drained the queue
+// twice per chunk: measured, 0.54 instead of 0.47 us per step) -- ~40 KB per band: FOUR bands (128 rows) per workgroup, one compute wave on
+// every SIMD, and a batch's level-0 launches (8 pairs x 2 directions x 16 workgroups = 256) fit the chip in ONE round.
+constexpr int tWaves = 4;
+constexpr int tThreads = 64 * (2 * tWaves + 3);
+constexpr int tPre = 6;                         // steps a record is requested ahead of its use
+constexpr int tRSG = 8;                         // record ring (steps): tPre in flight + the one being read + one being overwritten
 constexpr int tOS = 16;                         // result ring (steps)
-constexpr int tWA = tRows + 2 * kRad + 1;       // window rows (49)
+constexpr int tRect = tRows + 2 * kRadT;        // rows of a chunk's window rectangle: the band's 32 rows -+ 6 (44)
+constexpr int tRV = 48;                         // ring rows of the torus window: the rectangle + the rows it may have moved by while a chunk is in use (3) + 1
 constexpr int kWCPT = kWC + 2;                  // window row stride: ring columns 0 and 1 again behind column 63 (the skewed footprint reaches slot + 2)
+constexpr int tAhead = 3;                       // chunks the window loader may run ahead of its band (see the loader)
 
-template <bool RG>
 struct SmemTF {
-  static constexpr int tWaves = TGeom<RG>::kWaves;
-  float4 rec[tWaves][RG ? tRSG : tRS][tRows][2];   // the 32-byte records (I0x, I0y, blurred.x, blurred.y | E(C), C.x, C.y, Ea)
+  float4 rec[tWaves][tRSG][tRows][2];   // the 32-byte records (I0x, I0y, blurred.x, blurred.y | E(C), C.x, C.y, Ea)
   float2 out[tWaves][tOS][tRows];
-  float2 win[tWaves][tWA][kWCPT];
+  float2 win[tWaves][tRV + 1][kWCPT];   // texel (u, v) at row v mod tRV (row 0 again behind row tRV - 1), column (u + v) & 63
+  float4 woff[tWaves][4];               // per chunk (ring of 4): the window's offset (ox, oy) in image axes and the ring-row base of its rows (an int)
   unsigned long long bnd[kBS];
-  int recHead[tWaves], outHead[tWaves], outTail[tWaves];   // recHead: steps whose records (RG: whose window batches) are in LDS
+  int recHead[tWaves], outHead[tWaves], outTail[tWaves];   // recHead: steps whose window is in LDS
   int pubTail, bndHead, abort, wg;
   long long deadline;
 };
 // the LDS-DMA destination travels in M0, whose LDS-address field is 16 bits wide: the record rings must lie in the first 64 KB of the
 // workgroup's LDS (they are the struct's first member: 32 KB)
-static_assert(offsetof(SmemTF<true>, rec) == 0 && sizeof(SmemTF<true>::rec) <= 65536, "LDS-DMA rings must sit below 64 KB");
+static_assert(offsetof(SmemTF, rec) == 0 && sizeof(SmemTF::rec) <= 65536, "LDS-DMA rings must sit below 64 KB");
+static_assert(sizeof(SmemTF) <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
 
 // V_PERMLANE32_SWAP: lanes 32-63 of `a` trade places with lanes 0-31 of `b`.  With a == b == v: lo = role a's v in every lane, hi = role b's.
 __device__ __forceinline__ void swap_roles(float v, float& lo, float& hi) {
@@ -62,12 +65,13 @@ __device__ __forceinline__ void swap_roles(float v, float& lo, float& hi) {
 }
 
 // One step for one wave.  FAST: the exact cheap forms + range guard (emin / vmax out); !FAST: the IEEE sequence (cold redo path).
+// (ob = ring-row base of the chunk's window rows, wof = the window's offset in image axes, live = the pixel is updated: d_error_fast<FOLLOW = 2>)
 template <bool FAST, bool TR, bool FWD>
 __device__ __forceinline__ float2 t_step(const float2* __restrict__ g1, __attribute__((address_space(3))) const float2* win, int ob, int W, int H, float wm2, float hm2,
                                          float fW, float rW, float rEps, f2p posv, float4 ra, float eC, float2 C, float eCL, bool okL, bool okT, float2 along,
-                                         float2 across, int role, int& emin, float& vmax) {
+                                         float2 across, int role, int& emin, float& vmax, f2p wof, bool live) {
   auto energy = [&](float2 f, int& em, float& vm) -> float {
-    if (FAST) return d_error_fast<TR, FWD, tWA, kWCPT, true>(g1, win, ob, W, H, wm2, hm2, fW, rW, posv, ra.x, ra.y, ra.z, ra.w, f2p{f.x, f.y}, em, vm);
+    if (FAST) return d_error_fast<TR, FWD, tRV, kWCPT, true, 2>(g1, win, ob, W, H, wm2, hm2, fW, rW, posv, ra.x, ra.y, ra.z, ra.w, f2p{f.x, f.y}, em, vm, wof, live);
     em = 0; vm = 0.f;
     return d_error2(g1, W, wm2, hm2, fW, int(posv.x), int(posv.y), ra.x, ra.y, ra.z, ra.w, f.x, f.y);
   };
@@ -109,10 +113,11 @@ __device__ __forceinline__ float2 t_step(const float2* __restrict__ g1, __attrib
 }
 
 // One compute wave of the throughput form: a band of 32 rows.  TOP as in compute_band.
-template <bool RG, int TOP, bool TR, bool FWD>
-__device__ __forceinline__ bool compute_band_t(SmemTF<RG>& sm, const float2* __restrict__ g1, const float4* __restrict__ recg, int W, int H, int nsteps, int w, int band,
+template <int TOP, bool TR, bool FWD>
+__device__ __forceinline__ bool compute_band_t(SmemTF& sm, const float2* __restrict__ g1, const float4* __restrict__ recg, int W, int H, int nsteps, int w, int band,
                                                int nact, bool publishes, float rW, float rEps, int uLo, int LSv) {
-  constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0, tWaves = TGeom<RG>::kWaves;
+  constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0;
+  constexpr bool RG = true;
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, role = lane >> 5;
   const int ib = band * tRows + r;
@@ -121,8 +126,9 @@ __device__ __forceinline__ bool compute_band_t(SmemTF<RG>& sm, const float2* __r
   typedef __attribute__((address_space(3))) const float2 lds_cf2;
   lds_cf2* win = (lds_cf2*)&sm.win[w][0][0];
   asm volatile("" : "+s"(win));
-  int ob = band * tRows - kRad;
-  asm volatile("" : "+s"(ob));
+  int ob = 0;                       // ring-row base of the current chunk's window rows (from the loader, per chunk)
+  f2p wof = f2p{0.f, 0.f};          // the current chunk's window offset (image axes)
+  float4 woNext = make_float4(0.f, 0.f, 0.f, 0.f);
   const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W), fLast = float(LS - 1);
   const bool lastPub = publishes && (w == tWaves - 1);
   const bool hasNext = (w + 1 < nact);
@@ -176,10 +182,12 @@ __device__ __forceinline__ bool compute_band_t(SmemTF<RG>& sm, const float2* __r
         if (hasNext) fcNext = ld_cnt(&sm.outHead[w + 1]);
         if (spin_expired(spins, sm) || (((spins & 255) == 0) && ld_cnt(&sm.abort))) return false;
       }
-      if (!RG && __builtin_expect(spins != 0 || s0 == 0, 0)) {   // (re)load this chunk's first record: read ahead it was only good if already there
-        const float4* rp0 = &sm.rec[w][s0 % tRS][r][0];
-        ra = rp0[0]; rb = rp0[1];
-        asm volatile("" : "+v"(ra.x), "+v"(ra.y), "+v"(ra.z), "+v"(ra.w), "+v"(rb.x), "+v"(rb.y), "+v"(rb.z), "+v"(rb.w));
+      {   // the chunk's window: offset and ring-row base, published by the loader before the chunk's recHead (wave-uniform: scalar registers);
+          // read ahead in the middle of the previous chunk, good if the chunk was already published then (no waiting just now)
+        float4 wo = woNext;
+        if (__builtin_expect(spins != 0 || s0 == 0, 0)) wo = sm.woff[w][(s0 / kChunk) & 3];
+        wof = f2p{__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wo.x))), __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wo.y)))};
+        ob = __builtin_amdgcn_readfirstlane(__float_as_int(wo.z));
       }
     }
     // counters for the NEXT chunk's check: read in the middle of this chunk (a 16-step ring cannot satisfy a check that is a whole chunk old)
@@ -188,8 +196,8 @@ __device__ __forceinline__ bool compute_band_t(SmemTF<RG>& sm, const float2* __r
     typedef __attribute__((address_space(3))) const f4v lds_f4;
     typedef __attribute__((address_space(3))) f2w lds_wf2;
     typedef __attribute__((address_space(3))) const unsigned long long lds_u64;
-    lds_f4* recChunk = (lds_f4*)&sm.rec[w][RG ? 0 : s0 % tRS][r][0];                    // RG: the ring IS one chunk long
-    lds_f4* recNext = (lds_f4*)&sm.rec[w][RG ? 0 : (s0 + kChunk) % tRS][r][0];
+    lds_f4* recChunk = (lds_f4*)&sm.rec[w][0][r][0];                    // the ring IS one chunk long
+    lds_f4* recNext = recChunk;
     lds_wf2* outChunk = (lds_wf2*)&sm.out[w][s0 % tOS][r];   // (role a stores)
     lds_u64* topChunk = (lds_u64*)((TOP == 1) ? top_slot(s0 + 1) : &sm.bnd[s0 & (kBS - 1)] + 1);
     lds_u64* topNext = (lds_u64*)top_slot(s0 + kChunk);
@@ -201,6 +209,7 @@ __device__ __forceinline__ bool compute_band_t(SmemTF<RG>& sm, const float2* __r
       if (RG) dma_step(s + tPre);   // into the slot of step s - 2 (the stream is padded past its end)
       if (j == 5) {
         fcRec = ld_cnt(&sm.recHead[w]); fcTail = ld_cnt(&sm.outTail[w]);
+        woNext = sm.woff[w][((s0 / kChunk) + 1) & 3];   // (after the counter: published before it)
         if (lastPub) fcPub = ld_cnt(&sm.pubTail);
         if (hasNext) fcNext = ld_cnt(&sm.outHead[w + 1]);
       }
@@ -240,7 +249,7 @@ __device__ __forceinline__ bool compute_band_t(SmemTF<RG>& sm, const float2* __r
       const float eCL = transposed ? eC : eCa;
       const bool okL = transposed ? hasCross : hasAlong, okT = transposed ? hasAlong : hasCross;
       int emin; float vmax;
-      float2 fin = t_step<true, TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, rEps, posv, ra, eC, C, eCL, okL, okT, prev, across, role, emin, vmax);
+      float2 fin = t_step<true, TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, rEps, posv, ra, eC, C, eCL, okL, okT, prev, across, role, emin, vmax, wof, gated);
       // next step's inputs (LDS), behind the second gather round
       float4 na, nb; int hN = 0; unsigned long long tvN = tv;
       {
@@ -257,7 +266,7 @@ __device__ __forceinline__ bool compute_band_t(SmemTF<RG>& sm, const float2* __r
       asm volatile("" : "+v"(fin.x), "+v"(fin.y));
       if (__builtin_expect(__any((emin < -94 || !(vmax <= 0x1p100f)) && gated), 0)) {
         // an operand left the range where the fast forms are exact: the whole wave redoes the step with IEEE sqrt and division
-        fin = t_step<false, TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, rEps, posv, ra, eC, C, eCL, okL, okT, prev, across, role, emin, vmax);
+        fin = t_step<false, TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, rEps, posv, ra, eC, C, eCL, okL, okT, prev, across, role, emin, vmax, wof, gated);
       }
       fin.x = gated ? fin.x : C.x; fin.y = gated ? fin.y : C.y;   // a pixel that is not updated keeps its flow (PixFlow.hpp:317); slots without a pixel carry C = 0
       if (TOP != 0) {
@@ -279,36 +288,18 @@ __device__ __forceinline__ bool compute_band_t(SmemTF<RG>& sm, const float2* __r
 }
 }  // namespace
 
-// FU (with !RG): FUSED PREPASS -- the band's loader wave computes the 32-byte records itself (the expressions of k_sweep_prep<32, false>:
-// d_make_record_at) while it runs ahead of the wavefront and writes them straight into the LDS ring: no prepass launch, and the record
-// stream's round trip through HBM (32 B written + 32 B read back per level-pixel and sweep) is gone.  A pixel's own flow C is read before
-// its step is computed and overwritten (by the drainer) only afterwards, so reading it from the plane being updated is safe.
-// Wave roles.  Waves of a workgroup land on SIMD (wave % 4).  Record-stream forms: waves [0, n) compute, [n, 2n) load, then publisher, poller,
-// drainer.  FUSED form (n = 3, 12 waves): its loaders carry a third of a band's instructions (one energy per pixel), and a loader that shares
-// a SIMD with a compute wave slows that band -- and, bands being chained, the sweep -- by what it issues (first measurement: 0.71 instead of
-// 0.46 us per step).  So the three compute waves get SIMDs 0-2, ALL three loaders SIMD 3 (waves 3, 7, 11), the light helpers waves 4-6;
-// waves 8-10 exit at once.
-template <bool RG, bool FU> struct TRoles {
-  static constexpr int n = TGeom<RG>::kWaves;
-  static constexpr int kThreads = FU ? 64 * 12 : TGeom<RG>::kThreads;
-  __device__ static int loader_of(int wave) { return FU ? ((wave & 3) == 3 ? (wave >> 2) : -1) : ((wave >= n && wave < 2 * n) ? wave - n : -1); }
-  __device__ static bool publisher(int wave) { return wave == (FU ? 4 : 2 * n); }
-  __device__ static bool poller(int wave) { return wave == (FU ? 5 : 2 * n + 1); }
-  __device__ static bool drainer(int wave) { return wave == (FU ? 6 : 2 * n + 2); }
-};
-template <bool RG, bool FU, bool TR, bool FWD>
-__global__ __launch_bounds__((TRoles<RG, FU>::kThreads)) void k_sweep_t(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
+// Waves: [0, 4) compute (one per SIMD), [4, 8) the bands' window loaders, then publisher, poller, drainer.
+template <bool TR, bool FWD>
+__global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
                                                       unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H, int nstepsPad, int nbands,
                                                       float rW, float rEps, int uLo, int LSv, int bandLo, long long budgetTicks, size_t bstride,
-                                                      const float2* __restrict__ g0, const float2* __restrict__ blurred, const uint8_t* __restrict__ gate) {
-  static_assert(!FU || !RG, "the fused prepass fills the loader-staged record ring");
+                                                      const float2* __restrict__ blurred) {
   {
     const size_t bo = size_t(blockIdx.z) * bstride;
-    PF_BOFF(rec, bo); PF_BOFF(g1, bo); PF_BOFF(flow, bo); PF_BOFF(boundary, bo); PF_BOFF(ctrl, bo);
-    if (FU) { PF_BOFF(g0, bo); PF_BOFF(blurred, bo); PF_BOFF(gate, bo); }
+    PF_BOFF(rec, bo); PF_BOFF(g1, bo); PF_BOFF(flow, bo); PF_BOFF(boundary, bo); PF_BOFF(ctrl, bo); PF_BOFF(blurred, bo);
   }
-  constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0, tWaves = TGeom<RG>::kWaves;
-  __shared__ SmemTF<RG> sm;
+  constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0;
+  __shared__ SmemTF sm;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -336,184 +327,189 @@ __global__ __launch_bounds__((TRoles<RG, FU>::kThreads)) void k_sweep_t(const fl
     const int band = bandLo + band0 + wave;
     bool ok;
     const float4* recg = rec + size_t(band0 + wave) * nstepsPad * (tRows * 2);
-    if (top == 1) ok = compute_band_t<RG, 1, TR, FWD>(sm, g1, recg, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
-    else if (top == 2) ok = compute_band_t<RG, 2, TR, FWD>(sm, g1, recg, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
-    else ok = compute_band_t<RG, 0, TR, FWD>(sm, g1, recg, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
+    if (top == 1) ok = compute_band_t<1, TR, FWD>(sm, g1, recg, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
+    else if (top == 2) ok = compute_band_t<2, TR, FWD>(sm, g1, recg, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
+    else ok = compute_band_t<0, TR, FWD>(sm, g1, recg, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
     if (!ok) give_up();
     return;
   }
   __builtin_amdgcn_s_setprio(1);
-  using Roles = TRoles<RG, FU>;
-  if (Roles::loader_of(wave) >= 0) {
-    // ======================= loader of band w: records + skewed gather window HBM -> LDS =======================
-    // Window batch b = the ring slots d in [8b - 8, 8b) (d = u - uLo + window row), 8 x 49 texels: row a holds u = uLo + d - a.  A band working
-    // on chunk j reads d in [8j - 6, 8j + 31] = batches j .. j+4: batch j+4 is loaded with chunk j (batches 0..3 in the first round) and
-    // overwrites batch j-4, which the band left when it finished chunk j-4 (the 16-step record ring asks for more: chunk j-2).
-    const int w = Roles::loader_of(wave);
+  if (wave < 2 * tWaves) {
+    // ======================= window loader of band w: gather window HBM -> LDS =======================
+    // The window FOLLOWS THE FLOW (round 5; the latency form's loader in kernels_sweep2.hip has the full story).  Here in SKEWED coordinates:
+    // a pixel of chunk j (steps s = 8j .. 8j + 7; row r sits at sweep column uLo + s - r, row vb + r) needs, with the chunk's offset (ou, ov) in
+    // sweep order, the texels (u', v') with |u' - u - ou| <= 6, |v' - v - ov| <= 6 -- in D = u' + v' that is [DB + 8j - 12, DB + 8j + 20),
+    // DB = uLo + vb + ou + ov, for ALL 32 rows at once, rows [vb + ov - 6, vb + ov + 38).  The LDS window is a torus: row v' mod 48 (ring row 0
+    // again behind row 47), column D & 63 (columns 0 and 1 again behind 63).  Per chunk the loader brings the 6 .. 10 new D-slots of the 44 rows
+    // (8 + the change of ou + ov; an offset moves by at most one texel per chunk and axis) and, when ov moved, the one new row over the D-slots
+    // already present.  It runs at most tAhead = 3 chunks ahead of its band: the D-slots in use then span <= 32 + 24 + 6 of the ring's 64 (what
+    // a new slot overwrites, D - 64, has left every active chunk's range), the rows <= 44 + 3 of 48.  Window centres are kept inside the
+    // image (the test is made on the flow relative to the offset, before the sample's clamp to the image: d_error_fast<FOLLOW = 2>).
+    const int w = wave - tWaves;
     if (w >= nact) return;
-    constexpr int kKT = (8 * tWA + 63) / 64;   // window texels per lane and batch (7)
-    int ta[kKT], td[kKT]; bool tvalid[kKT];
-#pragma unroll
-    for (int k = 0; k < kKT; ++k) {
-      // which texel of a batch (8 ring slots d x 49 window rows a) this lane fetches: runs of 8 texels that are CONTIGUOUS in memory.
-      // Bands along x: a window row is an image row, a run = 8 consecutive d of one row a.  Transposed (bands along y): the window row
-      // index a is the image x, so a run = one image row u = d - a with 8 consecutive a -- the batch is a diagonal band of 56 such rows
-      // (dealt out by row a there, every texel would come from a cache line of its own).
-      const int t = lane + 64 * k;
-      if (TR) { const int ui = t >> 3, j = t & 7; ta[k] = tWA - 1 - ui + j; td[k] = j; tvalid[k] = ta[k] >= 0 && ta[k] < tWA; }
-      else { ta[k] = t >> 3; td[k] = t & 7; tvalid[k] = t < 8 * tWA; }
-    }
     float2* winw = &sm.win[w][0][0];
-    const int v0 = (bandLo + band0 + w) * tRows - kRad;
-    auto win_addr = [&](int b, int k, int& slot) -> const float2* {
-      const int d = 8 * b - 8 + td[k];                     // relative skewed index
-      const int u = uLo + d - ta[k], v = v0 + ta[k];       // absolute sweep-order texel
-      if (!tvalid[k] || u < 0 || u >= LS || v < 0 || v >= LB) { slot = 0; return nullptr; }
-      slot = ta[k] * kWCPT + ((u + ta[k]) & (kWC - 1));
+    const int vb = (bandLo + band0 + w) * tRows;
+    auto ring_row = [&](int v) { int a = v % tRV; return a < 0 ? a + tRV : a; };
+    auto win_store = [&](int D, int v, float2 val) {
+      const int rr = ring_row(v), cc = D & (kWC - 1);
+      float2* q = winw + rr * kWCPT + cc;
+      q[0] = val;
+      if (cc < 2) q[kWC] = val;
+      if (rr == 0) { q[tRV * kWCPT] = val; if (cc < 2) q[tRV * kWCPT + kWC] = val; }
+    };
+    // the same for a block: its rows' ring rows are one wave-uniform base + the texel's row (one conditional subtraction, no division), and
+    // its duplicates sit behind wave-uniform guards (dupc: the block's D-slots contain ring column 0 or 1; dupr: its rows contain ring row 0)
+    auto win_store_block = [&](int D, int r0m, int dr, float2 val, bool dupc, bool dupr) {
+      int rr = r0m + dr; rr = rr >= tRV ? rr - tRV : rr;
+      const int cc = D & (kWC - 1);
+      float2* q = winw + rr * kWCPT + cc;
+      q[0] = val;
+      if (dupc) { if (cc < 2) q[kWC] = val; }
+      if (dupr) { if (rr == 0) { q[tRV * kWCPT] = val; if (cc < 2) q[tRV * kWCPT + kWC] = val; } }
+    };
+    auto tex_ptr = [&](int D, int v) -> const float2* {   // texel (u = D - v, v) in sweep order; nullptr outside the image (never sampled)
+      const int u = D - v;
+      if (u < 0 || u >= LS || v < 0 || v >= LB) return nullptr;
       const int cxc = TR ? v : u, cyc = TR ? u : v;
       const int x = FWD ? cxc : W - 1 - cxc, y = FWD ? cyc : H - 1 - cyc;
       return g1 + (y * W + x);
     };
-    auto win_store = [&](int slot, float2 v) {   // ring columns 0 and 1 also go behind column 63
-      winw[slot] = v;
-      if (slot % kWCPT < 2) winw[slot + kWC] = v;
-    };
-    const float4* recw = rec + size_t(band0 + w) * nstepsPad * (tRows * 2);
-    constexpr int kQ = 8 * tRows * 2 / 64;   // a chunk's records: 512 float4, 8 per lane, the ring's layout is the stream's
-    // ---- fused prepass (FU): this lane computes the records of row fr, steps rh + fj0 .. + 3 of every chunk = four CONSECUTIVE pixels of one
-    // image row when the bands step along x (32-byte runs of every input plane).  Their inputs are requested one round ahead.
-    const int fr = lane >> 1, fj0 = (lane & 1) * 4;
-    struct FusedIn { float2 f, g, bl; int gate; } fin_[4];   // (what was loaded; the geometry is recomputed where it is used: registers are what this wave is short of)
-    const int fib = (bandLo + band0 + w) * tRows + fr;
-    const float fwm2 = float(W) - 2.0f, fhm2 = float(H) - 2.0f, ffW = float(W);
-    typedef __attribute__((address_space(3))) const float2 lds_cf2;
-    lds_cf2* lwin = (lds_cf2*)&sm.win[w][0][0];
-    const int lob = v0;
-    auto fused_geom = [&](int r0, int i, int& x, int& y, int& ia) -> bool {
-      const int sstep = r0 + fj0 + i;
-      ia = uLo + sstep - fr;
-      const bool valid = sstep - fr >= 0 && ia < uLo + LSv && ia < LS && fib < LB;
-      const int cxs = TR ? fib : ia, cys = TR ? ia : fib;   // position in sweep order
-      x = valid ? (FWD ? cxs : W - 1 - cxs) : 0; y = valid ? (FWD ? cys : H - 1 - cys) : 0;
-      return valid;
-    };
-    auto fetch_inputs = [&](int r0) {
+    // image index of texel (D, v) = iC + iA * (D - v) + iB * v: one wave-uniform base + a per-lane constant for a block inside the image
+    const int iA = TR ? (FWD ? W : -W) : (FWD ? 1 : -1), iB = TR ? (FWD ? 1 : -1) : (FWD ? W : -W), iC = FWD ? 0 : W * H - 1;
+    // a block = 8 D-slots x 44 rows = 352 texels: texel t = lane + 64 k (k < 6; k = 5: lanes 0-31 only), D-slot = t & 7 fastest (a wave's loads run
+    // along image rows when the bands step along x).  A chunk whose offset did not move needs exactly one block (the usual case): loads and
+    // stores are then UNCONDITIONAL (no exec-mask work per texel: this wave shares its SIMD's vector pipe with the band's compute wave); a chunk
+    // that needs 6, 7, 9 or 10 D-slots takes the predicated form / one more (narrow) block.
+    constexpr int kBlkD = 8, kKT = (kBlkD * tRect + 63) / 64;   // 6
+    static_assert(kBlkD * tRect == 64 * (kKT - 1) + 32, "the last texel slot belongs to lanes 0-31");
+    int tdD[kKT], tdr[kKT], tio[kKT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int x, y, ia;
-        fused_geom(r0, i, x, y, ia);
-        const int idx = y * W + x;
-        fin_[i].f = flow[idx]; fin_[i].gate = gate[idx]; fin_[i].g = g0[idx]; fin_[i].bl = blurred[idx];
-      }
+    for (int k = 0; k < kKT; ++k) {
+      const int t = lane + 64 * k;
+      tdD[k] = t & (kBlkD - 1); tdr[k] = t >> 3;   // (k = 5, lanes 32-63: row >= 44, no texel)
+      tio[k] = iA * (tdD[k] - tdr[k]) + iB * tdr[k];
+    }
+    const bool lastHalf = lane < 32;
+    // rounded blurred flow at the centre pixel of chunk (obase + lane): one gather serves 64 chunks; integers (scalar-unit work below)
+    int ocx = 0, ocy = 0; int obase = -(1 << 20);
+    auto refill_offsets = [&](int jb) {
+      obase = jb;
+      int ia = uLo + 8 * (jb + lane) + 3 - tRows / 2;
+      ia = ia < uLo ? uLo : ia; ia = ia > uLo + LSv - 1 ? uLo + LSv - 1 : ia; ia = ia > LS - 1 ? LS - 1 : ia; ia = ia < 0 ? 0 : ia;
+      int ibc = vb + tRows / 2; ibc = ibc > LB - 1 ? LB - 1 : ibc;
+      const int cxc = TR ? ibc : ia, cyc = TR ? ia : ibc;
+      const int x = FWD ? cxc : W - 1 - cxc, y = FWD ? cyc : H - 1 - cyc;
+      const float2 bl = blurred[y * W + x];
+      const float rx = __builtin_rintf(bl.x), ry = __builtin_rintf(bl.y);
+      ocx = (fabsf(rx) < 1.0e6f) ? int(rx) : 0;
+      ocy = (fabsf(ry) < 1.0e6f) ? int(ry) : 0;
     };
-    if (FU) fetch_inputs(0);
+    // image-axis offset -> sweep order, cut back so that every window centre of chunk j lies inside the image (pixels of the chunk: columns
+    // [uLo + 8j - 31, uLo + 8j + 7] clipped to the image, rows [vb, vb + 31]), and back
+    auto sweep_offsets = [&](int j, int& ox, int& oy, int& ou, int& ov) {
+      ou = TR ? (FWD ? oy : -oy) : (FWD ? ox : -ox);
+      ov = TR ? (FWD ? ox : -ox) : (FWD ? oy : -oy);
+      int plo = uLo + 8 * j - (tRows - 1), phi = uLo + 8 * j + (kChunk - 1);
+      plo = plo < 0 ? 0 : (plo > LS - 1 ? LS - 1 : plo); phi = phi < 0 ? 0 : (phi > LS - 1 ? LS - 1 : phi);
+      const int vhi = vb + tRows - 1 > LB - 1 ? LB - 1 : vb + tRows - 1;
+      ou = ou < -plo ? -plo : ou; ou = ou > LS - 1 - phi ? LS - 1 - phi : ou;
+      ov = ov < -vb ? -vb : ov; ov = ov > LB - 1 - vhi ? LB - 1 - vhi : ov;
+      const int sx = TR ? ov : ou, sy = TR ? ou : ov;
+      ox = FWD ? sx : -sx; oy = FWD ? sy : -sy;
+    };
+    auto publish_offsets = [&](int j, int ox, int oy, int row0) {   // (lane 0) what the band reads at the start of chunk j
+      const int k = row0 >= 0 ? row0 / tRV : -((-row0 + tRV - 1) / tRV);   // floor: the rows [row0, row0 + 44] then lie in [k * 48, k * 48 + 96)
+      if (lane == 0) sm.woff[w][j & 3] = make_float4(float(ox), float(oy), __int_as_float(k * tRV), 0.f);
+    };
+    // one block of D-slots [D0, D0 + n) x rows [row0, row0 + 48): loads into registers (issue), then stores
+    float2 bv[kKT]; bool bok[kKT];
+    auto block_load = [&](int D0, int n, int row0) {
+      const bool inside = row0 >= 0 && row0 + tRect <= LB && D0 - (row0 + tRect - 1) >= 0 && D0 + kBlkD - 1 - row0 < LS;   // (wave-uniform)
+      const int ibase = iC + iA * D0 + (iB - iA) * row0;
+      if (inside && n == kBlkD) {   // the usual block: whole, inside the image
+#pragma unroll
+        for (int k = 0; k < kKT - 1; ++k) { bok[k] = true; bv[k] = g1[ibase + tio[k]]; }
+        bok[kKT - 1] = lastHalf; bv[kKT - 1] = make_float2(0.f, 0.f);
+        if (lastHalf) bv[kKT - 1] = g1[ibase + tio[kKT - 1]];
+        return true;
+      }
+#pragma unroll
+      for (int k = 0; k < kKT; ++k) {
+        bv[k] = make_float2(0.f, 0.f);
+        bok[k] = tdD[k] < n && tdr[k] < tRect;
+        if (inside) { if (bok[k]) bv[k] = g1[ibase + tio[k]]; }
+        else { const float2* q = bok[k] ? tex_ptr(D0 + tdD[k], row0 + tdr[k]) : nullptr; bok[k] = q != nullptr; if (bok[k]) bv[k] = *q; }
+      }
+      return false;
+    };
+    auto block_store = [&](int D0, int row0, bool whole) {
+      const int r0m = ring_row(row0), c0 = D0 & (kWC - 1);   // (wave-uniform)
+      const bool dupc = c0 + kBlkD > kWC || c0 < 2, dupr = r0m == 0 || r0m + tRect > tRV;
+      if (whole) {
+#pragma unroll
+        for (int k = 0; k < kKT - 1; ++k) win_store_block(D0 + tdD[k], r0m, tdr[k], bv[k], dupc, dupr);
+        if (lastHalf) win_store_block(D0 + tdD[kKT - 1], r0m, tdr[kKT - 1], bv[kKT - 1], dupc, dupr);
+        return;
+      }
+#pragma unroll
+      for (int k = 0; k < kKT; ++k) if (bok[k]) win_store_block(D0 + tdD[k], r0m, tdr[k], bv[k], dupc, dupr);
+    };
     int rh = 0, idle = 0;
+    // ---- chunk 0's whole rectangle (32 D-slots x 44 rows: four blocks, one after the other, once per band) ----
+    int pox, poy, frontD, pov;
+    {
+      refill_offsets(0);
+      pox = __builtin_amdgcn_readfirstlane(ocx); poy = __builtin_amdgcn_readfirstlane(ocy);
+      int ou, ov; sweep_offsets(0, pox, poy, ou, ov);
+      const int DB = uLo + vb + ou + ov, row0 = vb - kRadT + ov;
+#pragma unroll 1
+      for (int b = 0; b < 4; ++b) { const bool whole = block_load(DB - 2 * kRadT + 8 * b, 8, row0); block_store(DB - 2 * kRadT + 8 * b, row0, whole); }
+      frontD = DB + 8 + 2 * kRadT; pov = ov;
+    }
     bool first = true;
     for (;;) {
       const int oh = first ? 0 : ld_cnt(&sm.outHead[w]);
-      // LDS records: room in the 16-step ring.  RG: the window batch loaded with chunk rh / 8 overwrites the one the band left with chunk rh / 8 - 4
-      const bool ld = rh < nsteps && (rh + kChunk - oh <= (RG ? 32 : tRS));
-#if PF_LOADER_IDLE
-      if (!first && !ld) {   // ring full (the usual state): a short idle iteration instead of a pass through the predicated-off body (see the latency form)
-        __builtin_amdgcn_s_sleep(PF_LOADER_IDLE);
+      const bool ld = rh < nsteps && (rh + kChunk - oh <= kChunk * (tAhead + 1));
+      if (!ld) {   // ring full (the usual state): a short idle iteration
+        __builtin_amdgcn_s_sleep(PF_LOADER_IDLE ? PF_LOADER_IDLE : 4);
         if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { give_up(); break; }
         continue;
       }
-#endif
-      float4 q[kQ];
-      float2 wv[kKT]; int ws[kKT]; bool wok[kKT];
-#pragma unroll
-      for (int k = 0; k < kKT; ++k) { wv[k] = make_float2(0.f, 0.f); ws[k] = 0; wok[k] = false; }
-      if (ld) {
-        if (!RG && !FU) {
-          const float4* src = recw + size_t(rh) * (tRows * 2);
-#pragma unroll
-          for (int k = 0; k < kQ; ++k) q[k] = src[lane + 64 * k];
-        }
-        // FU: one batch further ahead -- this round's records are computed from batches <= rh / 8 + 4, which earlier rounds have stored,
-        // while this round's window loads are still in flight (the loader-staged ring keeps the loader at most two chunks ahead of the
-        // band, so batch j + 5 only overwrites batch j - 3, which chunk j - 3 -- finished -- was the last to read)
-        const int b = rh / kChunk + (FU ? 5 : 4);
-#pragma unroll
-        for (int k = 0; k < kKT; ++k) {
-          const float2* p = win_addr(b, k, ws[k]);
-          wok[k] = p != nullptr;
-          if (wok[k]) wv[k] = *p;
-        }
+      first = false;
+      const int j = rh / kChunk;
+      if (j - obase >= 64 || j < obase) refill_offsets(j);
+      int tx = __builtin_amdgcn_readlane(ocx, j - obase), ty = __builtin_amdgcn_readlane(ocy, j - obase);
+      tx = tx < pox - 1 ? pox - 1 : (tx > pox + 1 ? pox + 1 : tx);
+      ty = ty < poy - 1 ? poy - 1 : (ty > poy + 1 ? poy + 1 : ty);
+      int ou, ov; sweep_offsets(j, tx, ty, ou, ov);
+      const int DB = uLo + vb + ou + ov, row0 = vb - kRadT + ov;
+      const int need_lo = DB + 8 * j - 2 * kRadT, need_front = DB + 8 * j + 8 + 2 * kRadT;
+      int n = need_front - frontD; n = n < 0 ? 0 : (n > 2 * kBlkD ? 2 * kBlkD : n);   // 6 .. 10 (0 for chunk 0, whose rectangle is in place)
+      const int n1 = n > kBlkD ? kBlkD : n;
+      const bool whole = block_load(frontD, n1, row0);
+      // the row that entered the rectangle, over the D-slots that are already there (wave-uniform: the offset across moved)
+      float2 sv = make_float2(0.f, 0.f); bool sok = false; int sD = 0, sV = 0;
+      if (ov != pov) {
+        sD = need_lo + lane; sV = ov > pov ? row0 + tRect - 1 : row0;
+        const float2* q = sD < frontD ? tex_ptr(sD, sV) : nullptr;
+        sok = q != nullptr;
+        if (sok) sv = *q;
       }
-      if (first) {
-        constexpr int kFirst = FU ? 5 : 4;
-        if (FU) {
-          // one batch at a time (five round trips, once per band, all loaders at the same time): five batches in flight would cost the fused
-          // loader 140 registers it does not have (three waves per SIMD: 168) and put spills into its steady-state loop
-#pragma unroll 1
-          for (int b = 0; b < kFirst; ++b) {
-            float2 pv1[kKT]; int ps1[kKT]; bool pk1[kKT];
-#pragma unroll
-            for (int k = 0; k < kKT; ++k) { pv1[k] = make_float2(0.f, 0.f); const float2* p = win_addr(b, k, ps1[k]); pk1[k] = p != nullptr; if (pk1[k]) pv1[k] = *p; }
-#pragma unroll
-            for (int k = 0; k < kKT; ++k) if (pk1[k]) win_store(ps1[k], pv1[k]);
-          }
-        } else {
-        float2 pv[kFirst][kKT]; int ps[kFirst][kKT]; bool pk[kFirst][kKT];
-#pragma unroll
-        for (int b = 0; b < kFirst; ++b)
-#pragma unroll
-          for (int k = 0; k < kKT; ++k) {
-            pv[b][k] = make_float2(0.f, 0.f);
-            const float2* p = win_addr(b, k, ps[b][k]);
-            pk[b][k] = p != nullptr;
-            if (pk[b][k]) pv[b][k] = *p;
-          }
-#pragma unroll
-        for (int b = 0; b < kFirst; ++b)
-#pragma unroll
-          for (int k = 0; k < kKT; ++k) if (pk[b][k]) win_store(ps[b][k], pv[b][k]);
-        }
-        first = false;
+      block_store(frontD, row0, whole);
+      if (__any(sok)) { if (sok) win_store(sD, sV, sv); }
+      if (n > kBlkD) {   // the ninth / tenth D-slot (wave-uniform, rare: the offsets' sum grew): one more, narrow block
+        block_load(frontD + kBlkD, n - kBlkD, row0); block_store(frontD + kBlkD, row0, false);
       }
-      if (ld) {
-        if (!RG && !FU) {
-          float4* d4 = &sm.rec[RG ? 0 : w][RG ? 0 : rh % tRS][0][0];
-#pragma unroll
-          for (int k = 0; k < kQ; ++k) d4[lane + 64 * k] = q[k];
-        }
-        if (FU) {
-          // this lane's four records of the chunk from the inputs requested a round ago.  E(C) with the sweep's own d_error_fast: its
-          // texels come from the band's LDS window (batches <= rh / 8 + 4 are in place), its range guard is checked per record and the
-          // IEEE form (d_error2g: the prepass kernel's) takes over outside it -- the same bits either way (exact_forms.hpp)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            int px, py, pia;
-            const bool valid = fused_geom(rh, i, px, py, pia);
-            const bool on = valid && fin_[i].gate != 0;
-            const float2 f = fin_[i].f, g = fin_[i].g, bl = fin_[i].bl;
-            int em; float vm;
-            float e0 = d_error_fast<TR, FWD, tWA, kWCPT, true>(g1, lwin, lob, W, H, fwm2, fhm2, ffW, rW, f2p{float(px), float(py)}, g.x, g.y, bl.x, bl.y,
-                                                                f2p{on ? f.x : 0.f, on ? f.y : 0.f}, em, vm);
-            if (__builtin_expect(__any(on && (em < -94 || !(vm <= 0x1p100f))), 0))
-              e0 = d_error2g(g1, W, fwm2, fhm2, ffW, rW, px, py, g.x, g.y, bl.x, bl.y, on ? f.x : 0.f, on ? f.y : 0.f);
-            float4* d4 = &sm.rec[RG ? 0 : w][RG ? 0 : (rh + fj0 + i) % tRS][fr][0];
-            d4[0] = on ? make_float4(g.x, g.y, bl.x, bl.y) : make_float4(0.f, 0.f, 0.f, 0.f);
-            d4[1] = make_float4(on ? e0 : kKeepEnergy, valid ? f.x : 0.f, valid ? f.y : 0.f, (on && pia > 0) ? e0 : kKeepEnergy);
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < kKT; ++k) if (wok[k]) win_store(ws[k], wv[k]);
-        rh += kChunk;
-        st_cnt(&sm.recHead[w], rh);
-        idle = 0;
-        if (FU && rh < nsteps) fetch_inputs(rh);
-      }
+      publish_offsets(j, tx, ty, row0);
+      frontD = frontD + n; pov = ov; pox = tx; poy = ty;
+      rh += kChunk;
+      st_cnt(&sm.recHead[w], rh);
+      idle = 0;
       if (rh >= nsteps) break;
-      if (!ld) {
-        __builtin_amdgcn_s_sleep(4);
-        if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { give_up(); break; }
-      }
     }
     return;
   }
-  if (Roles::drainer(wave)) {
+  if (wave == 2 * tWaves + 2) {
     // ======================= drainer: results LDS ring -> flow plane =======================
     int idle = 0;
     for (;;) {
@@ -559,7 +555,7 @@ __global__ __launch_bounds__((TRoles<RG, FU>::kThreads)) void k_sweep_t(const fl
     }
     return;
   }
-  if (Roles::publisher(wave)) {
+  if (wave == 2 * tWaves) {
     // ======================= publisher: last row of the workgroup -> granules in HBM =======================
     if (!publishes) return;
     unsigned long long* bnd_out = boundary + size_t(wg + 1) * LSv;
@@ -588,7 +584,7 @@ __global__ __launch_bounds__((TRoles<RG, FU>::kThreads)) void k_sweep_t(const fl
   }
   // ======================= poller: previous workgroup's granules HBM -> LDS ring =======================
   {
-    if ((wg == 0 && !staticTop) || !Roles::poller(wave)) return;
+    if ((wg == 0 && !staticTop) || wave != 2 * tWaves + 1) return;
     const unsigned long long* bnd_in = boundary + size_t(wg) * LSv;
     int bh = 0, idle = 0;
     while (bh < LSv) {
@@ -596,15 +592,7 @@ __global__ __launch_bounds__((TRoles<RG, FU>::kThreads)) void k_sweep_t(const fl
       if (bh + 64 - oh0 <= kBS) {
         unsigned long long g = kNotReady;
         if (bh + lane < LSv) {
-          if (FU && wg == 0) {
-            // (wg == 0 only gets here with a static top row) the row above the window never changes during this sweep: read from the plane itself
-            const int ia = uLo + bh + lane, ibt = bandLo * tRows - 1;
-            const int cxs = TR ? ibt : ia, cys = TR ? ia : ibt;
-            const int x = FWD ? cxs : W - 1 - cxs, y = FWD ? cys : H - 1 - cys;
-            g = pack2(flow[size_t(y) * W + x]);
-          } else {
-            g = __hip_atomic_load(bnd_in + bh + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
+          g = __hip_atomic_load(bnd_in + bh + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const bool ready = (g != kNotReady) || (bh + lane >= LSv);
         const unsigned long long m = __ballot(ready);
@@ -626,23 +614,19 @@ __global__ __launch_bounds__((TRoles<RG, FU>::kThreads)) void k_sweep_t(const fl
 }
 
 // host side of the throughput form
-template <bool RG, bool FU = false>
 static bool launch_sweep_t(hipStream_t st, const SweepArgs& a, float* rec) {
-  constexpr int tWaves = TGeom<RG>::kWaves;
   const SweepWindow win = make_sweep_window(a.W, a.H, a.forward, a.ax0, a.ay0, a.ax1, a.ay1, tRows, tWaves, kChunk);
   if (win.empty) return false;
   const int tr = win.tr, uLo = win.uLo, uHi = win.uHi, LSv = win.LSv, bandLo = win.bandLo, nbands = win.nbands;
   const int nwg = win.nwg, nbandsPad = nwg * tWaves, nstepsPad = win.nstepsPad;
   const float rW = (float)(1.0 / (double)(float)a.W), rEps = (float)(1.0 / (double)kGradEpsilon);
-  if (!FU)
-    hipExtLaunchKernelGGL((k_sweep_prep<tRows, false>), dim3((unsigned)((nstepsPad + 256 / tRows - 1) / (256 / tRows)), (unsigned)nbandsPad, a.bt.n), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate,
-                          a.flow, a.W, a.H, a.forward, tr, nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo,
-                          bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride);
-  hipEvent_t evs = FU ? a.ev_start : nullptr;   // without a prepass kernel the sweep launch carries both events
+  hipExtLaunchKernelGGL((k_sweep_prep<tRows, false>), dim3((unsigned)((nstepsPad + 256 / tRows - 1) / (256 / tRows)), (unsigned)nbandsPad, a.bt.n), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate,
+                        a.flow, a.W, a.H, a.forward, tr, nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo,
+                        bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride);
   const long long budget = 200000000ll + 1000ll * 50ll * (long long)(nstepsPad + 40 * nbands);
-  const dim3 grid(nwg, 1, a.bt.n), block(TRoles<RG, FU>::kThreads);
-  const float4* r4 = FU ? nullptr : reinterpret_cast<const float4*>(rec);
-#define PF_LAUNCH_SWEEP_T(TRV, FWV) hipExtLaunchKernelGGL((k_sweep_t<RG, FU, TRV, FWV>), grid, block, 0, st, evs, a.ev_stop, 0, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.bt.stride, a.g0, a.blurred, a.gate)
+  const dim3 grid(nwg, 1, a.bt.n), block(tThreads);
+  const float4* r4 = reinterpret_cast<const float4*>(rec);
+#define PF_LAUNCH_SWEEP_T(TRV, FWV) hipExtLaunchKernelGGL((k_sweep_t<TRV, FWV>), grid, block, 0, st, nullptr, a.ev_stop, 0, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.bt.stride, a.blurred)
   if (tr) { if (a.forward) PF_LAUNCH_SWEEP_T(true, true); else PF_LAUNCH_SWEEP_T(true, false); }
   else { if (a.forward) PF_LAUNCH_SWEEP_T(false, true); else PF_LAUNCH_SWEEP_T(false, false); }
 #undef PF_LAUNCH_SWEEP_T

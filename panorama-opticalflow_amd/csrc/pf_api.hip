@@ -816,14 +816,14 @@ pf_ctx* pf_create_cfg(const pf_config* user) {
   if (cfg.sweep_impl != 1 && cfg.sweep_impl != 3) cfg.sweep_impl = 2;
   if (cfg.record_path < 0 || cfg.record_path > 2) cfg.record_path = 0;
 #else
-  if (cfg.sweep_impl != 2 || cfg.record_path != 0 || cfg.sweep_wide == 1 || cfg.sweep_wide >= 3) {
-    fail(nullptr, PF_ERR_ARG, "sweep_impl / record_path / sweep_wide 1, 3 and 4 select cross-check implementations that only the -DPF_EXPERIMENTS build (libpanoflow_exp.so) contains");
+  if (cfg.sweep_impl != 2 || cfg.record_path != 0 || cfg.sweep_wide == 1) {
+    fail(nullptr, PF_ERR_ARG, "sweep_impl / record_path / sweep_wide 1 select cross-check implementations that only the -DPF_EXPERIMENTS build (libpanoflow_exp.so) contains");
     return nullptr;
   }
 #endif
   if (cfg.batch_pairs == 0 || cfg.batch_pairs < -1 || cfg.batch_pairs > kMaxBatch) { fail(nullptr, PF_ERR_ARG, "pf_create_cfg: batch_pairs must be -1 or 1..%d", kMaxBatch); return nullptr; }
   if (cfg.fine_gradient_blocks < 1 || cfg.stagger_levels < -1 || cfg.fuse_small_level_px < -1 || cfg.sparse_sweep < -1 || cfg.sparse_sweep > 1 ||
-      cfg.sweep_wide < -1 || cfg.sweep_wide > 4 || cfg.sweep_wide_threshold < 0) {
+      cfg.sweep_wide < -1 || cfg.sweep_wide > 2 || cfg.sweep_wide_threshold < 0) {
     fail(nullptr, PF_ERR_ARG, "pf_create_cfg: knob out of range");
     return nullptr;
   }
@@ -1450,7 +1450,7 @@ int pf_stage_sweep(pf_ctx* c, const float* g0, const float* g1, const float* blu
   SweepArgs sa; sa.prepcnt = pcnt; sa.g0 = (const float2*)dg0; sa.g1 = (const float2*)dg1; sa.blurred = (const float2*)dbl; sa.gate = gate; sa.flow = (float2*)df;
   sa.boundary = bnd; sa.ctrl = ctrl; sa.W = w; sa.H = h; sa.forward = forward; sa.sparse = (w * h) % 2;   // stage test: exercise both variants
   sa.wide = c->cfg.sweep_wide > 0 ? c->cfg.sweep_wide : 0;   // the sweep form the context was created for (auto = latency form: one pair)
-  if (sa.wide == 2 || sa.wide == 4) sa.sparse = 0;   // (the throughput form has no sparse variant)
+  if (sa.wide == 2) sa.sparse = 0;            // (the throughput form has no sparse variant)
   {
     std::vector<int> box; LevelTable t; t.n = 1; t.w[0] = w; t.h[0] = h; t.off[0] = 0;
     if (int e = gate_boxes_to_host(c, sm, gate, t, n, box)) return e;

@@ -143,8 +143,7 @@ struct SweepArgs {
   int ax0 = 0, ay0 = 0, ax1 = 1 << 30, ay1 = 1 << 30;   // bounding box [ax0,ax1) x [ay0,ay1) of the gated pixels (default: everything); v2 sweep only
   int wide = 0;           // v2 sweep form: 0 = latency form (8 lanes per pixel, 4 bands of 8 rows per workgroup, one compute wave per SIMD), 1 = the same step
                           // with 8 bands per workgroup (two compute waves per SIMD), 2 = throughput form (2 lanes per pixel, bands of 32 rows,
-                          // kernels_sweep_t.inl), -1 = throughput form when the launch oversubscribes the chip (dense, bands along x), else latency;
-                          // lab build only: 3 = throughput form with loader-staged records, 4 = with the prepass fused into the loader waves
+                          // kernels_sweep_t.inl), -1 = throughput form when the launch oversubscribes the chip (dense, bands along x), else latency
   int wide_threshold_wgs = 512;   // wide = -1: "oversubscribed" means more latency-form workgroups x concurrent_sweeps than this
   int wide_tr = 0;                // wide = -1: transposed sweeps (bands along y) may take the throughput form too (its window loads do not coalesce there)
   int concurrent_sweeps = 2;      // sweeps that run on the chip at the same time as this launch's (this launch's pairs x 2 directions x lanes)

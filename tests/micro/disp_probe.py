@@ -27,8 +27,17 @@ for sc in scales:
         l.pf_debug_sweep_stats(z, 1)
         call()
         l.pf_debug_sweep_stats(z, 1)
-        print("disp_scale %g: latency-form wave-steps %d, with a lane outside the LDS window %d (%.2f %%); throughput form %d / %d" %
-              (sc, z[0], z[1], 100.0 * z[1] / max(1, z[0]), z[2], z[3]), flush=True)
+        print("disp_scale %g lone pair: latency-form wave-steps %d, gather rounds that left the LDS window %d (%.2f %%)" % (sc, z[0], z[1], 100.0 * z[1] / max(1, z[0])), flush=True)
+        nb = 8
+        pairs = [synth.make_pair(cols, rows, 6000 + i, dev, disp_scale=sc)[:3] for i in range(nb)]
+        outs = [torch.empty((rows, cols, 4), dtype=torch.uint8, device=dev) for _ in range(nb)]
+        cb = pf.Context(0)
+        callb = lambda: cb.novel_view_batch_dev([p[0].data_ptr() for p in pairs], [p[1].data_ptr() for p in pairs], cols, rows, 0,
+                                                [p[2].data_ptr() for p in pairs], [o.data_ptr() for o in outs], None, None, in_flight=nb)
+        callb(); l.pf_debug_sweep_stats(z, 1); callb(); l.pf_debug_sweep_stats(z, 1)
+        print("disp_scale %g batch of %d: latency form %d wave-steps / %d rounds outside (%.2f %%); throughput form %d wave-steps (two gather rounds each) / %d rounds outside (%.2f %% of the rounds)" %
+              (sc, nb, z[0], z[1], 100.0 * z[1] / max(1, z[0]), z[2], z[3], 50.0 * z[3] / max(1, z[2])), flush=True)
+        cb.close(); del pairs, outs
         continue
     ts = []
     for _ in range(5):

@@ -8,14 +8,13 @@ pytestmark = pytest.mark.gpu
 rng = np.random.default_rng(11)
 
 
-@pytest.fixture(scope="module", params=["latency", "wide", "throughput", "throughput_lds", "throughput_fused"])
+@pytest.fixture(scope="module", params=["latency", "wide", "throughput"])
 def ctx(pf, request):
     """Every stage test runs with every form of the sweep (pf_config::sweep_wide): the latency form a lone pair uses (8 lanes per pixel),
     the same step with two compute waves per SIMD ("wide"), and the throughput form of the batch mode (2 lanes per pixel, bands of 32
-    rows, non-speculative two-round step, skewed gather window) with its three record paths (record stream + LDS-DMA; loader-staged;
-    FUSED prepass: the loader waves compute the records, no k_sweep_prep launch)."""
-    form = {"latency": 0, "wide": 1, "throughput": 2, "throughput_lds": 3, "throughput_fused": 4}[request.param]
-    c = pf.Context(0, exp=form in (1, 3, 4), sweep_wide=form)   # forms 1, 3 and 4 (measured and rejected) only exist in the lab build
+    rows, non-speculative two-round step, skewed gather window)."""
+    form = {"latency": 0, "wide": 1, "throughput": 2}[request.param]
+    c = pf.Context(0, exp=form == 1, sweep_wide=form)   # form 1 (measured and rejected) only exists in the lab build
     yield c
     c.close()
 
@@ -325,9 +324,11 @@ def test_product_library_ships_one_sweep(pf):
         pf.Context(0, sweep_impl=1)
     with pytest.raises(pf.PanoflowError, match="PF_EXPERIMENTS"):
         pf.Context(0, record_path=2)
-    for form in (1, 3, 4):   # the rejected sweep forms of rounds 4 and 5
-        with pytest.raises(pf.PanoflowError, match="PF_EXPERIMENTS"):
-            pf.Context(0, sweep_wide=form)
+    with pytest.raises(pf.PanoflowError, match="PF_EXPERIMENTS"):
+        pf.Context(0, sweep_wide=1)   # the rejected wide shape of round 4
+    for form in (3, 4):   # the throughput form's rejected record paths of rounds 4 / 5 no longer exist in any build
+        with pytest.raises(pf.PanoflowError):
+            pf.Context(0, exp=True, sweep_wide=form)
     blob = open(pf.SO_PATH, "rb").read()
     assert b"PANOFLOW_" not in blob and b"k_sweep_relax" not in blob
     assert b"k_sweep_relax" in open(pf.SO_PATH_EXP, "rb").read()

@@ -23,17 +23,16 @@ def _fetch(c, d, cols, rows):
             c.download(np.empty((rows, cols, 2), np.float32), d["f1"]))
 
 
-@pytest.mark.parametrize("in_flight,batch_pairs,wide", [(4, -1, -1), (6, -1, -1), (6, 1, -1), (5, 5, -1), (7, 2, -1), (8, 8, -1), (8, 8, 1), (5, 5, 1), (6, 3, 1), (8, 8, 2), (5, 5, 2), (6, 3, 2), (12, 12, 2), (12, 12, -1), (7, 7, 3), (8, 8, 4), (5, 5, 4), (6, 3, 4), (12, 12, 4)])
+@pytest.mark.parametrize("in_flight,batch_pairs,wide", [(4, -1, -1), (6, -1, -1), (6, 1, -1), (5, 5, -1), (7, 2, -1), (8, 8, -1), (8, 8, 1), (5, 5, 1), (6, 3, 1), (8, 8, 2), (5, 5, 2), (6, 3, 2), (12, 12, 2), (12, 12, -1)])
 def test_batch_entry_point_equals_single_calls(pf, synth, in_flight, batch_pairs, wide):
     """pf_novel_view_batch_dev = lanes x batches: pairs of a batch share every kernel launch (blockIdx.z = pair, slab buffers, one
     sweep window = the union of the pairs' windows), lanes run side by side.  Whatever the split -- also with a ragged last batch,
     with flows the caller does not want, and with pairs whose gates differ -- the results are the bits of single calls.
     wide = 1 / 2: every sweep launch of the batch in the wide workgroup shape / in the throughput form (pf_config::sweep_wide; by default
-    only launches that oversubscribe the chip take the throughput form; 4 = the throughput form with the fused prepass), held against
-    single calls in the latency form."""
+    only launches that oversubscribe the chip take the throughput form), held against single calls in the latency form."""
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     cols, rows, n = 1000, 1400, (12 if in_flight > 8 else 7)
-    c = pf.Context(0, exp=wide in (1, 3, 4), batch_pairs=batch_pairs, sweep_wide=wide)   # forms 1, 3 and 4 only exist in the lab build
+    c = pf.Context(0, exp=wide == 1, batch_pairs=batch_pairs, sweep_wide=wide)   # form 1 only exists in the lab build
     ref_ctx = pf.Context(0, sweep_wide=0)
     pairs = [_dev_pair(pf, c, synth, cols, rows, 100 + i) for i in range(n)]
     # pair 2: an extra hole in the alpha of both images -> a different gate / bounding box than its batch mates
