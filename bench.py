@@ -405,12 +405,14 @@ def main():
         # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is
         # READ FROM A COMMITTED FILE -- the rocprofv3 --pmc passes of this same command (profiles/, see its note) -- and labelled so.
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r04_pmc_bench.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r05_pmc_bench.json")
+        if not os.path.exists(pmc_path):
+            pmc_path = os.path.join(ROOT, "profiles", "r04_pmc_bench.json")
         if (cols, rows, args.alg) == (9000, 4000, "pixflow_low") and os.path.exists(pmc_path):
             try:
                 pl = json.load(open(pmc_path))["sweep_per_launch"]
                 traffic = round(0.5 * (pl["traffic_bytes_lo"] + pl["traffic_bytes_hi"]))
-                traffic_src = "from_file: profiles/r04_pmc_bench.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per sweep launch; read side bracketed [raw, 2x raw], midpoint reported; NOT measured by this run)"
+                traffic_src = "from_file: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per sweep launch; read side bracketed [raw, 2x raw], midpoint reported; NOT measured by this run)" % os.path.basename(pmc_path)
             except Exception:
                 pass
         if "sweep" in prof and prof["sweep"][1] > 0:
@@ -447,14 +449,16 @@ def main():
                 lb = {"swept_steps": swept, "t_step_us": round(t_step, 4), "bound_ms": round(bound_ms, 3),
                       "measured_sweep_ms_per_direction": round(sweep_ms_per_dir, 3), "frac_of_bound": round(bound_ms / sweep_ms_per_dir, 4),
                       "note": "bound = swept_steps x t_step of ONE lone band (8 rows x 4096, HIP events); the two directions run concurrently"}
-                isa = os.path.join(ROOT, "profiles", "r04_sweep_step_isa.json")
+                isa = os.path.join(ROOT, "profiles", "r05_sweep_step_isa.json")
+                if not os.path.exists(isa):
+                    isa = os.path.join(ROOT, "profiles", "r04_sweep_step_isa.json")
                 if os.path.exists(isa):
                     try:
                         hw = json.load(open(isa))
                         lb["hw_floor_us"] = hw["hw_floor_us"]
                         lb["hw_floor_ms"] = round(swept * hw["hw_floor_us"] * 1e-3, 3)
                         lb["frac_of_hw_floor"] = round(swept * hw["hw_floor_us"] * 1e-3 / sweep_ms_per_dir, 4)
-                        lb["hw_floor_source"] = "from_file: profiles/r04_sweep_step_isa.txt (loop-carried dependency chain of one step of compute_band<1,...>, priced with MI355X_MICROARCH.md latencies)"
+                        lb["hw_floor_source"] = "from_file: profiles/" + os.path.basename(isa).replace(".json", ".txt") + " (loop-carried dependency chain of one step of compute_band<1,...>, priced with MI355X_MICROARCH.md latencies)"
                     except Exception:
                         pass
                 res["roofline"]["latency_bound"] = lb
@@ -523,6 +527,14 @@ def main():
                                    "pairs_in_parallel": ({"value": round((1 + len(more)) * smp / t3, 4), "unit": "Mpix/s", "cores": 2 * (1 + len(more)), "pairs": 1 + len(more), "seconds": round(t3, 2),
                                                           "note": "SURVEY 8(d) leg (iii), config 5: the same sub-strip of the 8 pairs (seeds 1234..1241) at the same time, two threads each"} if t3 else None),
                                    "host_threads_available": os.cpu_count()}
+            fp = os.path.join(ROOT, "profiles", "r05_cpu_full_pair.json")
+            if (cols, rows, args.alg) == (9000, 4000, "pixflow_low") and os.path.exists(fp):
+                try:   # the WHOLE pair once on a GPU box's host (tests/micro/cpu_full_pair.py); read from the committed file, not run here (minutes)
+                    fj = json.load(open(fp))
+                    res["cpu_baseline"]["full_pair"] = {"from_file": "profiles/r05_cpu_full_pair.json", "two_threads": fj["two_threads"], "one_thread": fj["one_thread"],
+                                                        "cpu_model": fj["cpu_model"], "nproc": fj["nproc"], "outputs_equal_committed_fixture_sha256": fj["outputs_equal_committed_fixture_sha256"]}
+                except Exception:
+                    pass
             res["parity_vs_cpu"].update({"sample_max_abs_dflow_px": float(max(np.abs(g0 - r0).max(), np.abs(g1 - r1).max())),
                                          "sample_blend_bytes_off": int((gout != rout).sum())})
         if world == 1 and not args.no_extras and args.concurrent <= 1:
@@ -570,6 +582,40 @@ def main():
                 res["throughput_mode"][key] = {"value": round(nfl * mpix / tcm, 3), "unit": "Mpix/s", "pairs": nfl, "in_flight": nfl, "runs": 3, "warmup": 1,
                                                "statistic": "median", "roofline_path_frac": round(nfl * b_alg / tcm / 8e12, 6)}
             del pairs_c, outs_c
+            # ---- large displacements (round-4 review, next #2): the same dense pair with synth's displacement field scaled x4 / x8 (up to 18 / 36 px
+            # at the solver's half resolution; real rig parallax is why the reference has pixflow_search_20 at all): a lone pair and 16 in flight.
+            # The sweeps' LDS gather window follows the flow since round 5; before, x8 cost +47 % (lone pair) / +45 % (batch). ----
+            ld = {"x1": {"lone_pair_ms": round(med_ms, 3), "in_flight_16_ms_per_pair": round(1000 * mpix / res["throughput_mode"]["pairs_%dx%d_16_in_flight" % (cols, rows)]["value"], 3)}}
+            cl = pf.Context(local_rank, cols, rows)
+            for sc in (4, 8):
+                Lx, Rx, bx, _ = synth.make_pair(cols, rows, 1234, dev, disp_scale=float(sc))
+                torch.cuda.synchronize()
+                one_l = lambda: cl.novel_view_dev(Lx.data_ptr(), Rx.data_ptr(), cols, rows, max_pct, bx.data_ptr(), out.data_ptr(), f0.data_ptr(), f1.data_ptr())
+                one_l()
+                tl = []
+                for _ in range(5):
+                    t1 = time.perf_counter(); one_l(); tl.append(time.perf_counter() - t1)
+                fmax = float(f0.abs().max())
+                del Lx, Rx, bx
+                pairs_d = [synth.make_pair(cols, rows, 6000 + i, dev, disp_scale=float(sc))[:3] for i in range(16)]
+                outs_d = [torch.empty((rows, cols, 4), dtype=torch.uint8, device=dev) for _ in range(16)]
+                torch.cuda.synchronize()
+                call_d = lambda: ct.novel_view_batch_dev([p[0].data_ptr() for p in pairs_d], [p[1].data_ptr() for p in pairs_d], cols, rows, max_pct,
+                                                          [p[2].data_ptr() for p in pairs_d], [o.data_ptr() for o in outs_d], None, None, in_flight=16)
+                call_d()
+                td = []
+                for _ in range(3):
+                    t1 = time.perf_counter(); call_d(); td.append(time.perf_counter() - t1)
+                ld["x%d" % sc] = {"lone_pair_ms": round(1000 * statistics.median(tl), 3), "in_flight_16_ms_per_pair": round(1000 * statistics.median(td) / 16, 3),
+                                  "max_abs_flow_px_full_res": round(fmax, 1)}
+                del pairs_d, outs_d
+                torch.cuda.empty_cache()
+            cl.close()
+            for k in ("x4", "x8"):
+                ld[k]["lone_pair_vs_x1"] = round(ld[k]["lone_pair_ms"] / ld["x1"]["lone_pair_ms"], 4)
+                ld[k]["in_flight_16_vs_x1"] = round(ld[k]["in_flight_16_ms_per_pair"] / ld["x1"]["in_flight_16_ms_per_pair"], 4)
+            ld["note"] = "synth.make_pair(disp_scale = 4, 8): the dense pair's analytic displacement field scaled; lone pair = median of 5 calls of pf_novel_view_dev, 16 in flight = median of 3 calls of pf_novel_view_batch_dev"
+            res["large_displacement"] = ld
             ct.close()
             torch.cuda.empty_cache()
         line = json.dumps(res)

@@ -160,8 +160,11 @@ int pf_stitch_step(pf_ctx* ctx, const uint8_t* l_bgra, const uint8_t* r_bgra, in
 
 /* Hint, given BEFORE step i: the l_bgra of step i+1.  Step i then issues that host->device upload after its own kernels are
  * enqueued, so it overlaps the compute (CPU/main.cpp:66-69 reads image i+1 only after step i).  One-shot: step i consumes the
- * hint, step i+1 consumes (or, if it is called with anything else, drops) the uploaded copy; the buffer must stay valid and
- * unchanged until step i+1 has returned.  NULL cancels.  Purely an optimisation: results are identical. */
+ * hint, step i+1 consumes (or, if it is called with anything else, drops) the uploaded copy.  CONTRACT: the buffer must stay valid
+ * and UNCHANGED until step i+1 has returned.  The library guards against the common slip (a buffer reused for another image at the
+ * same address) with a content signature over 16 evenly spaced rows taken at upload time -- a sample, not a hash of the whole image:
+ * a partial overwrite that misses those rows is not detected and the stale device copy would be used.  NULL cancels.  With the
+ * contract kept it is purely an optimisation: results are identical. */
 int pf_stitch_prefetch(pf_ctx* ctx, const uint8_t* next_l_bgra, int cols, int rows, size_t step_bytes);
 
 /* ---- device-resident entry points (packed buffers already in this context's HBM) -----------

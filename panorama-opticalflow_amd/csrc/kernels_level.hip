@@ -1,5 +1,7 @@
 // Per-level kernels of PixFlow::patchMatchPropagationAndSearch (CPU/PixFlow.hpp:272-340) except the
 // sweeps, plus the inter-level and final upsampling (:122-134).  All stencil/streaming, HBM-bound.
+#include <stdio.h>
+#include <stdlib.h>
 #include "pf_common.hpp"
 
 namespace pf {
@@ -152,6 +154,11 @@ void launch_gradients(hipStream_t st, const float* img, int w, int h, float* gxy
 void launch_gradients_all(hipStream_t st, const float* pyr0, const float* pyr1, float* grad0, float* grad1, const LevelTable& t, size_t first,
                           size_t total, const Gauss& g3, int max_blocks, Batch bt) {
   if (total <= first) return;
+  // k_gradients_all takes four adjacent elements per thread and stores them as two float4: every level must start on a multiple of four
+  // elements and so must `first` (pf_api.hip pads the levels to multiples of 64).  A table from anywhere else is refused loudly.
+  bool aligned = first % 4 == 0;
+  for (int l = 0; l < t.n; ++l) aligned = aligned && t.off[l] % 4 == 0;
+  if (!aligned) { fprintf(stderr, "[panoflow] launch_gradients_all: level offsets must be multiples of 4 elements\n"); abort(); }
   size_t blocks = (total - first + 1023) / 1024;   // four elements per thread
   if (max_blocks > 0 && blocks > size_t(max_blocks)) blocks = size_t(max_blocks);
   hipLaunchKernelGGL(k_gradients_all, dim3((unsigned)blocks, 2, bt.n), dim3(256), 0, st, pyr0, pyr1, reinterpret_cast<float2*>(grad0),
