@@ -7,11 +7,11 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 R=${1:-r01}
 rm -rf gpurun_out/prof_$R gpurun_out/pmcb_*
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$R -o bench -- python bench.py --no-cpu-baseline --no-extras > gpurun_out/prof_$R.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$R -o bench -- python bench.py --no-cpu-baseline --no-extras --pairs-total 0 > gpurun_out/prof_$R.log 2>&1
 grep "^{\"metric\"" gpurun_out/prof_$R.log | tail -1 > gpurun_out/${R}_bench_line.json
 cp $(find gpurun_out/prof_$R -name '*kernel_stats.csv' | head -1) gpurun_out/${R}_bench_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 1200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcb_$c -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-profile > gpurun_out/pmcb_$c.log 2>&1
+  timeout 1200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcb_$c -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-profile --pairs-total 0 > gpurun_out/pmcb_$c.log 2>&1
   echo "$c rc=$?"
 done
 python - <<PY
