@@ -39,6 +39,34 @@ def test_flow_bidir_and_blend_512(ctx, orc, pf, pair512, alg):
     assert np.array_equal(out, rout), "%d blended bytes differ (PSNR %.2f dB)" % (int((out != rout).sum()), _psnr(out, rout))
 
 
+@pytest.mark.parametrize("cols,rows,scale,alg", [(900, 520, 6.0, "pixflow_low"), (520, 900, 10.0, "pixflow_search_20")])
+def test_large_displacement_pair_vs_oracle(ctx, orc, pf, synth, cols, rows, scale, alg):
+    """Round 5: a whole bidirectional solve + blend on a pair whose displacement field is 6x / 10x the benchmark scene's (up to ~90 px at full
+    resolution: the sweeps' gather windows follow offsets of tens of texels at the fine levels, drift with them and are cut back at the
+    borders), both band orientations (wide and tall pair), lone-pair entry point and a batch of three in the throughput form: the oracle's bits."""
+    import torch
+    L, R, blend, _ = synth.make_pair(cols, rows, 77, "cpu", disp_scale=scale)
+    L, R, blend = L.numpy(), R.numpy(), blend.numpy()
+    mp = pf.max_percentage_by_name(alg)
+    rLR, rRL = orc.flow_bidir(L, R, mp)
+    assert np.abs(rLR).max() > 3.5 * scale            # the solve does follow the large field
+    rout = orc.combine_novel_views(L, R, rLR, rRL, blend)
+    out, fLR, fRL = ctx.novel_view(L, R, mp, blend)
+    assert np.array_equal(fLR, rLR) and np.array_equal(fRL, rRL), "flows differ: max %g" % max(np.abs(fLR - rLR).max(), np.abs(fRL - rRL).max())
+    assert np.array_equal(out, rout)
+    c2 = pf.Context(0, sweep_wide=2)                  # every sweep launch in the throughput form
+    n = cols * rows
+    d = [{"L": c2.dev_alloc(n * 4), "R": c2.dev_alloc(n * 4), "b": c2.dev_alloc(n * 4), "o": c2.dev_alloc(n * 4), "f0": c2.dev_alloc(n * 8), "f1": c2.dev_alloc(n * 8)} for _ in range(3)]
+    for k in d:
+        c2.upload(k["L"], L); c2.upload(k["R"], R); c2.upload(k["b"], blend)
+    c2.novel_view_batch_dev([k["L"] for k in d], [k["R"] for k in d], cols, rows, mp, [k["b"] for k in d], [k["o"] for k in d], [k["f0"] for k in d], [k["f1"] for k in d], in_flight=3)
+    for k in d:
+        assert np.array_equal(c2.download(np.empty((rows, cols, 2), np.float32), k["f0"]), rLR)
+        assert np.array_equal(c2.download(np.empty((rows, cols, 2), np.float32), k["f1"]), rRL)
+        assert np.array_equal(c2.download(np.empty((rows, cols, 4), np.uint8), k["o"]), rout)
+    c2.close()
+
+
 def test_blend_only(ctx, orc, pair512):
     L, R, blend = pair512
     r = np.random.default_rng(3)

@@ -193,6 +193,29 @@ def test_sweep_large_flows_use_global_fallback(ctx, orc, w, h):
         assert np.array_equal(got, ref), "mismatches %d" % (got != ref).sum()
 
 
+@pytest.mark.parametrize("w,h,amp", [(420, 150, 30.0), (150, 420, 30.0), (700, 260, 60.0), (300, 330, 12.0)])
+def test_sweep_large_smooth_flows_window_follows(ctx, orc, w, h, amp):
+    """Round 5: the sweeps' LDS gather window follows the flow (centred per chunk on pixel + the rounded blurred flow).  A LARGE, SMOOTH flow
+    field -- tens of pixels, varying along and across the bands so that the window's offsets drift in both axes, running past the image
+    borders (clamped centres), with holes in the alpha (pixels that are not updated) and a discontinuity (the offset may only move one texel
+    per chunk: a stretch of chunks must fall back to HBM) -- in every sweep form and both band orientations, forward and backward:
+    bit-identical to the oracle.  (Small flows and wild random ones are the neighbouring tests.)"""
+    r = np.random.default_rng(int(amp) + w)
+    img0 = r.random((h, w)).astype(np.float32); img1 = r.random((h, w)).astype(np.float32)
+    g0 = np.stack(orc.gradients(img0), -1); g1 = np.stack(orc.gradients(img1), -1)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    flow = np.stack([amp * np.sin(2.3 * np.pi * y / h) + 0.4 * amp * np.cos(3.1 * np.pi * x / w), 0.35 * amp * np.sin(2.7 * np.pi * x / w + 0.6) - 0.2 * amp * y / h], -1).astype(np.float32)
+    flow[h // 3:h // 3 + 9, w // 2:] += np.float32(0.6 * amp)                     # a discontinuity across a few rows
+    flow += (r.standard_normal((h, w, 2)) * 0.7).astype(np.float32)              # proposals differ from pixel to pixel
+    blurred = orc.gaussian_blur(flow, 15, 8.0)
+    a0 = np.ones((h, w), np.float32); a1 = np.ones((h, w), np.float32)
+    a0[h // 5:h // 5 + 23, w // 4:w // 4 + 61] = 0.3; a1[2 * h // 3:, :w // 6] = 0.5                     # pixels that are not updated
+    for fwd in (1, 0):
+        ref = orc.sweep(g0[..., 0], g0[..., 1], g1[..., 0], g1[..., 1], blurred, a0, a1, flow, fwd)
+        got = ctx.stage_sweep(g0, g1, blurred, a0, a1, flow, fwd)
+        assert np.array_equal(got, ref), "forward %d: mismatches %d" % (fwd, (got != ref).sum())
+
+
 @pytest.mark.parametrize("w,h", [(96, 40), (40, 96)])
 def test_sweep_operands_outside_fast_math_range(ctx, orc, w, h):
     """The sweep kernel's cheap exact sqrt/division are only valid for operands that are 0 or in [2^-95, 2^100]; any
