@@ -110,6 +110,9 @@ constexpr int kWCp = kWC + PF_WCP_EXTRA; // row stride of the window: ring colum
 #ifndef PF_DRAIN_CHUNK
 #define PF_DRAIN_CHUNK 1  // 1: the drainer writes whole 8-step chunks instead of whatever has been produced
 #endif
+#ifndef PF_SELF_PUBLISH
+#define PF_SELF_PUBLISH 0 // 1: the last compute wave of a workgroup stores its hand-off granules itself (experiment: measured, slower, see compute_band)
+#endif
 #ifndef PF_DRAIN_SLEEP
 #define PF_DRAIN_SLEEP 8  // drainer: s_sleep between two looks at the bands' step counters when no chunk was complete
 #endif
@@ -445,7 +448,7 @@ __device__ __forceinline__ void st_cnt(int* p, int v) {
 // wave-uniform, so the per-step "is my top neighbour there" test is two scalar instructions.
 template <class G, int TOP, bool TR, bool FWD, bool SPARSE>
 __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restrict__ g1, int W, int H, int nsteps, int w, int band,
-                                             int nact, bool publishes, float rW, float rEps, int uLo, int LSv) {
+                                             int nact, bool publishes, float rW, float rEps, int uLo, int LSv, unsigned long long* bnd_out = nullptr) {
   constexpr int kWaves = G::kWaves, kRS = G::kRS, kOS = G::kOS, kWA = G::kWA;
   constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0;
   const int lane = threadIdx.x & 63;
@@ -469,7 +472,15 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
   // that computed it (lane 0 of a group), no select.
   const int kk = k & 3;
   const float addx = (kk == 1) ? kGradEpsilon : 0.0f, addy = (kk == 2) ? kGradEpsilon : 0.0f;
+#if PF_SELF_PUBLISH
+  // EXPERIMENT (round-4 review, next #3; profiles/r05_handoff_ab.txt): the workgroup's last band stores its granules itself -- no publisher
+  // wave in the relay -- at the price of an exec-masked 8-byte global store per step on a wave that is on the sweep's dependency chain
+  const bool selfPub = publishes && (w == kWaves - 1);
+  const bool lastPub = false;
+  const bool pubLane = (threadIdx.x & 63) == 8 * (kRows - 1);
+#else
   const bool lastPub = publishes && (w == kWaves - 1);
+#endif
   const bool hasNext = (w + 1 < nact);
   // where row 0's top neighbour of column c lives, and the counter that says how many columns are there
   const int wp = (w > 0) ? w - 1 : 0;
@@ -708,6 +719,12 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
         asm volatile("" : "+v"(tvN));   // the register PAIR as one operand: two 32-bit operands cost two v_mov per step to split and rejoin it
         tv = tvN;
       }
+#if PF_SELF_PUBLISH
+      if (selfPub) {
+        const int cx = s - (kRows - 1);
+        if (pubLane && cx >= 0 && cx < LSv) __hip_atomic_store(bnd_out + cx, pack2(fin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#endif
       prev = fin;   // valid in lane 0 of each group.  "no pixel" steps hand on their zero record: never used as a neighbour (masked / outside the image)
       // ---- publish: result ring (lane 0 of a group stores to the slot, the other lanes to a scratch slot of their own), then the step counter ----
       outChunk[j * kRows] = f2w{fin.x, fin.y};
@@ -1078,9 +1095,9 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
     const int top = (wave > 0) ? 1 : ((wg > 0 || staticTop) ? 2 : 0);   // where row 0's top neighbour comes from
     const int band = bandLo + band0 + wave;                               // absolute band index
     bool ok;
-    if (top == 1) ok = compute_band<G, 1, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
-    else if (top == 2) ok = compute_band<G, 2, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
-    else ok = compute_band<G, 0, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
+    if (top == 1) ok = compute_band<G, 1, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv, boundary + size_t(wg + 1) * LSv);
+    else if (top == 2) ok = compute_band<G, 2, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv, boundary + size_t(wg + 1) * LSv);
+    else ok = compute_band<G, 0, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv, boundary + size_t(wg + 1) * LSv);
     if (!ok) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #ifdef PF_SWEEP_STATS_PRINT   // (stage entry only: ctrl[2..3] belong to the next sweep in a whole solve)
     if (lane == 0) { atomicAdd(&ctrl[2], atomicExch(&sm.statHits, 0)); atomicAdd(&ctrl[3], atomicExch(&sm.statSpins, 0)); }
@@ -1416,7 +1433,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
 
   if (wave == kWaves + kLoaders) {
     // ======================= publisher: last row of the workgroup -> granules in HBM (tight loop, never waits on HBM) =======================
-    if (!publishes) return;
+    if (!publishes || PF_SELF_PUBLISH) return;
     unsigned long long* bnd_out = boundary + size_t(wg + 1) * LSv;   // granule row 0 belongs to the static row above the window
     const int wl = kWaves - 1;
     int pt = 0, idle = 0;
