@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from conftest import load_pkg_module
 pf = load_pkg_module("pyabi")
 _form = int(os.environ.get("SW_WIDE", "0"))
-ctx = pf.Context(0, exp=_form == 1, sweep_wide=_form)   # forms 1 and 3 live in the lab build only
+ctx = pf.Context(0, exp=_form == 1, sweep_wide=_form)   # form 1 lives in the lab build only
 ctx.profile_enable(True)
 r = np.random.default_rng(0)
 shapes = [(4000, 8), (4000, 32), (4000, 64), (1100, 2000), (2000, 1100), (300, 500)]

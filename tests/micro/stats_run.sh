@@ -8,7 +8,7 @@ import sys, os, numpy as np
 sys.path.insert(0, "tests")
 from conftest import load_pkg_module
 pf = load_pkg_module("pyabi")
-ctx = pf.Context(0, sweep_wide=int(os.environ.get("SW_WIDE", "0")))   # (build var_libs/lib_stats.so with -DPF_EXPERIMENTS for forms 1 and 3)
+ctx = pf.Context(0, sweep_wide=int(os.environ.get("SW_WIDE", "0")))   # (build var_libs/lib_stats.so with -DPF_EXPERIMENTS for form 1)
 r = np.random.default_rng(0)
 w, h = [int(v) for v in "$1".split("x")]
 g0 = r.standard_normal((h, w, 2)).astype(np.float32) * 0.1

@@ -20,7 +20,7 @@ if os.environ.get("TP_WIDE"): knobs["sweep_wide"] = int(os.environ["TP_WIDE"])
 if os.environ.get("TP_WIDE_THR"): knobs["sweep_wide_threshold"] = int(os.environ["TP_WIDE_THR"])
 if os.environ.get("TP_WIDE_TR"): knobs["sweep_throughput_transposed"] = int(os.environ["TP_WIDE_TR"])
 if os.environ.get("TP_GRAD_FULL"): knobs["full_width_batch_gradients"] = int(os.environ["TP_GRAD_FULL"])
-c = pf.Context(0, cols, rows, exp=knobs.get("sweep_wide") == 1, **knobs)   # forms 1 and 3 live in the lab build only
+c = pf.Context(0, cols, rows, exp=knobs.get("sweep_wide") == 1, **knobs)   # form 1 lives in the lab build only
 call = lambda: c.novel_view_batch_dev([p[0].data_ptr() for p in pairs], [p[1].data_ptr() for p in pairs], cols, rows, 0,
                                       [p[2].data_ptr() for p in pairs], [o.data_ptr() for o in outs], None, None, in_flight=infl)
 call()
