@@ -457,6 +457,7 @@ __global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__
     int rh = 0, idle = 0;
     // ---- chunk 0's whole rectangle (32 D-slots x 44 rows: four blocks, one after the other, once per band) ----
     int pox, poy, frontD, pov;
+    int haveLo;   // every row of the current rectangle holds the skew slots [haveLo, frontD): a row that entered later than a slot was loaded lacks it
     {
       refill_offsets(0);
       pox = __builtin_amdgcn_readfirstlane(ocx); poy = __builtin_amdgcn_readfirstlane(ocy);
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__
       const int DB = uLo + vb + ou + ov, row0 = vb - kRadT + ov;
 #pragma unroll 1
       for (int b = 0; b < 4; ++b) { const bool whole = block_load(DB - 2 * kRadT + 8 * b, 8, row0); block_store(DB - 2 * kRadT + 8 * b, row0, whole); }
-      frontD = DB + 8 + 2 * kRadT; pov = ov;
+      frontD = DB + 8 + 2 * kRadT; pov = ov; haveLo = DB - 2 * kRadT;
     }
     bool first = true;
     for (;;) {
@@ -497,6 +498,15 @@ __global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__
       }
       block_store(frontD, row0, whole);
       if (__any(sok)) { if (sok) win_store(sD, sV, sv); }
+      if (ov != pov && need_lo > haveLo) haveLo = need_lo;   // (the row that just entered starts at need_lo)
+      if (need_lo < haveLo) {
+        // the window's lower edge moved BACK (wave-uniform, rare: the offset along the step axis is being cut back at the image's far border by
+        // up to 8 per chunk while the offset across drifts the same way -- the sum may fall by 9): rows that entered during the last chunks lack
+        // these slots (tests/test_follow_window_model.py found this)
+        const int nb = haveLo - need_lo > kBlkD ? kBlkD : haveLo - need_lo;
+        block_load(haveLo - nb, nb, row0); block_store(haveLo - nb, row0, false);
+        haveLo -= nb;
+      }
       if (n > kBlkD) {   // the ninth / tenth D-slot (wave-uniform, rare: the offsets' sum grew): one more, narrow block
         block_load(frontD + kBlkD, n - kBlkD, row0); block_store(frontD + kBlkD, row0, false);
       }

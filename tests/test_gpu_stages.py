@@ -216,6 +216,35 @@ def test_sweep_large_smooth_flows_window_follows(ctx, orc, w, h, amp):
         assert np.array_equal(got, ref), "forward %d: mismatches %d" % (fwd, (got != ref).sum())
 
 
+@pytest.mark.parametrize("w,h", [(400, 96), (96, 400)])
+def test_sweep_flows_converging_on_the_far_border(ctx, orc, w, h):
+    """The window offset along the step axis is cut back at the image's far border (every window centre must lie inside the image): there it
+    falls by up to 8 texels per chunk while the offset across the band may drift at the same time.  Flows that point at the far border column /
+    row from tens of pixels away (so that the samples stay inside the cut-back window) with a steady drift across and proposals scattered
+    over the whole window, both band orientations, forward and backward, every form.  (In the throughput form the window's lower edge then
+    moves BACK by a slot per chunk and the loader fills in what recently entered rows lack: those are the window's one-texel margin, only
+    reachable through a rounding corner case -- tests/test_follow_window_model.py checks that bookkeeping on the CPU.)"""
+    r = np.random.default_rng(w)
+    img0 = r.random((h, w)).astype(np.float32); img1 = r.random((h, w)).astype(np.float32)
+    g0 = np.stack(orc.gradients(img0), -1); g1 = np.stack(orc.gradients(img1), -1)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    for sgn in (1.0, -1.0):
+        if w > h:   # bands along x: converge on the right (sgn > 0) / left border, drift in y
+            fx = np.minimum(40.0, (w - 1 - x) if sgn > 0 else x) * sgn
+            fy = -sgn * np.clip(((x - (w - 120)) if sgn > 0 else (120 - x)) / 8.0, 0.0, 15.0)
+        else:       # bands along y
+            fy = np.minimum(40.0, (h - 1 - y) if sgn > 0 else y) * sgn
+            fx = -sgn * np.clip(((y - (h - 120)) if sgn > 0 else (120 - y)) / 8.0, 0.0, 15.0)
+        # proposals scattered over the whole window (+-4.5 around the smooth field): its edge rows / columns are sampled too
+        flow = (np.stack([fx, fy], -1) + r.uniform(-4.5, 4.5, (h, w, 2))).astype(np.float32)
+        blurred = orc.gaussian_blur(np.stack([fx, fy], -1).astype(np.float32), 15, 8.0)
+        a = np.ones((h, w), np.float32)
+        for fwd in (1, 0):
+            ref = orc.sweep(g0[..., 0], g0[..., 1], g1[..., 0], g1[..., 1], blurred, a, a, flow, fwd)
+            got = ctx.stage_sweep(g0, g1, blurred, a, a, flow, fwd)
+            assert np.array_equal(got, ref), "sign %g forward %d: mismatches %d" % (sgn, fwd, (got != ref).sum())
+
+
 @pytest.mark.parametrize("w,h", [(96, 40), (40, 96)])
 def test_sweep_operands_outside_fast_math_range(ctx, orc, w, h):
     """The sweep kernel's cheap exact sqrt/division are only valid for operands that are 0 or in [2^-95, 2^100]; any
