@@ -222,9 +222,9 @@ __device__ __forceinline__ float dpp_shl0(float src) {
 // SKEW (throughput form, 32 rows per band): the window ring is indexed by u + (window row) instead of u -- at any step all 32 rows of a
 // band then touch the same ~31 ring slots although their pixels are 32 columns apart (a ring of 64 serves; unskewed it would take 128).
 // Moving one window row down also moves one slot on, and the first TWO ring columns are stored again behind column 63 (kWCPT).
-// FOLLOW: the window is a torus addressed by the texel's absolute coordinates and centred by its loader on pc = the pixel + an integer offset
-// (the rounded blurred flow of the chunk, kept with the record): resident are the texels of [pc - 8, pc + 8] in both axes, so the test is on
-// the sample position against pc -- a flow of any size whose sample falls within 7 of the centre is served from LDS.  A pixel that is not updated carries pc = NaN: its (discarded) evaluations never
+// FOLLOW: the window is a torus addressed by the texel's absolute coordinates and centred by its loader on the pixel + an integer offset pc
+// (the rounded blurred flow of the chunk, kept with the record): resident are the texels within 8 of the centre in both axes, so the test is on
+// the flow against pc -- a flow of any size within 7 of the offset is served from LDS.  A pixel that is not updated carries pc = NaN: its (discarded) evaluations never
 // send the wave through the HBM path -- they read a valid LDS slot with whatever it holds ("not > 7" is true for a NaN distance).
 // FOLLOW = 2 (throughput form): the same torus in skewed coordinates -- ring row = the texel's row mod kWA (52; `ob` = a multiple of 52 chosen by
 // the loader per chunk so that the chunk's rows fall in [ob, ob + 104): one conditional subtraction), ring column = (u + v) & 63; pc = the
@@ -250,11 +250,13 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
     const f2p dm = fd - pc;
     inwin = !(__builtin_fmaxf(fabsf(dm.x), fabsf(dm.y)) > float(kRadT - 1)) || !live;
   } else if (FOLLOW == 1) {
-    // The loader keeps every window centre INSIDE the image (it clamps the chunk's offset), so the test may be made on the sample position
-    // before the clamp to the image -- off the address chain, beside it: a sample within 7 of a centre in [0, W - 1] that the clamp moves
-    // to 0 or W - 2 is still within 7 of it.  The subtraction is exact to well under a texel, and the window holds one texel more than the test
-    // admits on either side ([pc - 8, pc + 8]): a difference that rounds onto +-7 is covered.
-    const f2p dm = match - pc;
+    // pc = the window's OFFSET o (the record's third quad, z / w; centre = pixel + o).  The loader keeps every window centre INSIDE the image
+    // (it clamps the chunk's offset), so the test may be made on the flow relative to the offset, before the sample's clamp to the image -- off
+    // the address chain, from the proposal alone (it issues beside the position sum and fills the wait state behind that packed add): a sample
+    // within 7 of a centre in [0, W - 1] that the clamp moves to 0 or W - 2 is still within 7 of it.  The subtraction is exact to well under a
+    // texel, and the window holds one texel more than the test admits on either side ([centre - 8, centre + 8]): a difference that rounds onto
+    // +-7 is covered.
+    const f2p dm = fd - pc;
     inwin = !(__builtin_fmaxf(fabsf(dm.x), fabsf(dm.y)) > float(kRad - 1));   // (NaN centre = a pixel that is not updated: "inside")
   } else inwin = __builtin_fmaxf(fabsf(fdx), fabsf(fdy)) <= float(kRad - 1);
   // sweep-order coordinates of texel (x0,y0): u along the step axis, v across the bands
@@ -516,7 +518,7 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
   int fcRec = 0, fcTail = 0, fcPub = 0, fcNext = 0;
   float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;   // this step's record (read one step ahead)
   float2 rc = make_float2(0.f, 0.f);                          // the record's third quad: the pixel's (x, y) ...
-  float2 rp = make_float2(0.f, 0.f);                          // ... and, FOLLOW, the centre of its gather window (x + ox, y + oy), written by the loader
+  float2 rp = make_float2(0.f, 0.f);                          // ... and, FOLLOW, the offset (ox, oy) of its gather window, written by the loader
   for (int s0 = 0; s0 < nsteps; s0 += kChunk) {
     // ---- once per 8 steps: records of the chunk present, result-ring slots of the chunk free ----
     if (dead) return false;
@@ -769,7 +771,7 @@ __device__ __forceinline__ void d_make_record_at(int band, int s, int r, bool in
   // A pixel that is not updated (gate <= 0) carries E(C) = kKeepEnergy and rC = C: every proposal's energy is >= 0 (or NaN), so
   // the selection keeps rC = C -- the sweep's step needs no "if not gated keep C" of its own (two v_cndmask per step).
   // (third quad: (x, y) and -- for the latency form's flow-following window -- z = w = 0 for a pixel that is updated, NaN otherwise: the sweep's
-  // loader adds the window centre x + ox, y + oy there, and a NaN centre means "never leaves the window", see d_error_fast<FOLLOW>)
+  // loader adds the window offset (ox, oy) there, and a NaN offset means "never leaves the window", see d_error_fast<FOLLOW>)
   a = make_float4(0.f, 0.f, 0.f, 0.f); b = make_float4(kKeepEnergy, 0.f, 0.f, kKeepEnergy); c = make_float4(0.f, 0.f, __builtin_nanf(""), __builtin_nanf(""));
   if (inside && s - r >= 0 && ia < uHi && ia < LS && ib < LB) {
     const int cx = transposed ? ib : ia, cy = transposed ? ia : ib;   // position in sweep order
@@ -1127,8 +1129,8 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
     //     the loader keeps a column front and loads the 7 / 8 / 9 new columns of the chunk's 24 rows (8 + the change of ou), and, when ov
     //     moved, the ONE new row over the columns already present; what it overwrites (column - 64, row -+ 32) left every active chunk's
     //     rectangle long ago (the loader is at most 4 chunks ahead: 31 + 24 + 3 columns < 64, 24 + 3 rows < 32);
-    //   * the pixel's window centre (x + ox, y + oy) travels with its record (third quad, z / w: patched in here), so the step's test is
-    //     |clamped sample - centre| <= 7 (d_error_fast<FOLLOW>): same texels as the HBM path => same bits, whatever the offsets are.
+    //   * the window's offset (ox, oy) travels with the pixel's record (third quad, z / w: patched in here), so the step's test is
+    //     |flow - offset| <= 7 (d_error_fast<FOLLOW>): same texels as the HBM path => same bits, whatever the offsets are.
     // One loader per compute wave: its in-order memory queue holds nothing but this band's loads, and a round
     // (issue up to kLoadAhead chunks, wait once, registers -> LDS, publish) costs one HBM round trip.
     const int w = wave - kWaves;
@@ -1353,7 +1355,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
             const float2 fv = make_float2(qvalid[c] ? f.x : 0.f, qvalid[c] ? f.y : 0.f);
             const float2 rc0 = on ? own_gradient_step(f, e0, e1, e2) : fv;
             dst[1] = make_float4(on ? e0 : kKeepEnergy, rc0.x, rc0.y, (on && ia_of[c] > 0) ? e0 : kKeepEnergy);
-            dst[2] = make_float4(float(qx[c]), float(qy[c]), on ? float(qx[c]) + cox[c] : __builtin_nanf(""), on ? float(qy[c]) + coy[c] : __builtin_nanf(""));
+            dst[2] = make_float4(float(qx[c]), float(qy[c]), on ? cox[c] : __builtin_nanf(""), on ? coy[c] : __builtin_nanf(""));
           }
         }
       }
@@ -1365,7 +1367,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
           if (!fused) {
             float4 v3[3] = {va[c], vb4[c], vc[c]};
 #pragma unroll
-            for (int k = 0; k < 3; ++k) if (isC[k]) { v3[k].z = (v3[k].x + cox[c]) + v3[k].z; v3[k].w = (v3[k].y + coy[c]) + v3[k].w; }   // (+ 0, or + NaN where the pixel is not updated)
+            for (int k = 0; k < 3; ++k) if (isC[k]) { v3[k].z = cox[c] + v3[k].z; v3[k].w = coy[c] + v3[k].w; }   // the chunk's window offset (+ 0, or + NaN where the pixel is not updated)
             dst[lane] = v3[0]; dst[lane + 64] = v3[1]; dst[lane + 128] = v3[2];
           }
 #pragma unroll

@@ -10,7 +10,7 @@
        * in-order    = one wave issuing the very instruction stream in order (issue cost per instruction, results available
                        after their latency, s_waitcnt lgkmcnt(0) drains the LDS queue) -- what ONE wave alone on a SIMD needs
                        per step; this is the floor bench.py reports as roofline.latency_bound.hw_floor_us,
-  4. writes profiles/r04_sweep_step_isa.txt (annotated listing of one step with the critical path marked) and .json.
+  4. writes profiles/r05_sweep_step_isa.txt (annotated listing of one step with the critical path marked) and .json.
 
 Latencies.  From /opt/skills/guides/MI355X_MICROARCH.md: wave64 VALU issue 2 cycles (SIMD-32), dependent VALU ~4 cycles,
 ds_read issue->use ~50 cycles, DS cycles per wave-instruction (LDS table).  Where the guide is silent the numbers are this repo's own
@@ -269,7 +269,7 @@ def main():
     ap.add_argument("--lat", action="append", default=[], help="override a lone-wave latency: name=cycles (valu, pk, trans, dpp, cmp, ds_read, salu, readlane)")
     ap.add_argument("--issue", action="append", default=[], help="override a lone-wave issue cost: name=cycles (valu, pk, trans, dpp, cmp, salu, readlane)")
     ap.add_argument("--clock-ghz", type=float, default=2.4)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_sweep_step_isa"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_sweep_step_isa"))
     a = ap.parse_args()
     lat, issue = dict(LAT_LONE), dict(ISSUE_LONE)
     for kv in a.lat:
@@ -318,11 +318,11 @@ def main():
                        e["issue_only_cycles_per_step"], e["recurrence_cycles_per_step"], e["in_order_cycles_per_step"], e["in_order_us_per_step"], a.clock_ghz,
                        g["issue_only_cycles_per_step"], g["recurrence_cycles_per_step"], g["in_order_cycles_per_step"], g["in_order_us_per_step"]))
         f.write("\nhw_floor_us = %.4f  (lone-wave pricing, max over the loops that read a top neighbour; bench.py: roofline.latency_bound.hw_floor_us).\n"
-                "Measured on MI355X: 0.275 us per step for a lone band (bench.py t_step_us, HIP events; effective clock 2.41 GHz by GRBM_GUI_ACTIVE,\n"
+                "Measured on MI355X: 0.267 us per step for a lone band (bench.py t_step_us, HIP events; effective clock 2.41 GHz by GRBM_GUI_ACTIVE,\n"
                 "tests/micro/clock_probe.sh): the kernel runs AT this floor (the model is a few percent pessimistic: it prices every vector instruction\n"
                 "at the measured average interval).  On an ideal single-wave pipeline (guide numbers) the same stream would need %.4f us: the factor\n"
                 "between the two is the lone-wave issue interval, which no instruction placement changes -- only fewer instructions per step do\n"
-                "(round 1: 0.70 us -> round 2: 0.35 -> round 3: 0.275 us by removing them; DESIGN.md 3.3), or a second wave that shares the step's work, which the\n"
+                "(round 1: 0.70 us -> round 2: 0.35 -> round 3: 0.275 -> round 5: 0.267 us by removing them; DESIGN.md 3.3), or a second wave that shares the step's work, which the\n"
                 "step's own dependency chain forbids (every hand-over between waves goes through LDS: >= 90 cycles per hop, lat_probe).\n"
                 "Round 4 measured the other side of the same coin: the SIMD's VALU pipe takes ~4 cycles per wave64 instruction, so ONE such wave already keeps it ~65 %% busy --\n"
                 "two compute waves per SIMD (the wide workgroup shape, same instruction stream) run at 0.43 us per step each, not 0.29 (profiles/r04_wide_sweep.txt).\n\n"
