@@ -131,6 +131,9 @@ struct F2x2 { float a, b, c, d; } __attribute__((aligned(8)));
 // pixel that is updated left the LDS gather window (the whole wave then takes the HBM path), [2] / [3] the same for the throughput form (two
 // gather rounds per step)
 __device__ unsigned long long g_sweep_stats[4];
+#ifdef PF_SWEEP_TRACE   // (with PF_SWEEP_STATS; tests/micro/band_trace.py) per band: [0] edge waits, [1] edge spins, [2] slow chunk starts, [3] end, [4 + i] start of chunk 64 i (wall clock, 10 ns)
+__device__ long long g_band_trace[1024][40];
+#endif
 #endif
 
 // errorFunction (PixFlow.hpp:427-456); identical operation order to kernels_sweep.hip / the oracle.
@@ -569,6 +572,9 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
 #endif
 #ifdef PF_SWEEP_STATS
     if (s0 == 8) statR8 = wall_clock64();
+#ifdef PF_SWEEP_TRACE
+    if (((s0 >> 3) & 63) == 0 && band < 1024 && (s0 >> 9) < 34 && lane == 0) g_band_trace[band][4 + (s0 >> 9)] = wall_clock64();
+#endif
     if (s0 == 0) statC0 = wall_clock64();
 #endif
     // Ring positions of the chunk (nsteps is a whole number of chunks; every ring length is a multiple of the chunk, so a
@@ -740,6 +746,9 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
   if (lane == 0) {
     atomicAdd(&sm.statHits, statHits); atomicAdd(&sm.statSpins, statSpins);
     atomicAdd(&g_sweep_stats[0], (unsigned long long)nsteps);   // ([1] is counted where it happens: d_error_fast)
+#ifdef PF_SWEEP_TRACE
+    if (band < 1024) { g_band_trace[band][0] = statHits; g_band_trace[band][1] = statSpins; g_band_trace[band][2] = statSlowChunks; g_band_trace[band][3] = wall_clock64(); }
+#endif
 #ifdef PF_SWEEP_STATS_PRINT
     if (band < 8 || band % 32 == 1 || (!hasNext && !publishes)) printf("band %d xcc %d: %lld cycles, %lld in chunk-start waits, %d edge waits, %d spins, nsteps %d, IEEE-redo steps %d, out-of-window steps %d, slow chunk starts %d (%d spins; first check failed on rec %d tail %d pub %d next %d), step8 at %lld, end at %lld; since kernel entry: band start %lld, first chunk %lld, end %lld (10ns)\n", band, (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF),
            (long long)__builtin_readcyclecounter() - statT0, statWait, statHits, statSpins, nsteps, statRedo, statOOW, statSlowChunks, statChunkSpins, statFailRec, statFailTail, statFailPub, statFailNext, statR8, (long long)wall_clock64(), statB - sm.statEntry, statC0 - sm.statEntry, (long long)wall_clock64() - sm.statEntry);
@@ -1553,6 +1562,12 @@ int sweep_pk_probe(hipStream_t st, unsigned* bad) {
 #ifdef PF_SWEEP_STATS
 }  // namespace pf
 // diagnostics build only: read (and optionally clear) the out-of-window counters
+#ifdef PF_SWEEP_TRACE
+extern "C" __attribute__((visibility("default"))) int pf_debug_band_trace(long long* out, int nbands) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::g_band_trace), size_t(nbands) * 40 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" __attribute__((visibility("default"))) int pf_debug_sweep_stats(unsigned long long* out4, int reset) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(pf::g_sweep_stats), 32) != hipSuccess) return -1;
