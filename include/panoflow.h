@@ -53,7 +53,7 @@ pf_ctx* pf_create(int device, int max_cols, int max_rows);
 typedef struct pf_config {
   int struct_size;
   int device, max_cols, max_rows;   /* as pf_create */
-  int stagger_levels;       /* direction R->L starts this many coarse levels behind L->R (-1: 2, or 4 for >= 5 Mpix half-res) */
+  int stagger_levels;       /* direction R->L starts this many coarse levels behind L->R (-1: 2, or 3 for >= 5 Mpix half-res) */
   int64_t fuse_small_level_px; /* levels up to this many pixels fold the upsample / second median into the neighbouring Gaussian
                                launches (-1: 0 for a lone pair, 262144 for the lanes of the throughput mode) */
   int fine_gradient_blocks; /* width of the launch that computes the gradients of the 4 finest levels beside the coarse sweeps (64) */

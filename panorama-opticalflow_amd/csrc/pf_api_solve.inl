@@ -394,8 +394,9 @@ int solve_n(pf_ctx* c, int nb, const uint8_t* const* d_img0, const uint8_t* cons
   // leave most CUs idle -- run beside each other too.  A small offset puts one direction's throughput kernels beside the other's
   // sweeps.  The late direction finishes k coarse levels later, which is what limits k: measured (profiles/r02_frontend_ab.txt)
   // strip 27.36 -> 27.18 ms at k = 2, 9000x4000 pair 59.1 -> 57.7 ms at k = 4-6.  Not for the lanes of the throughput mode (they are
-  // out of phase with each other anyway: -1 %).  pf_config::stagger_levels overrides.
-  const int stagger = c->cfg.stagger_levels >= 0 ? c->cfg.stagger_levels : (c->is_lane ? 0 : (size_t(g.w0) * g.h0 >= 5000000 ? 4 : 2));
+  // out of phase with each other anyway: -1 %).  Re-measured in round 5 (tests/micro/stagger_ab.py): dense pair k = 0 / 2 / 3 / 4 / 6:
+  // 48.30 / 47.46 / 47.31 / 47.45 / 48.10 ms, strip k = 0 / 2 / 3 / 4: 22.37 / 22.28 / 22.45 / 22.65.  pf_config::stagger_levels overrides.
+  const int stagger = c->cfg.stagger_levels >= 0 ? c->cfg.stagger_levels : (c->is_lane ? 0 : (size_t(g.w0) * g.h0 >= 5000000 ? 3 : 2));
   if (stagger > 0 && ndirs == 2 && g.n > 1) {
     const int k = stagger < g.n ? stagger : g.n - 1;
     for (int t = 0; t < g.n + k; ++t) {
