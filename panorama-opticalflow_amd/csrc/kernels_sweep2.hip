@@ -226,11 +226,11 @@ __device__ __forceinline__ float dpp_shl0(float src) {
 // band then touch the same ~31 ring slots although their pixels are 32 columns apart (a ring of 64 serves; unskewed it would take 128).
 // Moving one window row down also moves one slot on, and the first TWO ring columns are stored again behind column 63 (kWCPT).
 // FOLLOW: the window is a torus addressed by the texel's absolute coordinates and centred by its loader on the pixel + an integer offset pc
-// (the rounded blurred flow of the chunk, kept with the record): resident are the texels within 8 of the centre in both axes, so the test is on
+// (the rounded blurred flow of the chunk; the offset is kept with the record): resident are the texels within 8 of the centre in both axes, so the test is on
 // the flow against pc -- a flow of any size within 7 of the offset is served from LDS.  A pixel that is not updated carries pc = NaN: its (discarded) evaluations never
 // send the wave through the HBM path -- they read a valid LDS slot with whatever it holds ("not > 7" is true for a NaN distance).
-// FOLLOW = 2 (throughput form): the same torus in skewed coordinates -- ring row = the texel's row mod kWA (52; `ob` = a multiple of 52 chosen by
-// the loader per chunk so that the chunk's rows fall in [ob, ob + 104): one conditional subtraction), ring column = (u + v) & 63; pc = the
+// FOLLOW = 2 (throughput form): the same torus in skewed coordinates -- ring row = the texel's row mod kWA (tRV = 48; `ob` = a multiple of 48 chosen by
+// the loader per chunk so that the chunk's rows fall in [ob, ob + 96): one conditional subtraction, as v_min3_u32), ring column = (u + v) & 63; pc = the
 // chunk's OFFSET (wave-uniform, image axes) and the test is on the flow relative to it, |fd - pc| <= kRadT - 1 = 5 (the window holds [centre - 6,
 // centre + 6], so a difference that rounds onto +-5 is covered; centres are kept inside the image by the loader); `live` = the pixel is
 // updated -- one that is not never sends the wave to HBM.
@@ -260,7 +260,7 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
     // texel, and the window holds one texel more than the test admits on either side ([centre - 8, centre + 8]): a difference that rounds onto
     // +-7 is covered.
     const f2p dm = fd - pc;
-    inwin = !(__builtin_fmaxf(fabsf(dm.x), fabsf(dm.y)) > float(kRad - 1));   // (NaN centre = a pixel that is not updated: "inside")
+    inwin = !(__builtin_fmaxf(fabsf(dm.x), fabsf(dm.y)) > float(kRad - 1));   // (NaN offset = a pixel that is not updated: "inside")
   } else inwin = __builtin_fmaxf(fabsf(fdx), fabsf(fdy)) <= float(kRad - 1);
   // sweep-order coordinates of texel (x0,y0): u along the step axis, v across the bands
   // The 2x2 footprint in sweep order is (v0, v0 + sg) x (u0, u0 + sg), sg = +1 forward / -1 backward.  Addressed from its LOWER
@@ -1219,7 +1219,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
     const int lj = lane >> 3, lr = lane & 7;
     const int lib = (bandLo + band0 + w) * kRows + lr;       // position across the bands (absolute)
     // record stream: lane i of a chunk's three loads holds quads i, i + 64, i + 128 of its 192; quad q is part q % 3 of record q / 3 -- the
-    // third part (x, y, -, -) gets the window centre (x + ox, y + oy) in z / w
+    // third part (x, y, -, -) gets the window OFFSET (ox, oy) in z / w
     bool isC[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) isC[k] = (lane + 64 * k) % 3 == 2;
