@@ -103,4 +103,31 @@ __device__ __forceinline__ f2p sqrt_core2(f2p x, int& exp_x0) {
   return out;
 #endif
 }
+// Sum of the squares of a packed difference, (a - b).x^2 + (a - b).y^2, as ONE block: subtraction, product, and the sum of the product's two halves as a
+// packed add that reads it with swapped halves (lo = x^2 + y^2, hi = y^2 + x^2: the same addition as the scalar v_add_f32 of the two halves).  Three
+// instructions as before, but no wait state between them (round 5, tests/micro/nop_cost.hip: an s_nop costs a lone wave 4 cycles -- as much as an instruction).
+__device__ __forceinline__ float sumsq_diff2(f2p a, f2p b) {
+#if PF_PK_ASM
+  f2p r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_mul_f32 %0, %0, %0\n\tv_pk_add_f32 %0, %0, %0 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(r) : "v"(a), "v"(b));
+  return r.x;
+#else
+  const f2p d = a - b, d2 = d * d;
+  return d2.x + d2.y;
+#endif
+}
+__device__ __forceinline__ float sumsq_diff2_safe(f2p a, f2p b) { const f2p d = a - b, d2 = d * d; return d2.x + d2.y; }
+// The same with the subtrahend still to be summed: (a - (p + l)).x^2 + (a - (p + l)).y^2 -- the bilinear sample's last addition rides in the block.
+__device__ __forceinline__ float sumsq_diff2_sum(f2p a, f2p p, f2p l) {
+#if PF_PK_ASM
+  f2p r;
+  asm("v_pk_add_f32 %0, %2, %3\n\tv_pk_add_f32 %0, %1, %0 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_mul_f32 %0, %0, %0\n\tv_pk_add_f32 %0, %0, %0 op_sel:[0,1] op_sel_hi:[1,0]"
+      : "=&v"(r) : "v"(a), "v"(p), "v"(l));
+  return r.x;
+#else
+  const f2p d = a - (p + l), d2 = d * d;
+  return d2.x + d2.y;
+#endif
+}
+__device__ __forceinline__ float sumsq_diff2_sum_safe(f2p a, f2p p, f2p l) { const f2p d = a - (p + l), d2 = d * d; return d2.x + d2.y; }
 }  // namespace pf

@@ -111,6 +111,12 @@ constexpr int kWCp = kWC + PF_WCP_EXTRA; // row stride of the window: ring colum
 #define PF_DRAIN_CHUNK 1  // 1: the drainer writes whole 8-step chunks instead of whatever has been produced
 #endif
 #ifndef PF_SELF_PUBLISH
+#ifndef PF_TF_ADDR_ASM
+#define PF_TF_ADDR_ASM 0   // throughput form: the window address as one three-instruction block (latency form: always)
+#endif
+#ifndef PF_TF_SUMSQ_ASM
+#define PF_TF_SUMSQ_ASM 0  // throughput form: the two sum-of-squares chains as single blocks (latency form: always)
+#endif
 #define PF_SELF_PUBLISH 0 // 1: the last compute wave of a workgroup stores its hand-off granules itself (experiment: measured, slower, see compute_band)
 #endif
 #ifndef PF_DRAIN_SLEEP
@@ -284,21 +290,34 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   typedef __attribute__((address_space(3))) const f2v lds_f2;
   // explicit LDS address space: ds_read2_b64, never a flat access.  The corner's byte address as (ring column << 3) + window, then
   // + row * stride in one 24-bit multiply-add: five instructions from (x0, y0) to the address.
-  unsigned ringCol = unsigned((SKEW ? ulo + (FOLLOW == 2 ? vlo : alo) : ulo) & (kWC - 1));
-  asm("" : "+v"(ringCol));   // (x & 63) << 3 + base as v_and + v_lshl_add, not the canonical v_lshl + v_and + v_add
-  const unsigned cornerCol = (ringCol << 3) + (unsigned)(size_t)win;
-  unsigned cornerAddr;   // = alo * row stride + cornerCol; written out because the compiler turns it into v_mul_u32_u24 + v_add3_u32 (one more)
-  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(cornerAddr) : "v"(alo), "s"(unsigned(WCP * sizeof(float2))), "v"(cornerCol));
+  // = ((column & 63) << 3) + window base + alo * row stride.  Written out as ONE block of three instructions (round 5): the compiler's own form is
+  // v_lshl + v_and + v_add + v_mul_u32_u24 + v_add3 (two more), and pinning single instructions with asm statements costs an s_nop behind each
+  // statement whose result the next instruction reads (4 cycles for a lone wave: as much as the instruction saved).
+  const unsigned colSum = unsigned(SKEW ? ulo + (FOLLOW == 2 ? vlo : alo) : ulo);
+  unsigned cornerAddr;
+  if (!SKEW || PF_TF_ADDR_ASM) {
+    asm("v_and_b32 %0, %5, %1\n\tv_lshl_add_u32 %0, %0, 3, %2\n\tv_mad_u32_u24 %0, %3, %4, %0"
+        : "=&v"(cornerAddr) : "v"(colSum), "s"((unsigned)(size_t)win), "v"(alo), "s"(unsigned(WCP * sizeof(float2))), "n"(kWC - 1));
+  } else {
+    unsigned ringCol = colSum & (kWC - 1);
+    asm("" : "+v"(ringCol));   // (x & 63) << 3 + base as v_and + v_lshl_add, not the canonical v_lshl + v_and + v_add
+    const unsigned cornerCol = (ringCol << 3) + (unsigned)(size_t)win;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(cornerAddr) : "v"(alo), "s"(unsigned(WCP * sizeof(float2))), "v"(cornerCol));
+  }
   lds_f2* win3 = (lds_f2*)(size_t)cornerAddr;
   const f2v w00 = win3[o00], w10 = win3[o10], w01 = win3[o01], w11 = win3[o11];
   float2 t00 = make_float2(w00.x, w00.y), t10 = make_float2(w10.x, w10.y), t01 = make_float2(w01.x, w01.y), t11 = make_float2(w11.x, w11.y);
   __builtin_amdgcn_sched_barrier(0);
   // ---- B ----
   const float xR = __builtin_amdgcn_fractf(cx), yR = __builtin_amdgcn_fractf(cy);   // cx, cy >= 0: exactly cx - float(int(cx))
-  const f2p df = f2p{bx, by} - fd;
-  const f2p df2 = df * df;
-  float s2 = df2.x + df2.y;
-  asm volatile("" : "+v"(s2));   // a finished scalar here: otherwise the SLP vectoriser packs this add with d2's below behind two register moves (3 instructions for 2)
+  float s2;
+  if (PF_PK_ASM && (!SKEW || PF_TF_SUMSQ_ASM)) s2 = sumsq_diff2(f2p{bx, by}, fd);   // |blurred - flow|^2: one block (exact_forms.hpp)
+  else {
+    const f2p df = f2p{bx, by} - fd;
+    const f2p df2 = df * df;
+    s2 = df2.x + df2.y;
+    asm volatile("" : "+v"(s2));   // a finished scalar here: otherwise the SLP vectoriser packs this add with d2's below behind two register moves (3 instructions for 2)
+  }
   float av = kVerticalRegularizationCoef * fabsf(fdy);
   asm volatile("" : "+v"(av));   // keeps the two products scalar (|x| is a free source modifier there); packed, they need two v_and for the abs: 3 instructions for 2
   const float ah = kHorizontalRegularizationCoef * fabsf(fdx);
@@ -324,25 +343,32 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   }
   __builtin_amdgcn_sched_barrier(0);
   // ---- C ----
-  float i1x, i1y;
+  // i1 = a1 + a2 * xR + a3 * yR + a4 * xR * yR per channel, left to right: the last addition (p + l) is made inside the block that also takes
+  // the difference to I0, its square and the sum of the two channels (exact_forms.hpp: no wait states between the four)
+  float px, py, lx, ly;
   {
     const float f00 = t00.x, f10 = t10.x, f01 = t01.x, f11 = t11.x;
     const float a1 = f00, a2 = f10 - f00, a3 = f01 - f00, a4 = f00 + f11 - f10 - f01;
-    i1x = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
+    px = a1 + a2 * xR + a3 * yR; lx = a4 * xR * yR;
   }
   {
     const float f00 = t00.y, f10 = t10.y, f01 = t01.y, f11 = t11.y;
     const float a1 = f00, a2 = f10 - f00, a3 = f01 - f00, a4 = f00 + f11 - f10 - f01;
-    i1y = a1 + a2 * xR + a3 * yR + a4 * xR * yR;
+    py = a1 + a2 * xR + a3 * yR; ly = a4 * xR * yR;
   }
-  f2p di, di2;   // (i0 - i1)^2 per channel: one asm block, see exact_forms.hpp
+  float d2;
+  if (PF_PK_ASM && (!SKEW || PF_TF_SUMSQ_ASM)) d2 = sumsq_diff2_sum(f2p{i0x, i0y}, f2p{px, py}, f2p{lx, ly});
+  else {
+    const float i1x = px + lx, i1y = py + ly;
+    f2p di, di2;   // (i0 - i1)^2 per channel: one asm block, see exact_forms.hpp
 #if PF_PK_ASM
-  asm("v_pk_add_f32 %0, %2, %3 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_mul_f32 %1, %0, %0" : "=&v"(di), "=&v"(di2) : "v"(f2p{i0x, i0y}), "v"(f2p{i1x, i1y}));
+    asm("v_pk_add_f32 %0, %2, %3 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_mul_f32 %1, %0, %0" : "=&v"(di), "=&v"(di2) : "v"(f2p{i0x, i0y}), "v"(f2p{i1x, i1y}));
 #else
-  di = f2p{i0x, i0y} - f2p{i1x, i1y}; di2 = di * di;
+    di = f2p{i0x, i0y} - f2p{i1x, i1y}; di2 = di * di;
 #endif
-  float d2 = di2.x + di2.y;
-  asm volatile("" : "+v"(d2));   // a scalar add into the register next to s2 (not a packed add + a move of s2)
+    d2 = di2.x + di2.y;
+    asm volatile("" : "+v"(d2));   // a scalar add into the register next to s2 (not a packed add + a move of s2)
+  }
   vmax = __builtin_fmaxf(vmax, d2);
   int ed2;
   const f2p sq = sqrt_core2(f2p{d2, s2}, ed2);   // both square roots of the step as one packed sequence (+ d2's exponent for the guard)
@@ -1535,8 +1561,12 @@ __global__ __launch_bounds__(1024) void k_pk_probe(int rounds, unsigned* __restr
     di = f2p{c, q.x} - f2p{q.y, d}; di2 = di * di;
 #endif
     const f2p ds = f2p{c, qs.x} - f2p{qs.y, d}, ds2 = ds * ds;
+    // the step's two sum-of-squares blocks (round 5), fed with results that are one instruction old
+    const float u0 = sumsq_diff2(f2p{c, q.x}, f2p{q.y, d}), u1 = sumsq_diff2_safe(f2p{c, qs.x}, f2p{qs.y, d});
+    const float w0 = sumsq_diff2_sum(f2p{c, d}, f2p{q.x, q.y}, di2), w1 = sumsq_diff2_sum_safe(f2p{c, d}, f2p{qs.x, qs.y}, ds2);
     diff |= (__float_as_uint(q.x) ^ __float_as_uint(qs.x)) | (__float_as_uint(q.y) ^ __float_as_uint(qs.y)) | unsigned(e0 ^ e1) |
-            (__float_as_uint(di2.x) ^ __float_as_uint(ds2.x)) | (__float_as_uint(di2.y) ^ __float_as_uint(ds2.y));
+            (__float_as_uint(di2.x) ^ __float_as_uint(ds2.x)) | (__float_as_uint(di2.y) ^ __float_as_uint(ds2.y)) |
+            (__float_as_uint(u0) ^ __float_as_uint(u1)) | (__float_as_uint(w0) ^ __float_as_uint(w1));
     // the next operands depend on this round's results (a dependent chain, like a sweep step), folded back into the guard's range
     const unsigned ua = __float_as_uint(di2.x), ub = __float_as_uint(q.y);
     a = __uint_as_float((ua & 0x007fffffu) | ((37u + ((ua >> 23) & 0xffu) % 180u) << 23));
