@@ -44,7 +44,7 @@ LAT_LONE = {         # result latency: issue -> a dependent instruction may issu
     "salu": 4,
     "readlane": 7,   # v_readfirstlane -> v_mov from the SGPR pair 13.25
 }
-ISSUE_LONE = {"valu": 5.5, "pk": 6.75, "trans": 8, "dpp": 7.5, "cmp": 5.5, "salu": 4, "readlane": 5.5, "nop": 1, "branch": 2, "wait": 1}   # 4 independent chains: per instruction
+ISSUE_LONE = {"valu": 5.5, "pk": 6.75, "trans": 8, "dpp": 7.5, "cmp": 5.5, "salu": 4, "readlane": 5.5, "nop": 4, "branch": 2, "wait": 1}   # 4 independent chains: per instruction; s_nop 0: 4 cycles (tests/micro/nop_cost.hip, round 5)
 LAT_GUIDE = {"valu": 4, "pk": 4, "trans": 16, "dpp": 11, "cmp": 7, "ds_read": 50, "salu": 4, "readlane": 8}
 ISSUE_GUIDE = {"valu": 2, "pk": 2, "trans": 8, "dpp": 2, "cmp": 2, "salu": 2, "readlane": 2, "nop": 1, "branch": 2, "wait": 1}
 LAT = dict(LAT_LONE)
