@@ -97,12 +97,17 @@ constexpr int kWCp = kWC + PF_WCP_EXTRA; // row stride of the window: ring colum
 #endif
 #ifndef PF_MARGIN
 #ifndef PF_MARGIN_X
-#define PF_MARGIN_X 1
+#define PF_MARGIN_X 0
+#endif
+#ifndef PF_MARGIN_TX
+#define PF_MARGIN_TX 1   // the throughput form's margin across workgroups
 #endif
 #ifndef PF_MARGIN_IN
 #define PF_MARGIN_IN 0
 #endif
-#define PF_MARGIN(top) ((top) == 2 ? PF_MARGIN_X : PF_MARGIN_IN)   // extra columns to fall behind after catching up with the producer (measured: 0 inside a workgroup, 1 across)
+#define PF_MARGIN(top) ((top) == 2 ? PF_MARGIN_X : PF_MARGIN_IN)   // extra columns to fall behind after catching up with the producer (measured: 0 inside a workgroup; across
+                                                                  // workgroups 1 until round 4, 0 since the window follows the flow: dense pair 46.75 -> 46.4 ms, strip 22.13 -> 22.02)
+#define PF_MARGIN_T(top) ((top) == 2 ? PF_MARGIN_TX : PF_MARGIN_IN)
 #endif
 #ifndef PF_LOADER_IDLE
 #define PF_LOADER_IDLE 8  // > 0: the loader's ring-full iteration is a short s_sleep of this length instead of a pass through its predicated-off body
@@ -110,13 +115,13 @@ constexpr int kWCp = kWC + PF_WCP_EXTRA; // row stride of the window: ring colum
 #ifndef PF_DRAIN_CHUNK
 #define PF_DRAIN_CHUNK 1  // 1: the drainer writes whole 8-step chunks instead of whatever has been produced
 #endif
-#ifndef PF_SELF_PUBLISH
 #ifndef PF_TF_ADDR_ASM
 #define PF_TF_ADDR_ASM 0   // throughput form: the window address as one three-instruction block (latency form: always)
 #endif
 #ifndef PF_TF_SUMSQ_ASM
 #define PF_TF_SUMSQ_ASM 0  // throughput form: the two sum-of-squares chains as single blocks (latency form: always)
 #endif
+#ifndef PF_SELF_PUBLISH
 #define PF_SELF_PUBLISH 0 // 1: the last compute wave of a workgroup stores its hand-off granules itself (experiment: measured, slower, see compute_band)
 #endif
 #ifndef PF_DRAIN_SLEEP

@@ -216,7 +216,7 @@ __device__ __forceinline__ bool compute_band_t(SmemTF& sm, const float2* __restr
       if (TOP != 0) {
         if (__builtin_expect(waitTop, 0)) {
           if (!dead && s < LSv) {
-            const int need = (s + 1 + PF_MARGIN(TOP) < LSv) ? s + 1 + PF_MARGIN(TOP) : LSv;
+            const int need = (s + 1 + PF_MARGIN_T(TOP) < LSv) ? s + 1 + PF_MARGIN_T(TOP) : LSv;
             int spins = 0;
             for (;;) {
               const int avail = __builtin_amdgcn_readfirstlane(ld_cnt(topHead)) - kBias;
