@@ -80,6 +80,12 @@ struct SwGeom {
 };
 using SwLatency = SwGeom<4, 1>;
 using SwWide = SwGeom<8, 2>;
+#ifndef PF_PRIO_C
+#define PF_PRIO_C 3   // s_setprio of the compute waves / of the helper waves (above another kernel's waves on the same CU)
+#endif
+#ifndef PF_PRIO_H
+#define PF_PRIO_H 1
+#endif
 #ifndef PF_WCP_EXTRA
 #define PF_WCP_EXTRA 3
 #endif
@@ -1130,7 +1136,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
   if (wave < kWaves) {
     // ======================= compute wave: band of 8 rows =======================
     if (wave >= nact) return;
-    __builtin_amdgcn_s_setprio(3);   // the helper waves share SIMDs with compute waves: compute wins issue arbitration
+    __builtin_amdgcn_s_setprio(PF_PRIO_C);   // the helper waves share SIMDs with compute waves: compute wins issue arbitration
 #ifdef PF_SWEEP_STATS
     sm.statEntry = tEntry;
 #endif
@@ -1149,7 +1155,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
 
   // helper waves: below the compute waves (3), above another kernel's waves that share this CU -- since the two directions run
   // out of phase, the other direction's Gaussians / medians / prepass sit on the sweep's SIMDs (strip -0.12 ms, 9000x4000 pair -0.4 ms)
-  __builtin_amdgcn_s_setprio(1);
+  __builtin_amdgcn_s_setprio(PF_PRIO_H);
   if constexpr (G::kBPW == 2) {
     if (wave >= kWaves && wave < kWaves + kLoaders) {
       sweep_loader_pair<G, TR, FWD>(sm, rec, g1, ctrl, W, H, nsteps, nstepsPad, wave - kWaves, nact, band0, bandLo, uLo, LSv);
