@@ -1,3 +1,5 @@
+#!/bin/bash
+# same-box A/B of library variants var_libs/lib_ab_<name>.so: lone 2000x4000 strip and the x8-displacement dense pair: strip_ab.sh names...
 cd $GRAFT_REPO_ROOT
 export GPU_MAX_HW_QUEUES=24
 cp panorama-opticalflow_amd/libpanoflow.so /tmp/lib_orig.so

@@ -1,3 +1,5 @@
+#!/bin/bash
+# same-box A/B of library variants var_libs/lib_ab_<name>.so: throughput-form sweep alone + dense pairs 8 / 32 in flight: tf_ab.sh names...
 cd $GRAFT_REPO_ROOT
 export GPU_MAX_HW_QUEUES=32 TP_LOOPS=3
 cp panorama-opticalflow_amd/libpanoflow.so /tmp/lib_orig.so
