@@ -63,3 +63,23 @@ def test_throughput_form_hot_loop_has_one_record_request_per_step(asm):
                 waits = [l for l in lines[a + 1:b] if l.startswith("s_waitcnt") and "vmcnt" in l]
                 assert waits and all("vmcnt(5)" in w for w in waits), (name, waits)   # the hand-counted wait, and no compiler-inserted vmcnt(0)
         assert steps == 3 * 7, (name, steps)
+
+
+def test_latency_form_step_keeps_its_wait_states_down(asm):
+    """Round 5: for a lone wave an s_nop costs 4 cycles -- as much as an instruction (tests/micro/nop_cost.hip) -- and the step is issue-bound.
+    hipcc put 8 into every step; the window-address block and the two sum-of-squares blocks (csrc/exact_forms.hpp) took three out.  A compiler or
+    source change that brings them back costs ~2 % of every sweep without failing any parity test: caught here.  (Dense, not transposed, forward.)"""
+    names = [n for n in _kernels(asm, "k_sweep2") if "SwGeomILi4ELi1EEELb0ELb1ELb0ELi0" in n]
+    assert len(names) == 1, names
+    body = asm[asm.index("\n" + names[0] + ":"):]
+    body = body[:body.index("\n.Lfunc_end")]      # (the kernel has several s_endpgm: one per wave role)
+    lines = [l.strip() for l in body.splitlines() if l.strip() and not l.strip().startswith((";", ".")) and not l.strip().endswith(":")]
+    # a step starts at its first `row_newbcast:0` DPP move (two per step: x and y of the proposal)
+    starts = [i for i, l in enumerate(lines) if "row_newbcast:0" in l and (i == 0 or "row_newbcast:0" not in lines[i - 1])]
+    steps = [(a, b) for a, b in zip(starts, starts[1:]) if 100 <= b - a <= 140]     # consecutive steps of the unrolled chunks (a step is ~119 instructions)
+    assert len(steps) >= 3 * 7, len(steps)                                          # three compute_band<TOP> instances x seven whole steps
+    nops = [sum(1 for l in lines[a:b] if l.startswith("s_nop")) for a, b in steps]
+    assert max(nops) <= 7 and sum(nops) / len(nops) <= 6.0, nops     # (5-7 today, 5.7 on average over the three loop instances; the profiled instance had 8 before the blocks)
+    # and the blocks are there: one packed add per block that reads its operand with swapped halves
+    swaps = [sum(1 for l in lines[a:b] if l.startswith("v_pk_add_f32") and "op_sel:[0,1] op_sel_hi:[1,0]" in l) for a, b in steps]
+    assert min(swaps) == 2 and max(swaps) == 2, swaps
