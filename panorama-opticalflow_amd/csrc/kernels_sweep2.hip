@@ -21,11 +21,15 @@
 //     waves stream records and window texels HBM->LDS ahead of the wavefront, drain results LDS->HBM,
 //     publish the granules and poll the previous workgroup's granules, so the long-latency traffic sits in
 //     THEIR in-order memory queues, not in the compute waves'.
-//   * a lone wave issues one instruction every ~5.5 cycles here, so the step time is the instruction count
-//     (and, among equals, the length of the loop-carried chain): ~118 instructions per step (packed fp32
-//     math, exact cheap forms of sqrt and division -- exact_forms.hpp --, one range guard per step, no
-//     per-step address arithmetic that a loop-carried register or an immediate can replace, no LDS-order
-//     stalls).  DESIGN.md 3.4 has the history (154 -> 118) and profiles/r03_sweep_step_isa.txt the listing.
+//   * a lone wave issues one instruction every ~5 cycles here (independent 4.75, directly dependent 8.25, an s_nop 4.0:
+//     tests/micro/nop_cost.hip), so the step time is the instruction count (and, among equals, the length of the
+//     loop-carried chain): ~119 instructions per step (packed fp32 math, exact cheap forms of sqrt and division --
+//     exact_forms.hpp --, one range guard per step, no per-step address arithmetic that a loop-carried register or an
+//     immediate can replace, no LDS-order stalls, the serial packed chains and the window address as single instruction
+//     blocks without the compiler's wait states).  DESIGN.md 3.2-3.3 and docs/history.md have the history (154 -> 119),
+//     profiles/r05_sweep_step_isa.txt the listing.
+//   * the gather window in LDS follows the flow (round 5): centred per chunk of 8 steps on pixel + the rounded blurred
+//     flow, a torus addressed by absolute texel coordinates (the loader of k_sweep2 below).
 // Workgroups take their band index from an atomic ticket (a band only waits for bands already
 // running), every spin is bounded and raises ctrl[1] instead of hanging.
 #include <hip/hip_ext.h>
