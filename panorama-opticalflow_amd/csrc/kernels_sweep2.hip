@@ -873,7 +873,11 @@ __device__ __forceinline__ void d_make_record(size_t tid, size_t total, const fl
 // When the window does not start at the first band, the row above it never changes during this sweep: its flow
 // is written as the granule row the first workgroup's poller reads (top0).
 // ------------------------------------------------------------------------------------------------
-template <int ROWS, bool RC>
+// SOA (the product's latency form, round 5): the record stream holds TWO quads per record -- the third, (x, y, window offset), is a function of
+// the slot and of E(C)'s sign and is formed by the sweep's loader -- laid out per chunk of 8 steps x 8 rows as [64 first quads][64 second
+// quads]: a wave of this kernel IS one chunk, so its two stores are 1 KB runs without the LDS stage, and a loader lane reads its own record's
+// two quads with two coalesced loads.  32 instead of 48 bytes per record written here and read there (the prepass is bandwidth-bound at the large levels).
+template <int ROWS, bool RC, bool SOA = false>
 __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g0, const float2* __restrict__ g1, const float2* __restrict__ blurred,
                                                     const uint8_t* __restrict__ gate, const float2* __restrict__ flow, int W, int H, int forward,
                                                     int transposed, int nstepsPad, int nbandsPad, float rW, float4* __restrict__ rec, int uLo, int uHi,
@@ -903,9 +907,17 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
   // of 16-byte pieces at a 48-byte stride)
   // (throughput form: 32-byte records -- the step forms the pixel's coordinates itself, the record stream is what bounds this kernel there)
   constexpr int kQuads = RC ? 3 : 2;
-  __shared__ float4 stage[256 * kQuads];
   float4 a, b, c;
   d_make_record_at<ROWS, RC>(band, s, r, band < nbandsPad && s < nstepsPad, g0, g1, blurred, gate, flow, W, H, forward, transposed, rW, uLo, uHi, bandLo, a, b, c);
+  if (SOA) {
+    static_assert(!SOA || (ROWS == 8 && RC), "chunk layout of the latency form");
+    // float4 index in the band's stream: chunk * 128 + quad * 64 + (record in chunk); lt = 64 * (chunk in block) + (record in chunk)
+    const size_t bandBase2 = size_t(band) * nstepsPad * ROWS * 2;
+    const unsigned o = (unsigned(blockIdx.x) * 4u + (lt >> 6)) * 128u + (lt & 63u);
+    if (s < nstepsPad) { rec[bandBase2 + o] = a; rec[bandBase2 + o + 64u] = b; }   // (nstepsPad is a whole number of chunks; s is wave-uniform up to the chunk)
+    return;
+  }
+  __shared__ float4 stage[256 * kQuads];
   stage[lt * kQuads + 0] = a; stage[lt * kQuads + 1] = b;
   if (kQuads == 3) stage[lt * kQuads + 2] = c;
   __syncthreads();
@@ -1253,7 +1265,8 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
       ox = FWD ? sx : -sx; oy = FWD ? sy : -sy;
     };
     constexpr bool fused = MODE == 1;
-    const float4* recw = fused ? nullptr : rec + size_t(band0 + w) * nstepsPad * (kRows * 3);
+    constexpr bool soa = MODE == 0;   // the product's record stream: 32-byte records, [64 first quads][64 second quads] per chunk (k_sweep_prep<.., SOA>)
+    const float4* recw = fused ? nullptr : rec + size_t(band0 + w) * nstepsPad * (kRows * (soa ? 2 : 3));
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
     // fused prepass: this lane's slot inside a chunk is (step offset lane >> 3, row lane & 7)
@@ -1329,8 +1342,19 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
         for (int k = 0; k < 5; ++k) { wv[c][k] = make_float2(0.f, 0.f); wu[c][k] = 0; wvv[c][k] = 0; wok[c][k] = false; }
         if (ld[c]) {
           if (!fused) {
-            const float4* src = recw + size_t(r0) * (kRows * 3);
-            va[c] = src[lane]; vb4[c] = src[lane + 64]; vc[c] = src[lane + 128];
+            if (soa) {
+              const float4* src = recw + size_t(r0) * (kRows * 2);   // chunk r0 / 8: 128 quads
+              va[c] = src[lane]; vb4[c] = src[lane + 64];            // this lane's own record (step r0 + lane / 8, row lane % 8)
+              // its third quad: the pixel's coordinates (0, 0 for a slot without a pixel, as the prepass wrote them until round 5)
+              const int sstep = r0 + lj, ia = uLo + sstep - lr;
+              const bool inside = sstep - lr >= 0 && ia < uLo + LSv && ia < LS && lib < LB;
+              const int cxs = TR ? lib : ia, cys = TR ? ia : lib;   // position in sweep order
+              const int px = FWD ? cxs : W - 1 - cxs, py = FWD ? cys : H - 1 - cys;
+              vc[c] = make_float4(inside ? float(px) : 0.f, inside ? float(py) : 0.f, 0.f, 0.f);
+            } else {
+              const float4* src = recw + size_t(r0) * (kRows * 3);
+              va[c] = src[lane]; vb4[c] = src[lane + 64]; vc[c] = src[lane + 128];
+            }
           } else {
             const int sstep = r0 + lj, ia = uLo + sstep - lr;
             ia_of[c] = ia;
@@ -1414,7 +1438,13 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
       for (int c = 0; c < kLoadAhead; ++c) {
         if (ld[c]) {
           float4* dst = &sm.rec[w][rh % kRS][0][0];
-          if (!fused) {
+          if (!fused && soa) {
+            // "updated" is E(C) != kKeepEnergy (d_make_record_at): the window offset for such a pixel, NaN ("never leaves the window") otherwise
+            const bool on = vb4[c].x != kKeepEnergy;
+            float4 q2 = vc[c];
+            q2.z = on ? cox[c] : __builtin_nanf(""); q2.w = on ? coy[c] : __builtin_nanf("");
+            dst[3 * lane] = va[c]; dst[3 * lane + 1] = vb4[c]; dst[3 * lane + 2] = q2;
+          } else if (!fused) {
             float4 v3[3] = {va[c], vb4[c], vc[c]};
 #pragma unroll
             for (int k = 0; k < 3; ++k) if (isC[k]) { v3[k].z = cox[c] + v3[k].z; v3[k].w = coy[c] + v3[k].w; }   // the chunk's window offset (+ 0, or + NaN where the pixel is not updated)
@@ -1672,7 +1702,11 @@ static bool launch_sweep2_form(hipStream_t st, const SweepArgs& a, float* rec) {
 #else
   constexpr int mode = 0;
 #endif
-  if (mode == 0)
+  if (mode == 0 && G::kBPW == 1)
+    hipExtLaunchKernelGGL((k_sweep_prep<kRows, true, true>), dim3((unsigned)((nstepsPad + 256 / kRows - 1) / (256 / kRows)), (unsigned)nbandsPad, a.bt.n), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate, a.flow,
+                          a.W, a.H, a.forward, tr, nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo,
+                          bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride);
+  else if (mode == 0)
     hipExtLaunchKernelGGL((k_sweep_prep<kRows, true>), dim3((unsigned)((nstepsPad + 256 / kRows - 1) / (256 / kRows)), (unsigned)nbandsPad, a.bt.n), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate, a.flow,
                           a.W, a.H, a.forward, tr, nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo,
                           bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride);
