@@ -4,7 +4,7 @@
 // the time of ONE step instead of bytes moved:
 //   * 8 lanes per pixel.  Everything about a pixel that does not depend on its neighbours -- E(C) and
 //     the gradient step its own incoming flow C would take, rC -- is computed by a fully parallel prepass
-//     (k_sweep_prep) which also packs the static per-pixel inputs into 48-byte records laid out in the
+//     (k_sweep_prep) which also packs the static per-pixel inputs into records (32 bytes in memory, 48 in LDS) laid out in the
 //     order the wavefront consumes them.  In the sequential kernel six lanes evaluate
 //     E(L), E(L+dx), E(L+dy), E(T), E(T+dx), E(T+dy) for the two proposals (L = previous column,
 //     T = previous row) AT THE SAME TIME: one gather round per step instead of five dependent ones --
@@ -68,7 +68,7 @@ struct SwGeom {
   static constexpr int kBPW = BPW;               // adjacent bands that share one gather window and one loader wave
   static constexpr int kLoaders = NW / BPW;
   static constexpr int kRS = BPW == 1 ? 32 : 24; // record ring (steps)
-  static constexpr int kRQ = BPW == 1 ? 3 : 2;   // float4 quads per record in the LDS ring: the 48-byte record as it is in memory, or -- wide form, where
+  static constexpr int kRQ = BPW == 1 ? 3 : 2;   // float4 quads per record in the LDS ring: two quads from memory + (x, y, window offset) formed by the loader, or -- wide form, where
                                                  // LDS is what limits the rings -- its first two quads, the (x, y) of the third in a ring of its own (40 bytes)
   static constexpr int kLoadAhead = BPW == 1 ? 3 : 1;   // chunks per band the loader fetches in one round when the ring has room
   static constexpr int kOS = 32;                 // result ring (steps)
@@ -861,7 +861,8 @@ __device__ __forceinline__ void d_make_record(size_t tid, size_t total, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
-// prepass: records in wavefront order.  rec[((band*nstepsPad + s)*8 + r)*3 + j] for the ACTIVE window of the sweep:
+// prepass: records in wavefront order for the ACTIVE window of the sweep -- the product's latency form (SOA): per band and chunk of 8 steps
+// [64 first quads][64 second quads], record (s % 8) * 8 + r; the lab forms: rec[((band*nstepsPad + s)*8 + r)*3 + j] with the third quad (x, y, -, -):
 // band counts from bandLo, step s handles sweep-order column uLo + s - r (columns [uLo, uHi)).
 //   j=0: (I0x, I0y, blurred.x, blurred.y)   j=1: (E(C), rC.x, rC.y, Ea)   j=2: (x, y, -, -)     (the step reads 16 + 16 + 8 bytes)
 //   rC = C after its own gradient step, C - 0.5 * ((E(C+dx), E(C+dy)) - E(C)) / eps (IEEE operations: what the sweep's exact fast
