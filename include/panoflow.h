@@ -92,7 +92,7 @@ const char* pf_last_error(const pf_ctx* ctx);  /* ctx may be NULL (creation erro
  * Today there is one: a call that drives more HIP streams than the HIP runtime has hardware queues (pf_novel_view_batch_dev needs
  * 3 x lanes + 2, pf_stitch_step 5; the runtime sizes its pool from GPU_MAX_HW_QUEUES -- default 4 -- when the process makes its first
  * HIP call) runs correctly but with streams sharing queues.  The library reads GPU_MAX_HW_QUEUES only to report this; it reads no
- * other environment variable.  pf_profile_get lists the count as an entry named "warnings". */
+ * other environment variable (once per process).  A context raises the warning once per condition, not once per call. */
 const char* pf_last_warning(const pf_ctx* ctx);
 int pf_warning_count(const pf_ctx* ctx);
 const char* pf_version(void);
@@ -100,6 +100,27 @@ const char* pf_version(void);
 /* makeOpticalFlowByName, CPU/PixFlow.hpp:459-500: "pixflow_low" -> 0, "pixflow_search_20" -> 20,
  * anything else -> PF_ERR_ARG (the reference throws VrCamException). */
 int pf_max_percentage_by_name(const char* flow_alg_name);
+
+/* The constructor arguments of the reference's PixFlow<P> (CPU/PixFlow.hpp:46-68).  Its factory only ever passes the values
+ * pf_solver_params_init() fills in (:459-497, both presets), but the class accepts any: so does this library (round 6).  The
+ * parameters belong to the context and apply to every later solve on it (pf_flow*, pf_novel_view*, pf_stitch_step, the lanes of
+ * pf_novel_view_batch_dev).  Results are bit-identical to the reference's arithmetic for every accepted set.
+ *   pyr_scale_factor  in [0.25, 0.98]: level sizes int(w * s + 0.5f) while both > 24 (:137-151), inter-level flow scale 1.0f / s (:124);
+ *                     at most 96 levels (PF_ERR_ARG from the solve otherwise);
+ *   smoothness_coef, vertical_/horizontal_regularization_coef: finite and >= 0 (errorFunction :450-453; a negative coefficient could
+ *                     make an energy negative, which the sweep's "keep" sentinel excludes);
+ *   gradient_step_size: finite and >= 0 (:321,334).  A power of two in [2^-16, 2^16] (the presets' 0.5 is one) runs at full speed; any
+ *                     other value is computed with the IEEE multiply + subtract in every step of the sweeps (same bits as the reference,
+ *                     about 2-3x the sweep time);
+ *   downscale_factor: must be 0.5 (the 8-bit half-resolution path, :81-83, is built for it): anything else is PF_ERR_ARG;
+ *   directional_regularization_coef: stored and ignored, as in the reference (no code there reads it). */
+typedef struct pf_solver_params {
+  float pyr_scale_factor, smoothness_coef, vertical_regularization_coef, horizontal_regularization_coef, gradient_step_size, downscale_factor,
+      directional_regularization_coef;
+} pf_solver_params;
+void pf_solver_params_init(pf_solver_params* p);   /* 0.9, 0.001, 0.01, 0.01, 0.5, 0.5, 0 */
+int pf_set_solver_params(pf_ctx* ctx, const pf_solver_params* p);   /* p == NULL: back to the presets */
+int pf_get_solver_params(const pf_ctx* ctx, pf_solver_params* out);
 
 /* ---- host-buffer entry points (the drop-in boundary) --------------------------------------- */
 

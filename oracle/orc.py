@@ -128,6 +128,17 @@ def preprocess(bgra):
     return I, A
 
 
+def set_params(pyr_scale=0.9, smoothness=0.001, vreg=0.01, hreg=0.01, step=0.5):
+    """PixFlow's constructor arguments (CPU/PixFlow.hpp:46-68) for every later solver call of this process; reset_params() = the factory's presets."""
+    l = lib()
+    l.orc_set_params.argtypes = [C.c_float] * 5
+    l.orc_set_params(pyr_scale, smoothness, vreg, hreg, step)
+
+
+def reset_params():
+    lib().orc_reset_params()
+
+
 def pyr_down(src, dw, dh):
     return resize_linear_f32(src, dw, dh)
 

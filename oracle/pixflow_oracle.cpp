@@ -801,7 +801,10 @@ struct Stitch {
 
 static ImgU8 wrapU8(const uint8_t* p, int w, int h, int c) { ImgU8 i(w, h, c); std::memcpy(i.d.data(), p, i.d.size()); return i; }
 static ImgF wrapF(const float* p, int w, int h, int c) { ImgF i(w, h, c); std::memcpy(i.d.data(), p, i.d.size() * 4); return i; }
-static Params mkParams(int maxPct) { Params p; p.maxPercentage = maxPct; return p; }
+// PixFlow's constructor arguments (PixFlow.hpp:46-68): the factory's presets unless a test set others (orc_set_params; process-wide,
+// set between calls only -- the parity tests of pf_set_solver_params are the one user)
+static Params g_params;
+static Params mkParams(int maxPct) { Params p = g_params; p.maxPercentage = maxPct; return p; }
 
 }  // namespace orc
 
@@ -837,8 +840,15 @@ void orc_gradients(const float* I, int w, int h, float* Ix, float* Iy) {
   ImgF s = wrapF(I, w, h, 1), a, b; gradients(s, a, b);
   std::memcpy(Ix, a.d.data(), a.d.size() * 4); std::memcpy(Iy, b.d.data(), b.d.size() * 4);
 }
+// PixFlow(pyrScaleFactor, smoothnessCoef, verticalRegularizationCoef, horizontalRegularizationCoef, gradientStepSize, ...) -- PixFlow.hpp:54-68;
+// downscaleFactor stays 0.5 (the GPU path supports nothing else), directionalRegularizationCoef is read by no code of the reference
+void orc_set_params(float pyrScaleFactor, float smoothnessCoef, float verticalRegularizationCoef, float horizontalRegularizationCoef, float gradientStepSize) {
+  g_params.pyrScaleFactor = pyrScaleFactor; g_params.smoothnessCoef = smoothnessCoef; g_params.verticalRegularizationCoef = verticalRegularizationCoef;
+  g_params.horizontalRegularizationCoef = horizontalRegularizationCoef; g_params.gradientStepSize = gradientStepSize;
+}
+void orc_reset_params() { g_params = Params(); }
 int orc_pyramid_sizes(int w0, int h0, int* ws, int* hs, int cap) {
-  std::vector<int> a, b; pyramid_sizes(w0, h0, 0.9f, a, b);
+  std::vector<int> a, b; pyramid_sizes(w0, h0, g_params.pyrScaleFactor, a, b);
   for (int i = 0; i < (int)a.size() && i < cap; ++i) { ws[i] = a[i]; hs[i] = b[i]; }
   return (int)a.size();
 }
@@ -855,7 +865,7 @@ void orc_sweep(const float* I0x, const float* I0y, const float* I1x, const float
                const float* a1, float* flow, int w, int h, int forward) {
   ImgF i0x = wrapF(I0x, w, h, 1), i0y = wrapF(I0y, w, h, 1), i1x = wrapF(I1x, w, h, 1), i1y = wrapF(I1y, w, h, 1),
        bl = wrapF(blurred, w, h, 2), A0 = wrapF(a0, w, h, 1), A1 = wrapF(a1, w, h, 1), f = wrapF(flow, w, h, 2);
-  Params p; LevelCtx L{&i0x, &i0y, &i1x, &i1y, &bl, &p, w};
+  Params p = g_params; LevelCtx L{&i0x, &i0y, &i1x, &i1y, &bl, &p, w};
   sweep(L, A0, A1, f, forward != 0);
   std::memcpy(flow, f.d.data(), f.d.size() * 4);
 }
@@ -863,7 +873,7 @@ void orc_sweep(const float* I0x, const float* I0y, const float* I1x, const float
 void orc_error_function(const float* I0x, const float* I0y, const float* I1x, const float* I1y, const float* blurred, int w, int h,
                         const float* cand, float* err) {
   ImgF i0x = wrapF(I0x, w, h, 1), i0y = wrapF(I0y, w, h, 1), i1x = wrapF(I1x, w, h, 1), i1y = wrapF(I1y, w, h, 1), bl = wrapF(blurred, w, h, 2);
-  Params p; LevelCtx L{&i0x, &i0y, &i1x, &i1y, &bl, &p, w};
+  Params p = g_params; LevelCtx L{&i0x, &i0y, &i1x, &i1y, &bl, &p, w};
   for (int y = 0; y < h; ++y)
     for (int x = 0; x < w; ++x) err[size_t(y) * w + x] = errorFunction(L, x, y, cand[(size_t(y) * w + x) * 2], cand[(size_t(y) * w + x) * 2 + 1]);
 }

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kRXThreads) void k_sweep_relax(const float2* __rest
           float e = 0.0f;
           if (act && kk < 3) e = d_error_rx(g1, sm.win, wx0, wy0, W, wm2, hm2, fW, rW, FWD ? cu : W - 1 - cu, FWD ? cv : H - 1 - cv, g.x, g.y, bl.x, bl.y, fx, fy);
           int emin = 0; float vmax = 0.0f;
-          const float2 o = select_step<false, false>(e, sm.cE[0][q], sm.cE[0][q], own_gradient_step(C, sm.cE[0][q], sm.cE[1][q], sm.cE[2][q]), base, okL, okT, 0.0f, emin, vmax);
+          const float2 o = select_step<false, false>(e, sm.cE[0][q], sm.cE[0][q], own_gradient_step(C, sm.cE[0][q], sm.cE[1][q], sm.cE[2][q], kGradientStepSize), base, okL, okT, 0.0f, kGradientStepSize, emin, vmax);   // (this rejected experiment knows the factory's presets only: pf_set_solver_params refuses other sets for sweep_impl 3)
           if (act && k == 0) {
             atomicAnd(&sm.bits[pc][q >> 5], ~(1u << (q & 31)));
             const unsigned long long nv = pack2(o);

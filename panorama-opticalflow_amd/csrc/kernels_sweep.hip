@@ -31,7 +31,7 @@ constexpr int kSpinLimit = 1 << 22;
 struct F2x2 { float a, b, c, d; } __attribute__((aligned(8)));  // two adjacent float2 texels
 
 // errorFunction (PixFlow.hpp:427-456); every operation in the reference's order, no FMA.
-__device__ __forceinline__ float d_error(const float2* __restrict__ g1, int W, float wm2, float hm2, float fW, int x, int y, float i0x, float i0y,
+__device__ __forceinline__ float d_error(const float2* __restrict__ g1, int W, float wm2, float hm2, float fW, const SolverCoef& cf, int x, int y, float i0x, float i0y,
                                          float bx, float by, float fdx, float fdy) {
   const float matchX = float(x) + fdx, matchY = float(y) + fdy;
   float cx = (0.0f < matchX) ? matchX : 0.0f; cx = (cx < wm2) ? cx : wm2;   // min(w-2, max(0,x)) with std::min/max semantics
@@ -54,8 +54,8 @@ __device__ __forceinline__ float d_error(const float2* __restrict__ g1, int W, f
   }
   const float dfx = bx - fdx, dfy = by - fdy;
   const float smoothness = sqrtf(dfx * dfx + dfy * dfy);
-  const float err = sqrtf((i0x - i1x) * (i0x - i1x) + (i0y - i1y) * (i0y - i1y)) + smoothness * kSmoothnessCoef +
-                    kVerticalRegularizationCoef * fabsf(fdy) / fW + kHorizontalRegularizationCoef * fabsf(fdx) / fW;
+  const float err = sqrtf((i0x - i1x) * (i0x - i1x) + (i0y - i1y) * (i0y - i1y)) + smoothness * cf.smooth +
+                    cf.vreg * fabsf(fdy) / fW + cf.hreg * fabsf(fdx) / fW;
   return err;
 }
 
@@ -120,16 +120,16 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
         // neighbour proposes the current flow, which can never be strictly better.
         const float2 pl = (cx > 0) ? prev : f;
         const float2 pt = (ry > 0) ? up : f;
-        float currErr = d_error(a.g1, W, wm2, hm2, fW, x, y, g0.x, g0.y, bl.x, bl.y, f.x, f.y);
-        const float eL = d_error(a.g1, W, wm2, hm2, fW, x, y, g0.x, g0.y, bl.x, bl.y, pl.x, pl.y);
-        const float eT = d_error(a.g1, W, wm2, hm2, fW, x, y, g0.x, g0.y, bl.x, bl.y, pt.x, pt.y);
+        float currErr = d_error(a.g1, W, wm2, hm2, fW, a.cf, x, y, g0.x, g0.y, bl.x, bl.y, f.x, f.y);
+        const float eL = d_error(a.g1, W, wm2, hm2, fW, a.cf, x, y, g0.x, g0.y, bl.x, bl.y, pl.x, pl.y);
+        const float eT = d_error(a.g1, W, wm2, hm2, fW, a.cf, x, y, g0.x, g0.y, bl.x, bl.y, pt.x, pt.y);
         if (eL < currErr) { f = pl; currErr = eL; }
         if (eT < currErr) { f = pt; currErr = eT; }
-        const float ex = d_error(a.g1, W, wm2, hm2, fW, x, y, g0.x, g0.y, bl.x, bl.y, f.x + kGradEpsilon, f.y + 0.0f);
-        const float ey = d_error(a.g1, W, wm2, hm2, fW, x, y, g0.x, g0.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
+        const float ex = d_error(a.g1, W, wm2, hm2, fW, a.cf, x, y, g0.x, g0.y, bl.x, bl.y, f.x + kGradEpsilon, f.y + 0.0f);
+        const float ey = d_error(a.g1, W, wm2, hm2, fW, a.cf, x, y, g0.x, g0.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
         const float gx = (ex - currErr) / kGradEpsilon, gy = (ey - currErr) / kGradEpsilon;
-        f.x = f.x - kGradientStepSize * gx;
-        f.y = f.y - kGradientStepSize * gy;
+        f.x = f.x - a.cf.step * gx;
+        f.y = f.y - a.cf.step * gy;
         a.flow[idx] = f;
       }
       if (publishes) __hip_atomic_store(bnd_out + cx, d_pack(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

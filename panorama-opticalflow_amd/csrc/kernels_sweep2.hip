@@ -158,7 +158,7 @@ __device__ long long g_band_trace[1024][40];
 #endif
 
 // errorFunction (PixFlow.hpp:427-456); identical operation order to kernels_sweep.hip / the oracle.
-__device__ __forceinline__ float d_error2(const float2* __restrict__ g1, int W, float wm2, float hm2, float fW, int x, int y, float i0x, float i0y,
+__device__ __forceinline__ float d_error2(const float2* __restrict__ g1, int W, float wm2, float hm2, float fW, const SolverCoef& cf, int x, int y, float i0x, float i0y,
                                           float bx, float by, float fdx, float fdy) {
   const float matchX = float(x) + fdx, matchY = float(y) + fdy;
   float cx = (0.0f < matchX) ? matchX : 0.0f; cx = (cx < wm2) ? cx : wm2;
@@ -181,8 +181,8 @@ __device__ __forceinline__ float d_error2(const float2* __restrict__ g1, int W, 
   }
   const float dfx = bx - fdx, dfy = by - fdy;
   const float smoothness = sqrtf(dfx * dfx + dfy * dfy);
-  return sqrtf((i0x - i1x) * (i0x - i1x) + (i0y - i1y) * (i0y - i1y)) + smoothness * kSmoothnessCoef +
-         kVerticalRegularizationCoef * fabsf(fdy) / fW + kHorizontalRegularizationCoef * fabsf(fdx) / fW;
+  return sqrtf((i0x - i1x) * (i0x - i1x) + (i0y - i1y) * (i0y - i1y)) + smoothness * cf.smooth +
+         cf.vreg * fabsf(fdy) / fW + cf.hreg * fabsf(fdx) / fW;
 }
 
 // all of v0..v3 (>= 0) are zero or inside [2^-95, 2^100]: the range where sqrt_core/div_core are exact
@@ -201,7 +201,7 @@ __device__ __forceinline__ bool fast_range_ok1(float v) {
 
 // errorFunction for the prepass: identical values to d_error2, with the two square roots and two divisions in their
 // cheap exact forms whenever every operand is inside the valid range (per-thread test; otherwise the IEEE sequence).
-__device__ __forceinline__ float d_error2g(const float2* __restrict__ g1, int W, float wm2, float hm2, float fW, float rW, int x, int y, float i0x,
+__device__ __forceinline__ float d_error2g(const float2* __restrict__ g1, int W, float wm2, float hm2, float fW, float rW, const SolverCoef& cf, int x, int y, float i0x,
                                            float i0y, float bx, float by, float fdx, float fdy) {
   const float matchX = float(x) + fdx, matchY = float(y) + fdy;
   float cx = (0.0f < matchX) ? matchX : 0.0f; cx = (cx < wm2) ? cx : wm2;
@@ -225,10 +225,10 @@ __device__ __forceinline__ float d_error2g(const float2* __restrict__ g1, int W,
   const float dfx = bx - fdx, dfy = by - fdy;
   const float s2 = dfx * dfx + dfy * dfy;
   const float d2 = (i0x - i1x) * (i0x - i1x) + (i0y - i1y) * (i0y - i1y);
-  const float av = kVerticalRegularizationCoef * fabsf(fdy), ah = kHorizontalRegularizationCoef * fabsf(fdx);
+  const float av = cf.vreg * fabsf(fdy), ah = cf.hreg * fabsf(fdx);
   if (fast_range_ok(s2, d2, av, ah))
-    return sqrt_core(d2) + sqrt_core(s2) * kSmoothnessCoef + div_core(av, fW, rW) + div_core(ah, fW, rW);
-  return sqrtf(d2) + sqrtf(s2) * kSmoothnessCoef + av / fW + ah / fW;
+    return sqrt_core(d2) + sqrt_core(s2) * cf.smooth + div_core(av, fW, rW) + div_core(ah, fW, rW);
+  return sqrtf(d2) + sqrtf(s2) * cf.smooth + av / fW + ah / fW;
 }
 
 // lane i reads lane i+N of its row of 16; lanes whose source falls outside the row read 0 (bound_ctrl), no 'old' operand to set up
@@ -257,7 +257,7 @@ __device__ __forceinline__ float dpp_shl0(float src) {
 // updated -- one that is not never sends the wave to HBM.
 template <bool TR, bool FWD, int kWA, int WCP = kWCp, bool SKEW = false, int FOLLOW = 0>
 __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __attribute__((address_space(3))) const float2* win, int ob, int W, int H, float wm2, float hm2,
-                                              float fW, float rW, f2p pos, float i0x, float i0y, float bx, float by, f2p fd,
+                                              float fW, float rW, const SolverCoef& cf, f2p pos, float i0x, float i0y, float bx, float by, f2p fd,
                                               int& emin, float& vmax, f2p pc = f2p{0.f, 0.f}, bool live = true) {
   // ---- A ----  (pos = the pixel's (x, y), fd = the candidate flow: packed fp32 wherever both components take the same operation)
   const float fdx = fd.x, fdy = fd.y;
@@ -333,9 +333,9 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
     s2 = df2.x + df2.y;
     asm volatile("" : "+v"(s2));   // a finished scalar here: otherwise the SLP vectoriser packs this add with d2's below behind two register moves (3 instructions for 2)
   }
-  float av = kVerticalRegularizationCoef * fabsf(fdy);
+  float av = cf.vreg * fabsf(fdy);
   asm volatile("" : "+v"(av));   // keeps the two products scalar (|x| is a free source modifier there); packed, they need two v_and for the abs: 3 instructions for 2
-  const float ah = kHorizontalRegularizationCoef * fabsf(fdx);
+  const float ah = cf.hreg * fabsf(fdx);
   const f2p reg = div_core2(f2p{av, ah}, fW, rW);
   const float rv = reg.x, rh = reg.y;
   emin = min(min(__builtin_amdgcn_frexp_expf(s2), __builtin_amdgcn_frexp_expf(av)), __builtin_amdgcn_frexp_expf(ah));   // 0 for a zero operand
@@ -388,7 +388,7 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   int ed2;
   const f2p sq = sqrt_core2(f2p{d2, s2}, ed2);   // both square roots of the step as one packed sequence (+ d2's exponent for the guard)
   emin = min(emin, ed2);
-  return sq.x + sq.y * kSmoothnessCoef + rv + rh;
+  return sq.x + sq.y * cf.smooth + rv + rh;
 }
 
 // The tail of a step.  Every proposal takes its OWN gradient step, in its own lane, before anybody knows which one wins: lane 0
@@ -401,7 +401,7 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
 // step: two DPP moves and five v_cndmask more per step, all on the dependency chain.)
 // FAST uses div_core and extends the running range guard; !FAST is the IEEE sequence.
 template <bool FAST, bool TR>
-__device__ __forceinline__ float2 select_step(float e, float eC, float eCL, float2 rC, float2 cnd, bool okL, bool okT, float rEps, int& emin, float& vmax) {
+__device__ __forceinline__ float2 select_step(float e, float eC, float eCL, float2 rC, float2 cnd, bool okL, bool okT, float rEps, float step, int& emin, float& vmax) {
   const float g1 = dpp_shl0<1>(e), g2 = dpp_shl0<2>(e);   // row_shl:n reads lane+n
   float2 rp;                                               // this lane's proposal after its gradient step (meaningful in lanes 0 and 4)
   if (FAST) {
@@ -411,15 +411,16 @@ __device__ __forceinline__ float2 select_step(float e, float eC, float eCL, floa
     const f2p gq = div_core2(dg, kGradEpsilon, rEps);
     emin = min(emin, min(__builtin_amdgcn_frexp_expf(ax), __builtin_amdgcn_frexp_expf(ay)));
     vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(ax, ay));
-    // flow - 0.5 * g as ONE fused multiply-add: the product with a power of two is exact (|g| >= 2^-84 or 0 inside the guard's
-    // range, so no underflow), hence the single rounding of the FMA is the rounding of the reference's subtraction -- bit for
+    // flow - step * g as ONE fused multiply-add: the product with a power of two is exact (|g| >= 2^-84 or 0 inside the guard's
+    // range, so no underflow for step >= 2^-16), hence the single rounding of the FMA is the rounding of the reference's subtraction -- bit for
     // bit, signs of zero included (g = +0: f + (-0) = f) -- and one instruction less on the step's dependency chain.
-    static_assert(kGradientStepSize == 0.5f, "the exactness argument needs a power of two");
-    const f2p r = __builtin_elementwise_fma(gq, f2p{-kGradientStepSize, -kGradientStepSize}, f2p{cnd.x, cnd.y});
+    // (`step` is a kernel argument since round 6: the host only lets the fast form's result stand when step is a power of two in
+    // [2^-16, 2^16] -- SolverCoef::guard_min sends every other step size through the IEEE branch below.)
+    const f2p r = __builtin_elementwise_fma(gq, f2p{-step, -step}, f2p{cnd.x, cnd.y});
     rp = make_float2(r.x, r.y);
   } else {
     const float gx = (g1 - e) / kGradEpsilon, gy = (g2 - e) / kGradEpsilon;
-    rp = make_float2(cnd.x - kGradientStepSize * gx, cnd.y - kGradientStepSize * gy);
+    rp = make_float2(cnd.x - step * gx, cnd.y - step * gy);
   }
   // lane 0: the across proposal's energy and result from lane 4; L is the along-axis proposal unless the sweep is transposed
   const float eX = dpp_shl0<4>(e);
@@ -494,7 +495,7 @@ __device__ __forceinline__ void st_cnt(int* p, int v) {
 // wave-uniform, so the per-step "is my top neighbour there" test is two scalar instructions.
 template <class G, int TOP, bool TR, bool FWD, bool SPARSE>
 __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restrict__ g1, int W, int H, int nsteps, int w, int band,
-                                             int nact, bool publishes, float rW, float rEps, int uLo, int LSv, unsigned long long* bnd_out = nullptr) {
+                                             int nact, bool publishes, float rW, float rEps, const SolverCoef cf, int uLo, int LSv, unsigned long long* bnd_out = nullptr) {
   constexpr int kWaves = G::kWaves, kRS = G::kRS, kOS = G::kOS, kWA = G::kWA;
   constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0;
   const int lane = threadIdx.x & 63;
@@ -723,7 +724,7 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
       const float2 cand = cnd;
       int emin; float vmax;
       const f2p fdv = f2p{cand.x, cand.y} + f2p{addx, addy};
-      float e = d_error_fast<TR, FWD, kWA, kWCp, false, G::kFollow ? 1 : 0>(g1, win, ob, W, H, wm2, hm2, fW, rW, posv, ra.x, ra.y, ra.z, ra.w, fdv, emin, vmax, f2p{rp.x, rp.y});
+      float e = d_error_fast<TR, FWD, kWA, kWCp, false, G::kFollow ? 1 : 0>(g1, win, ob, W, H, wm2, hm2, fW, rW, cf, posv, ra.x, ra.y, ra.z, ra.w, fdv, emin, vmax, f2p{rp.x, rp.y});
       { // Only what the step uses is loaded: a loaded register nothing reads is handed out again by the register allocator at once,
         // and the hardware must then wait for the load in flight before the new value may be written (s_waitcnt right behind the
         // loads, ~50 cycles per step).  Transposed sweeps do not use Ea, the fourth float of the second quad.
@@ -735,17 +736,17 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
         if (transposed) { const f3v q1 = *(__attribute__((address_space(3))) const f3v*)(rpn + 1); nb = make_float4(q1.x, q1.y, q1.z, 0.f); }
         else { const f4v q1 = rpn[1]; nb = make_float4(q1.x, q1.y, q1.z, q1.w); } }
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-      fin = select_step<true, TR>(e, eC, eCL, rC, cnd, okL, okT, rEps, emin, vmax);
+      fin = select_step<true, TR>(e, eC, eCL, rC, cnd, okL, okT, rEps, cf.step, emin, vmax);
       asm volatile("" : "+v"(fin.x), "+v"(fin.y));   // finish the fast result before the branch: the range test then runs beside the division, not before it
       // Only pixels that will be updated count: the lanes of a pixel without data (gate <= 0) still run the arithmetic, and
       // there the inputs are blur tails of black borders (operands ~1e-40) -- their result is discarded two lines below.
-      if (__builtin_expect(__any((emin < -94 || !(vmax <= 0x1p100f)) && gated), 0)) {
+      if (__builtin_expect(__any((emin < cf.guard_min || !(vmax <= 0x1p100f)) && gated), 0)) {
 #ifdef PF_SWEEP_STATS
         ++statRedo;
 #endif
         // an operand left the range where the fast forms are exact: the whole wave redoes the step with IEEE sqrt and division
-        e = d_error2(g1, W, wm2, hm2, fW, int(posv.x), int(posv.y), ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
-        fin = select_step<false, TR>(e, eC, eCL, rC, cnd, okL, okT, rEps, emin, vmax);
+        e = d_error2(g1, W, wm2, hm2, fW, cf, int(posv.x), int(posv.y), ra.x, ra.y, ra.z, ra.w, cand.x + addx, cand.y + addy);
+        fin = select_step<false, TR>(e, eC, eCL, rC, cnd, okL, okT, rEps, cf.step, emin, vmax);
       }
       // (a pixel that is not updated keeps C through its record: kKeepEnergy, see d_make_record)
       } else {
@@ -800,9 +801,9 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
 }
 
 // The current flow's own gradient step (PixFlow.hpp:322-341 with the pixel's own energies), IEEE operations in the reference's order.
-__device__ __forceinline__ float2 own_gradient_step(float2 f, float e0, float ex, float ey) {
+__device__ __forceinline__ float2 own_gradient_step(float2 f, float e0, float ex, float ey, float step) {
   const float gx = (ex - e0) / kGradEpsilon, gy = (ey - e0) / kGradEpsilon;
-  return make_float2(f.x - kGradientStepSize * gx, f.y - kGradientStepSize * gy);
+  return make_float2(f.x - step * gx, f.y - step * gy);
 }
 
 // One record of the prepass (slot = linear index in wavefront order, see k_sweep_prep): shared by the prepass kernel and by
@@ -814,7 +815,7 @@ __device__ __forceinline__ float2 own_gradient_step(float2 f, float e0, float ex
 template <int ROWS = kRows, bool RC = true>
 __device__ __forceinline__ void d_make_record_at(int band, int s, int r, bool inside, const float2* __restrict__ g0, const float2* __restrict__ g1,
                                                  const float2* __restrict__ blurred, const uint8_t* __restrict__ gate, const float2* __restrict__ flow, int W,
-                                                 int H, int forward, int transposed, float rW, int uLo, int uHi, int bandLo, float4& a,
+                                                 int H, int forward, int transposed, float rW, const SolverCoef& cf, int uLo, int uHi, int bandLo, float4& a,
                                                  float4& b, float4& c) {
   const int LS = transposed ? H : W, LB = transposed ? W : H;   // extent along the step axis / across the bands
   const int ia = uLo + s - r, ib = (bandLo + band) * ROWS + r;
@@ -835,12 +836,12 @@ __device__ __forceinline__ void d_make_record_at(int band, int s, int r, bool in
       const float wm2 = float(W) - 2.0f, hm2 = float(H) - 2.0f, fW = float(W);
       a = make_float4(g.x, g.y, bl.x, bl.y);
       c.z = 0.f; c.w = 0.f;
-      const float e0 = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x, f.y);
+      const float e0 = d_error2g(g1, W, wm2, hm2, fW, rW, cf, x, y, g.x, g.y, bl.x, bl.y, f.x, f.y);
       b.x = e0;
       if (RC) {
-        const float e1 = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x + kGradEpsilon, f.y + 0.0f);
-        const float e2 = d_error2g(g1, W, wm2, hm2, fW, rW, x, y, g.x, g.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
-        const float2 rc0 = own_gradient_step(f, e0, e1, e2);
+        const float e1 = d_error2g(g1, W, wm2, hm2, fW, rW, cf, x, y, g.x, g.y, bl.x, bl.y, f.x + kGradEpsilon, f.y + 0.0f);
+        const float e2 = d_error2g(g1, W, wm2, hm2, fW, rW, cf, x, y, g.x, g.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
+        const float2 rc0 = own_gradient_step(f, e0, e1, e2, cf.step);
         b.y = rc0.x; b.z = rc0.y;
       }
       b.w = (ia > 0) ? e0 : kKeepEnergy;   // E(C) as the proposal from the previous pixel ALONG the step axis sees it: unbeatable at the first pixel of a row (there is none)
@@ -852,12 +853,12 @@ __device__ __forceinline__ void d_make_record_at(int band, int s, int r, bool in
 template <int ROWS = kRows, bool RC = true>
 __device__ __forceinline__ void d_make_record(size_t tid, size_t total, const float2* __restrict__ g0, const float2* __restrict__ g1,
                                               const float2* __restrict__ blurred, const uint8_t* __restrict__ gate, const float2* __restrict__ flow, int W,
-                                              int H, int forward, int transposed, int nstepsPad, float rW, int uLo, int uHi, int bandLo, float4& a,
+                                              int H, int forward, int transposed, int nstepsPad, float rW, const SolverCoef& cf, int uLo, int uHi, int bandLo, float4& a,
                                               float4& b, float4& c) {
   const int r = int(tid % ROWS);
   const int s = int((tid / ROWS) % nstepsPad);
   const int band = int(tid / (size_t(ROWS) * nstepsPad));
-  d_make_record_at<ROWS, RC>(band, s, r, tid < total, g0, g1, blurred, gate, flow, W, H, forward, transposed, rW, uLo, uHi, bandLo, a, b, c);
+  d_make_record_at<ROWS, RC>(band, s, r, tid < total, g0, g1, blurred, gate, flow, W, H, forward, transposed, rW, cf, uLo, uHi, bandLo, a, b, c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -882,7 +883,7 @@ template <int ROWS, bool RC, bool SOA = false>
 __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g0, const float2* __restrict__ g1, const float2* __restrict__ blurred,
                                                     const uint8_t* __restrict__ gate, const float2* __restrict__ flow, int W, int H, int forward,
                                                     int transposed, int nstepsPad, int nbandsPad, float rW, float4* __restrict__ rec, int uLo, int uHi,
-                                                    int bandLo, unsigned long long* __restrict__ top0, size_t bstride) {
+                                                    int bandLo, unsigned long long* __restrict__ top0, size_t bstride, SolverCoef cf) {
   {   // blockIdx.z = pair of a batched launch (every pointer is pair 0's)
     const size_t bo = size_t(blockIdx.z) * bstride;
     PF_BOFF(g0, bo); PF_BOFF(g1, bo); PF_BOFF(blurred, bo); PF_BOFF(gate, bo); PF_BOFF(flow, bo); PF_BOFF(rec, bo);
@@ -909,7 +910,7 @@ __global__ __launch_bounds__(256) void k_sweep_prep(const float2* __restrict__ g
   // (throughput form: 32-byte records -- the step forms the pixel's coordinates itself, the record stream is what bounds this kernel there)
   constexpr int kQuads = RC ? 3 : 2;
   float4 a, b, c;
-  d_make_record_at<ROWS, RC>(band, s, r, band < nbandsPad && s < nstepsPad, g0, g1, blurred, gate, flow, W, H, forward, transposed, rW, uLo, uHi, bandLo, a, b, c);
+  d_make_record_at<ROWS, RC>(band, s, r, band < nbandsPad && s < nstepsPad, g0, g1, blurred, gate, flow, W, H, forward, transposed, rW, cf, uLo, uHi, bandLo, a, b, c);
   if (SOA) {
     static_assert(!SOA || (ROWS == 8 && RC), "chunk layout of the latency form");
     // float4 index in the band's stream: chunk * 128 + quad * 64 + (record in chunk); lt = 64 * (chunk in block) + (record in chunk)
@@ -1080,7 +1081,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
                                                 unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H,
                                                 int nstepsPad, int nbands, float rW, float rEps, int uLo, int LSv, int bandLo, long long budgetTicks,
                                                 const float2* __restrict__ g0, const float2* __restrict__ blurred, const uint8_t* __restrict__ gate,
-                                                int nwgSweep, int* __restrict__ prepcnt, size_t bstride) {
+                                                int nwgSweep, int* __restrict__ prepcnt, size_t bstride, SolverCoef cf) {
   {   // blockIdx.z = pair of a batched launch: an independent sweep with its own ticket, granules and records
     const size_t bo = size_t(blockIdx.z) * bstride;
     PF_BOFF(rec, bo); PF_BOFF(g1, bo); PF_BOFF(flow, bo); PF_BOFF(boundary, bo); PF_BOFF(ctrl, bo); PF_BOFF(g0, bo); PF_BOFF(blurred, bo); PF_BOFF(gate, bo);
@@ -1095,7 +1096,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
     const size_t total = size_t(nwgSweep) * slotsPerWG;
     const size_t first = size_t(int(blockIdx.x) - nwgSweep) * blockDim.x, slot = first + threadIdx.x;
     float4 a, b, c;
-    d_make_record(slot, total, g0, g1, blurred, gate, flow, W, H, FWD ? 1 : 0, TR ? 1 : 0, nstepsPad, rW, uLo, uLo + LSv, bandLo, a, b, c);
+    d_make_record(slot, total, g0, g1, blurred, gate, flow, W, H, FWD ? 1 : 0, TR ? 1 : 0, nstepsPad, rW, cf, uLo, uLo + LSv, bandLo, a, b, c);
     if (slot < total) {
       // sc1 (write-through) 16-byte stores through a buffer descriptor built from wave-uniform values (G16 R1)
       typedef unsigned int u4v __attribute__((ext_vector_type(4)));
@@ -1160,9 +1161,9 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
     const int top = (wave > 0) ? 1 : ((wg > 0 || staticTop) ? 2 : 0);   // where row 0's top neighbour comes from
     const int band = bandLo + band0 + wave;                               // absolute band index
     bool ok;
-    if (top == 1) ok = compute_band<G, 1, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv, boundary + size_t(wg + 1) * LSv);
-    else if (top == 2) ok = compute_band<G, 2, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv, boundary + size_t(wg + 1) * LSv);
-    else ok = compute_band<G, 0, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv, boundary + size_t(wg + 1) * LSv);
+    if (top == 1) ok = compute_band<G, 1, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, cf, uLo, LSv, boundary + size_t(wg + 1) * LSv);
+    else if (top == 2) ok = compute_band<G, 2, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, cf, uLo, LSv, boundary + size_t(wg + 1) * LSv);
+    else ok = compute_band<G, 0, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, cf, uLo, LSv, boundary + size_t(wg + 1) * LSv);
     if (!ok) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #ifdef PF_SWEEP_STATS_PRINT   // (stage entry only: ctrl[2..3] belong to the next sweep in a whole solve)
     if (lane == 0) { atomicAdd(&ctrl[2], atomicExch(&sm.statHits, 0)); atomicAdd(&ctrl[3], atomicExch(&sm.statSpins, 0)); }
@@ -1422,13 +1423,13 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
           if (ld[c]) {
             const float2 f = qf[c], g = qg[c], bl = qb[c];
             const bool on = qvalid[c] && qgate[c] != 0;
-            const float e0 = d_error2g(g1, W, wm2, hm2, fW, rW, qx[c], qy[c], g.x, g.y, bl.x, bl.y, f.x, f.y);
-            const float e1 = d_error2g(g1, W, wm2, hm2, fW, rW, qx[c], qy[c], g.x, g.y, bl.x, bl.y, f.x + kGradEpsilon, f.y + 0.0f);
-            const float e2 = d_error2g(g1, W, wm2, hm2, fW, rW, qx[c], qy[c], g.x, g.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
+            const float e0 = d_error2g(g1, W, wm2, hm2, fW, rW, cf, qx[c], qy[c], g.x, g.y, bl.x, bl.y, f.x, f.y);
+            const float e1 = d_error2g(g1, W, wm2, hm2, fW, rW, cf, qx[c], qy[c], g.x, g.y, bl.x, bl.y, f.x + kGradEpsilon, f.y + 0.0f);
+            const float e2 = d_error2g(g1, W, wm2, hm2, fW, rW, cf, qx[c], qy[c], g.x, g.y, bl.x, bl.y, f.x + 0.0f, f.y + kGradEpsilon);
             float4* dst = &sm.rec[w][(rh + c * kChunk) % kRS][0][0] + lane * 3;   // slot (lane >> 3, lane & 7) = linear slot `lane`
             dst[0] = on ? make_float4(g.x, g.y, bl.x, bl.y) : z4;
             const float2 fv = make_float2(qvalid[c] ? f.x : 0.f, qvalid[c] ? f.y : 0.f);
-            const float2 rc0 = on ? own_gradient_step(f, e0, e1, e2) : fv;
+            const float2 rc0 = on ? own_gradient_step(f, e0, e1, e2, cf.step) : fv;
             dst[1] = make_float4(on ? e0 : kKeepEnergy, rc0.x, rc0.y, (on && ia_of[c] > 0) ? e0 : kKeepEnergy);
             dst[2] = make_float4(float(qx[c]), float(qy[c]), on ? cox[c] : __builtin_nanf(""), on ? coy[c] : __builtin_nanf(""));
           }
@@ -1706,18 +1707,18 @@ static bool launch_sweep2_form(hipStream_t st, const SweepArgs& a, float* rec) {
   if (mode == 0 && G::kBPW == 1)
     hipExtLaunchKernelGGL((k_sweep_prep<kRows, true, true>), dim3((unsigned)((nstepsPad + 256 / kRows - 1) / (256 / kRows)), (unsigned)nbandsPad, a.bt.n), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate, a.flow,
                           a.W, a.H, a.forward, tr, nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo,
-                          bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride);
+                          bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride, a.cf);
   else if (mode == 0)
     hipExtLaunchKernelGGL((k_sweep_prep<kRows, true>), dim3((unsigned)((nstepsPad + 256 / kRows - 1) / (256 / kRows)), (unsigned)nbandsPad, a.bt.n), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate, a.flow,
                           a.W, a.H, a.forward, tr, nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo,
-                          bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride);
+                          bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride, a.cf);
   hipEvent_t evs = mode == 0 ? nullptr : a.ev_start;   // without a prepass kernel the sweep launch carries both events
   // wall-clock budget of every wait inside the launch, in 100 MHz ticks: 2 s + 1000 x the expected duration (~0.5 us per step)
   const long long budget = 200000000ll + 1000ll * 50ll * (long long)(nstepsPad + 9 * nbands);
   const unsigned nthreads = G::kThreads;
   const dim3 grid(mode == 2 ? nwg + (unsigned)((total + nthreads - 1) / nthreads) : nwg, 1, a.bt.n), block(nthreads);
   const float4* r4 = mode == 1 ? nullptr : reinterpret_cast<const float4*>(rec);
-#define PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, MDV) hipExtLaunchKernelGGL((k_sweep2<G, TRV, FWV, SPV, MDV>), grid, block, 0, st, evs, a.ev_stop, 0, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.g0, a.blurred, a.gate, nwg, a.prepcnt, a.bt.stride)
+#define PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, MDV) hipExtLaunchKernelGGL((k_sweep2<G, TRV, FWV, SPV, MDV>), grid, block, 0, st, evs, a.ev_stop, 0, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.g0, a.blurred, a.gate, nwg, a.prepcnt, a.bt.stride, a.cf)
 #ifdef PF_EXPERIMENTS
 #define PF_LAUNCH_SWEEP2__(TRV, FWV, SPV) do { if constexpr (G::kBPW == 1) { if (mode == 2) { PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 2); break; } if (mode == 1) { PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 1); break; } } PF_LAUNCH_SWEEP2_(TRV, FWV, SPV, 0); } while (0)
 #else

@@ -68,12 +68,12 @@ __device__ __forceinline__ void swap_roles(float v, float& lo, float& hi) {
 // (ob = ring-row base of the chunk's window rows, wof = the window's offset in image axes, live = the pixel is updated: d_error_fast<FOLLOW = 2>)
 template <bool FAST, bool TR, bool FWD>
 __device__ __forceinline__ float2 t_step(const float2* __restrict__ g1, __attribute__((address_space(3))) const float2* win, int ob, int W, int H, float wm2, float hm2,
-                                         float fW, float rW, float rEps, f2p posv, float4 ra, float eC, float2 C, float eCL, bool okL, bool okT, float2 along,
+                                         float fW, float rW, float rEps, const SolverCoef& cf, f2p posv, float4 ra, float eC, float2 C, float eCL, bool okL, bool okT, float2 along,
                                          float2 across, int role, int& emin, float& vmax, f2p wof, bool live) {
   auto energy = [&](float2 f, int& em, float& vm) -> float {
-    if (FAST) return d_error_fast<TR, FWD, tRV, kWCPT, true, 2>(g1, win, ob, W, H, wm2, hm2, fW, rW, posv, ra.x, ra.y, ra.z, ra.w, f2p{f.x, f.y}, em, vm, wof, live);
+    if (FAST) return d_error_fast<TR, FWD, tRV, kWCPT, true, 2>(g1, win, ob, W, H, wm2, hm2, fW, rW, cf, posv, ra.x, ra.y, ra.z, ra.w, f2p{f.x, f.y}, em, vm, wof, live);
     em = 0; vm = 0.f;
-    return d_error2(g1, W, wm2, hm2, fW, int(posv.x), int(posv.y), ra.x, ra.y, ra.z, ra.w, f.x, f.y);
+    return d_error2(g1, W, wm2, hm2, fW, cf, int(posv.x), int(posv.y), ra.x, ra.y, ra.z, ra.w, f.x, f.y);
   };
   // ---- round 1: the two proposals (reference order: previous column = L, then previous row = T; transposed sweeps step along y) ----
   const float2 p1 = role ? across : along;
@@ -102,11 +102,11 @@ __device__ __forceinline__ float2 t_step(const float2* __restrict__ g1, __attrib
     const f2p gq = div_core2(dg, kGradEpsilon, rEps);
     emin = min(min(em1, em2), min(__builtin_amdgcn_frexp_expf(ax), __builtin_amdgcn_frexp_expf(ay)));
     vmax = __builtin_fmaxf(__builtin_fmaxf(vm1, vm2), __builtin_fmaxf(ax, ay));
-    const f2p r = __builtin_elementwise_fma(gq, f2p{-kGradientStepSize, -kGradientStepSize}, f2p{Wf.x, Wf.y});   // exact: see select_step
+    const f2p r = __builtin_elementwise_fma(gq, f2p{-cf.step, -cf.step}, f2p{Wf.x, Wf.y});   // exact: see select_step
     res = make_float2(r.x, r.y);
   } else {
     const float gx = (g1e - eW) / kGradEpsilon, gy = (g2e - eW) / kGradEpsilon;
-    res = make_float2(Wf.x - kGradientStepSize * gx, Wf.y - kGradientStepSize * gy);
+    res = make_float2(Wf.x - cf.step * gx, Wf.y - cf.step * gy);
     emin = 0; vmax = 0.f;
   }
   return res;
@@ -115,7 +115,7 @@ __device__ __forceinline__ float2 t_step(const float2* __restrict__ g1, __attrib
 // One compute wave of the throughput form: a band of 32 rows.  TOP as in compute_band.
 template <int TOP, bool TR, bool FWD>
 __device__ __forceinline__ bool compute_band_t(SmemTF& sm, const float2* __restrict__ g1, const float4* __restrict__ recg, int W, int H, int nsteps, int w, int band,
-                                               int nact, bool publishes, float rW, float rEps, int uLo, int LSv) {
+                                               int nact, bool publishes, float rW, float rEps, const SolverCoef cf, int uLo, int LSv) {
   constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0;
   constexpr bool RG = true;
   const int lane = threadIdx.x & 63;
@@ -249,7 +249,7 @@ __device__ __forceinline__ bool compute_band_t(SmemTF& sm, const float2* __restr
       const float eCL = transposed ? eC : eCa;
       const bool okL = transposed ? hasCross : hasAlong, okT = transposed ? hasAlong : hasCross;
       int emin; float vmax;
-      float2 fin = t_step<true, TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, rEps, posv, ra, eC, C, eCL, okL, okT, prev, across, role, emin, vmax, wof, gated);
+      float2 fin = t_step<true, TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, rEps, cf, posv, ra, eC, C, eCL, okL, okT, prev, across, role, emin, vmax, wof, gated);
       // next step's inputs (LDS), behind the second gather round
       float4 na, nb; int hN = 0; unsigned long long tvN = tv;
       {
@@ -264,9 +264,9 @@ __device__ __forceinline__ bool compute_band_t(SmemTF& sm, const float2* __restr
         hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       asm volatile("" : "+v"(fin.x), "+v"(fin.y));
-      if (__builtin_expect(__any((emin < -94 || !(vmax <= 0x1p100f)) && gated), 0)) {
+      if (__builtin_expect(__any((emin < cf.guard_min || !(vmax <= 0x1p100f)) && gated), 0)) {
         // an operand left the range where the fast forms are exact: the whole wave redoes the step with IEEE sqrt and division
-        fin = t_step<false, TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, rEps, posv, ra, eC, C, eCL, okL, okT, prev, across, role, emin, vmax, wof, gated);
+        fin = t_step<false, TR, FWD>(g1, win, ob, W, H, wm2, hm2, fW, rW, rEps, cf, posv, ra, eC, C, eCL, okL, okT, prev, across, role, emin, vmax, wof, gated);
       }
       fin.x = gated ? fin.x : C.x; fin.y = gated ? fin.y : C.y;   // a pixel that is not updated keeps its flow (PixFlow.hpp:317); slots without a pixel carry C = 0
       if (TOP != 0) {
@@ -293,7 +293,7 @@ template <bool TR, bool FWD>
 __global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__ rec, const float2* __restrict__ g1, float2* __restrict__ flow,
                                                       unsigned long long* __restrict__ boundary, int* __restrict__ ctrl, int W, int H, int nstepsPad, int nbands,
                                                       float rW, float rEps, int uLo, int LSv, int bandLo, long long budgetTicks, size_t bstride,
-                                                      const float2* __restrict__ blurred) {
+                                                      const float2* __restrict__ blurred, SolverCoef cf) {
   {
     const size_t bo = size_t(blockIdx.z) * bstride;
     PF_BOFF(rec, bo); PF_BOFF(g1, bo); PF_BOFF(flow, bo); PF_BOFF(boundary, bo); PF_BOFF(ctrl, bo); PF_BOFF(blurred, bo);
@@ -327,9 +327,9 @@ __global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__
     const int band = bandLo + band0 + wave;
     bool ok;
     const float4* recg = rec + size_t(band0 + wave) * nstepsPad * (tRows * 2);
-    if (top == 1) ok = compute_band_t<1, TR, FWD>(sm, g1, recg, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
-    else if (top == 2) ok = compute_band_t<2, TR, FWD>(sm, g1, recg, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
-    else ok = compute_band_t<0, TR, FWD>(sm, g1, recg, W, H, nsteps, wave, band, nact, publishes, rW, rEps, uLo, LSv);
+    if (top == 1) ok = compute_band_t<1, TR, FWD>(sm, g1, recg, W, H, nsteps, wave, band, nact, publishes, rW, rEps, cf, uLo, LSv);
+    else if (top == 2) ok = compute_band_t<2, TR, FWD>(sm, g1, recg, W, H, nsteps, wave, band, nact, publishes, rW, rEps, cf, uLo, LSv);
+    else ok = compute_band_t<0, TR, FWD>(sm, g1, recg, W, H, nsteps, wave, band, nact, publishes, rW, rEps, cf, uLo, LSv);
     if (!ok) give_up();
     return;
   }
@@ -632,11 +632,11 @@ static bool launch_sweep_t(hipStream_t st, const SweepArgs& a, float* rec) {
   const float rW = (float)(1.0 / (double)(float)a.W), rEps = (float)(1.0 / (double)kGradEpsilon);
   hipExtLaunchKernelGGL((k_sweep_prep<tRows, false>), dim3((unsigned)((nstepsPad + 256 / tRows - 1) / (256 / tRows)), (unsigned)nbandsPad, a.bt.n), dim3(256), 0, st, a.ev_start, nullptr, 0, a.g0, a.g1, a.blurred, a.gate,
                         a.flow, a.W, a.H, a.forward, tr, nstepsPad, nbandsPad, rW, reinterpret_cast<float4*>(rec), uLo, uHi, bandLo,
-                        bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride);
+                        bandLo > 0 ? a.boundary : (unsigned long long*)nullptr, a.bt.stride, a.cf);
   const long long budget = 200000000ll + 1000ll * 50ll * (long long)(nstepsPad + 40 * nbands);
   const dim3 grid(nwg, 1, a.bt.n), block(tThreads);
   const float4* r4 = reinterpret_cast<const float4*>(rec);
-#define PF_LAUNCH_SWEEP_T(TRV, FWV) hipExtLaunchKernelGGL((k_sweep_t<TRV, FWV>), grid, block, 0, st, nullptr, a.ev_stop, 0, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.bt.stride, a.blurred)
+#define PF_LAUNCH_SWEEP_T(TRV, FWV) hipExtLaunchKernelGGL((k_sweep_t<TRV, FWV>), grid, block, 0, st, nullptr, a.ev_stop, 0, r4, a.g1, a.flow, a.boundary, a.ctrl, a.W, a.H, nstepsPad, nbands, rW, rEps, uLo, LSv, bandLo, budget, a.bt.stride, a.blurred, a.cf)
   if (tr) { if (a.forward) PF_LAUNCH_SWEEP_T(true, true); else PF_LAUNCH_SWEEP_T(true, false); }
   else { if (a.forward) PF_LAUNCH_SWEEP_T(false, true); else PF_LAUNCH_SWEEP_T(false, false); }
 #undef PF_LAUNCH_SWEEP_T

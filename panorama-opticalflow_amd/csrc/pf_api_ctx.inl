@@ -25,10 +25,13 @@ struct pf_ctx {
   hipEvent_t ev_fine = nullptr;   // gradients of the fine levels done (the directions start on the coarse ones before that)
   std::string err;
   std::string warn; int warn_count = 0;   // pf_last_warning / pf_warning_count: conditions that cost performance, never results
+  int warned_streams = 0;                 // the largest stream count the hardware-queue warning was already raised for (once per condition, not per call)
   std::map<std::string, DevBuf> bufs;  // named grow-only arena: everything a solve needs stays resident
   Gauss g5, g3_05, g3_1, g15;
   int prof = 0;   // 0 off, 1 every kernel family, 2 only the dominant family (the sweeps): fewer events in a timed region
   pf_config cfg;  // scheduling knobs (pf_create_cfg); results never depend on them
+  pf_solver_params sp = {kPyrScaleFactor, kSmoothnessCoef, kVerticalRegularizationCoef, kHorizontalRegularizationCoef, kGradientStepSize, kDownscaleFactor, 0.0f};   // PixFlow's constructor arguments (pf_set_solver_params)
+  SolverCoef cf;  // ... as the sweep kernels take them (guard_min: see pf_common.hpp)
   bool is_lane = false;   // one of several lanes of pf_novel_view_batch_dev running side by side
   int lanes_running = 1;  // throughput mode: lanes (this one included) solving batches side by side on the device right now
   long fuse_ups_px = 0;   // levels up to this many pixels get their incoming flow upsampled inside their first Gaussian (0 = never)
@@ -66,10 +69,13 @@ int fail(pf_ctx* c, int code, const char* fmt, ...) {
 // A call that drives `needed` HIP streams at once on a runtime that maps streams onto fewer hardware queues runs them partly one after the
 // other -- correct, slower, and silent.  The runtime sizes its queue pool from GPU_MAX_HW_QUEUES (default 4) when it is initialised; the
 // library cannot change that any more, but it can say so.  (The only environment variable this library looks at, and only to report.)
+// The variable is read ONCE per process (the runtime reads it once, too -- at its initialisation; a value set later changes nothing), and a
+// context raises the warning once per condition (a stream count it has not warned about yet), not once per call.
 void check_hw_queues(pf_ctx* c, int needed, const char* what) {
-  const char* e = getenv("GPU_MAX_HW_QUEUES");
-  const int queues = e ? atoi(e) : 4;
-  if (queues <= 0 || needed <= queues) return;
+  static const char* const e = getenv("GPU_MAX_HW_QUEUES");
+  static const int queues = e ? atoi(e) : 4;
+  if (queues <= 0 || needed <= queues || needed <= c->warned_streams) return;
+  c->warned_streams = needed;
   char buf[512];
   snprintf(buf, sizeof buf, "%s drives %d HIP streams, but the HIP runtime maps streams onto %d hardware queues (GPU_MAX_HW_QUEUES %s): streams share queues "
            "and their kernels serialise; set GPU_MAX_HW_QUEUES >= %d in the environment before the first HIP call of the process", what, needed, queues,
@@ -149,12 +155,13 @@ struct Geometry {
   size_t P;                 // total level pixels (padded to 64 per level)
   size_t Pexact;
 };
-Geometry make_geometry(int cols, int rows, int pad) {
+Geometry make_geometry(int cols, int rows, int pad, float pyrScale = kPyrScaleFactor) {
   Geometry g; g.cols = cols; g.rows = rows; g.pad = pad; g.ce = cols + 2 * pad;
   g.w0 = int(g.ce * kDownscaleFactor); g.h0 = int(rows * kDownscaleFactor);
   g.ws = {g.w0}; g.hs = {g.h0};
   while ((int)g.ws.size() < kPyrMaxLevels) {
-    const int nw = int(g.ws.back() * kPyrScaleFactor + 0.5f), nh = int(g.hs.back() * kPyrScaleFactor + 0.5f);
+    const int nw = int(g.ws.back() * pyrScale + 0.5f), nh = int(g.hs.back() * pyrScale + 0.5f);
+    if (nw >= g.ws.back() && nh >= g.hs.back()) break;   // (a scale that does not shrink the image any more: pf_set_solver_params keeps it below 1, this keeps the loop finite regardless)
     if (nh <= kPyrMinImageSize || nw <= kPyrMinImageSize) break;
     g.ws.push_back(nw); g.hs.push_back(nh);
   }

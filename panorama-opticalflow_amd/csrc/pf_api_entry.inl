@@ -101,7 +101,7 @@ int pf_novel_view_batch_dev(pf_ctx* c, int n_pairs, const uint8_t* const* d_l, c
     if (!l) return fail(c, PF_ERR_NOMEM, "cannot create lane %d: %s", (int)c->lanes.size() + 1, g_err.c_str());
     c->lanes.push_back(l);
   }
-  for (pf_ctx* l : c->lanes) l->prof = c->prof;   // profiling covers every lane (collected into the lane's own totals)
+  for (pf_ctx* l : c->lanes) { l->prof = c->prof; l->sp = c->sp; l->cf = c->cf; }   // profiling covers every lane (collected into the lane's own totals); lanes solve with the owner's parameters
   const int ngroups = (n_pairs + per_batch - 1) / per_batch;
   std::vector<int> rc(nlanes, 0);
   std::vector<std::string> msg(nlanes);

@@ -126,29 +126,31 @@ pf_ctx* create_ctx(const pf_config& cfg, bool lane) {
     // blend's two small tables (kernels_misc.hip: device globals, the same values for every context -- written once, so that no later
     // context rewrites them under a blend another context has in flight).  Only SUCCESS is cached: a probe that could not run
     // (a transient allocation / launch failure) is tried again by the next pf_create.
-    struct DeviceInit { bool probed = false; bool tables = false; };
+    // (round 6: the tables are written again by EVERY pf_create, under the mutex -- 2 x 256 floats, the same values each time, so a rewrite
+    // under another context's blend in flight changes no bit -- instead of once per process: device globals do not survive a hipDeviceReset,
+    // and a cached "done" would then leave later contexts with zeroed tables.  The failure paths leave the lock before they destroy the context.)
     static std::mutex init_mu;
-    static std::map<int, DeviceInit> init_done;
-    std::lock_guard<std::mutex> lk(init_mu);
-    DeviceInit& di = init_done[device];
-    if (!di.probed) {
-      unsigned* scratch = nullptr;
-      int r = -1;
-      if (hipMalloc((void**)&scratch, 256) == hipSuccess) { r = sweep_pk_probe(c->s_main, scratch); hipFree(scratch); }
-      if (r != 0) {
-        fail(nullptr, PF_ERR_DEVICE, r < 0 ? "the packed-fp32 probe could not run on device %d"
-                                             : "device %d: the sweep's asm-block packed-fp32 chains do not reproduce the compiler-scheduled forms (%d threads differ); rebuild with -DPF_SAFE_PK",
-             device, r);
-        pf_destroy(c);
-        return nullptr;
+    static std::map<int, bool> probed;
+    bool failed = false;
+    {
+      std::lock_guard<std::mutex> lk(init_mu);
+      if (!probed[device]) {
+        unsigned* scratch = nullptr;
+        int r = -1;
+        if (hipMalloc((void**)&scratch, 256) == hipSuccess) { r = sweep_pk_probe(c->s_main, scratch); hipFree(scratch); }
+        if (r != 0) {
+          fail(nullptr, PF_ERR_DEVICE, r < 0 ? "the packed-fp32 probe could not run on device %d"
+                                               : "device %d: the sweep's asm-block packed-fp32 chains do not reproduce the compiler-scheduled forms (%d threads differ); rebuild with -DPF_SAFE_PK",
+               device, r);
+          failed = true;
+        } else probed[device] = true;
       }
-      di.probed = true;
+      if (!failed) {
+        launch_blend_tables(c->s_main);
+        if (hipStreamSynchronize(c->s_main) != hipSuccess) { fail(nullptr, PF_ERR_DEVICE, "device %d: the blend tables could not be initialised", device); failed = true; }
+      }
     }
-    if (!di.tables) {
-      launch_blend_tables(c->s_main);
-      if (hipStreamSynchronize(c->s_main) != hipSuccess) { fail(nullptr, PF_ERR_DEVICE, "device %d: the blend tables could not be initialised", device); pf_destroy(c); return nullptr; }
-      di.tables = true;
-    }
+    if (failed) { pf_destroy(c); return nullptr; }
   }
   c->g5 = make_gauss(5, 0.25); c->g3_05 = make_gauss(3, 0.5); c->g3_1 = make_gauss(3, 1.0); c->g15 = make_gauss(15, 8.0);
   // Pre-sizing: every buffer a bidirectional solve / a stitch step on max_cols x max_rows needs is
@@ -229,6 +231,46 @@ void pf_destroy(pf_ctx* c) {
 const char* pf_last_error(const pf_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
 const char* pf_last_warning(const pf_ctx* c) { return c ? c->warn.c_str() : ""; }
 int pf_warning_count(const pf_ctx* c) { return c ? c->warn_count : 0; }
+
+void pf_solver_params_init(pf_solver_params* p) {
+  if (!p) return;
+  p->pyr_scale_factor = kPyrScaleFactor; p->smoothness_coef = kSmoothnessCoef; p->vertical_regularization_coef = kVerticalRegularizationCoef;
+  p->horizontal_regularization_coef = kHorizontalRegularizationCoef; p->gradient_step_size = kGradientStepSize; p->downscale_factor = kDownscaleFactor;
+  p->directional_regularization_coef = 0.0f;
+}
+// PixFlow's constructor arguments (CPU/PixFlow.hpp:46-68) as context state; see include/panoflow.h for the accepted ranges
+int pf_set_solver_params(pf_ctx* c, const pf_solver_params* p) {
+  if (!c) return fail(nullptr, PF_ERR_ARG, "null context");
+  pf_solver_params q;
+  if (p) q = *p; else pf_solver_params_init(&q);
+  auto coef_ok = [](float v) { return std::isfinite(v) && v >= 0.0f; };
+  if (!(q.pyr_scale_factor >= 0.25f && q.pyr_scale_factor <= 0.98f)) return fail(c, PF_ERR_ARG, "pyrScaleFactor %g outside [0.25, 0.98]", (double)q.pyr_scale_factor);
+  if (!coef_ok(q.smoothness_coef) || !coef_ok(q.vertical_regularization_coef) || !coef_ok(q.horizontal_regularization_coef))
+    return fail(c, PF_ERR_ARG, "smoothnessCoef / verticalRegularizationCoef / horizontalRegularizationCoef must be finite and >= 0");
+  if (!coef_ok(q.gradient_step_size)) return fail(c, PF_ERR_ARG, "gradientStepSize must be finite and >= 0");
+  if (q.downscale_factor != kDownscaleFactor) return fail(c, PF_ERR_ARG, "downscaleFactor %g: only 0.5 is supported (the 8-bit half-resolution path)", (double)q.downscale_factor);
+#ifdef PF_EXPERIMENTS
+  if (c->cfg.sweep_impl == 3 && p && memcmp(&q, &c->sp, sizeof q) != 0) {   // the relaxation experiment (kernels_relax.inl) is compiled for the presets
+    pf_solver_params d; pf_solver_params_init(&d);
+    if (memcmp(&q, &d, sizeof q) != 0) return fail(c, PF_ERR_ARG, "sweep_impl 3 (lab build) supports the preset parameters only");
+  }
+#endif
+  c->sp = q;
+  SolverCoef cf;
+  cf.smooth = q.smoothness_coef; cf.vreg = q.vertical_regularization_coef; cf.hreg = q.horizontal_regularization_coef; cf.step = q.gradient_step_size;
+  // the fast step's single fused multiply-add is the reference's multiply + subtract only for a power-of-two step size (pf_common.hpp: SolverCoef)
+  int ex = 0;
+  const bool pow2 = q.gradient_step_size > 0.0f && std::frexp(q.gradient_step_size, &ex) == 0.5f && ex - 1 >= -16 && ex - 1 <= 16;
+  cf.guard_min = pow2 ? -94 : 0x7fffffff;
+  c->cf = cf;
+  for (pf_ctx* l : c->lanes) { l->sp = c->sp; l->cf = c->cf; }
+  return 0;
+}
+int pf_get_solver_params(const pf_ctx* c, pf_solver_params* out) {
+  if (!c || !out) return PF_ERR_ARG;
+  *out = c->sp;
+  return 0;
+}
 
 int pf_max_percentage_by_name(const char* name) {
   if (name && strcmp(name, "pixflow_low") == 0) return 0;

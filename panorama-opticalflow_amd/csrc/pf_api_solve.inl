@@ -21,10 +21,10 @@ void run_level(pf_ctx* c, hipStream_t st, const float* g0, const float* g1, cons
                int* pc_fwd = nullptr, int* pc_bwd = nullptr, const float* ups_src = nullptr, int ups_w = 0, int ups_h = 0, Batch bt = Batch()) {
   // ups_src: flow_a does not hold this level's incoming flow yet -- it is the upsample of the coarser level's result (ups_w x ups_h),
   // computed by the Gaussian's tile loader on the way (small levels: one launch instead of two)
-  if (ups_src) { PROF(c, st, "gauss15_blurredFlow"); launch_gauss15_upsample(st, ups_src, ups_w, ups_h, 1.0f / kPyrScaleFactor, b.flow_a, b.blurred, w, h, c->g15, bt); }
+  if (ups_src) { PROF(c, st, "gauss15_blurredFlow"); launch_gauss15_upsample(st, ups_src, ups_w, ups_h, 1.0f / c->sp.pyr_scale_factor, b.flow_a, b.blurred, w, h, c->g15, bt); }
   else { PROF(c, st, "gauss15_blurredFlow"); launch_gauss15(st, b.flow_a, b.tmp, b.blurred, w, h, c->g15, bt); }
   SweepArgs sa;
-  sa.bt = bt;
+  sa.bt = bt; sa.cf = c->cf;
   sa.g0 = reinterpret_cast<const float2*>(g0); sa.g1 = reinterpret_cast<const float2*>(g1);
   sa.blurred = reinterpret_cast<const float2*>(b.blurred); sa.gate = gate; sa.W = w; sa.H = h; sa.sparse = sparse;
   if (box) { sa.ax0 = box[0]; sa.ay0 = box[1]; sa.ax1 = box[2] + 1; sa.ay1 = box[3] + 1; }   // empty (max < min): the sweeps are the identity
@@ -212,9 +212,10 @@ int solve_n(pf_ctx* c, int nb, const uint8_t* const* d_img0, const uint8_t* cons
   if (int e = check_dims(c, cols, rows, pad)) return e;
   if (max_pct < 0 || max_pct > 100) return fail(c, PF_ERR_ARG, "max_percentage %d out of range", max_pct);
   if (nb < 1 || nb > kMaxBatch) return fail(c, PF_ERR_ARG, "batch of %d pairs (1..%d)", nb, kMaxBatch);
-  const Geometry g = make_geometry(cols, rows, pad);
+  const Geometry g = make_geometry(cols, rows, pad, c->sp.pyr_scale_factor);
   SolveBufs sb;
   Batch bt;
+  if (g.n > kLevelTableMax && c->sp.pyr_scale_factor != kPyrScaleFactor) return fail(c, PF_ERR_ARG, "pyrScaleFactor %g gives %d pyramid levels (at most %d)", (double)c->sp.pyr_scale_factor, g.n, kLevelTableMax);
   if (nb == 1) { if (int e = alloc_solve(c, g, ndirs, sb)) return e; }
   else {
     if (g.n > kLevelTableMax || g.P >= (size_t(1) << 31)) return fail(c, PF_ERR_ARG, "image too large for a batched solve");
@@ -374,7 +375,7 @@ int solve_n(pf_ctx* c, int nb, const uint8_t* const* d_img0, const uint8_t* cons
     if (level > 0) {
       if (!fuse_ups(level - 1)) {
         PROF(c, st, "upsample_cubic");
-        launch_upsample_cubic(st, res, w, h, b.flow_a, g.ws[level - 1], g.hs[level - 1], 1.0f / kPyrScaleFactor, bt);
+        launch_upsample_cubic(st, res, w, h, b.flow_a, g.ws[level - 1], g.hs[level - 1], 1.0f / c->sp.pyr_scale_factor, bt);
       }
     } else {
       PROF(c, st, "final_flow");

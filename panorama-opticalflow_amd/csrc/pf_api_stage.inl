@@ -80,7 +80,7 @@ int pf_stage_sweep(pf_ctx* c, const float* g0, const float* g1, const float* blu
   int* pcnt = (int*)ensure(c, "sg_pc", 2 * size_t(sweep2_num_wgs_max(w, h)) * sizeof(int));
   if (!pcnt) return PF_ERR_NOMEM;
   HIPCHK(c, hipMemsetAsync(pcnt, 0, 2 * size_t(sweep2_num_wgs_max(w, h)) * sizeof(int), sm));
-  SweepArgs sa; sa.prepcnt = pcnt; sa.g0 = (const float2*)dg0; sa.g1 = (const float2*)dg1; sa.blurred = (const float2*)dbl; sa.gate = gate; sa.flow = (float2*)df;
+  SweepArgs sa; sa.cf = c->cf; sa.prepcnt = pcnt; sa.g0 = (const float2*)dg0; sa.g1 = (const float2*)dg1; sa.blurred = (const float2*)dbl; sa.gate = gate; sa.flow = (float2*)df;
   sa.boundary = bnd; sa.ctrl = ctrl; sa.W = w; sa.H = h; sa.forward = forward; sa.sparse = (w * h) % 2;   // stage test: exercise both variants
   sa.wide = c->cfg.sweep_wide > 0 ? c->cfg.sweep_wide : 0;   // the sweep form the context was created for (auto = latency form: one pair)
   if (sa.wide == 2) sa.sparse = 0;            // (the throughput form has no sparse variant)
@@ -188,15 +188,9 @@ int pf_stage_blend_smooth(pf_ctx* c, float* blend, const float* md, int cols, in
 // ---- profiling ----
 int pf_profile_enable(pf_ctx* c, int on) { if (!c) return PF_ERR_ARG; c->prof = on < 0 ? 0 : (on > 2 ? 1 : on); return 0; }
 int pf_profile_reset(pf_ctx* c) { if (!c) return PF_ERR_ARG; for (auto& t : c->prof_tot) t = ProfEntry(); return 0; }
-// (a context that has raised warnings lists them as one more entry, "warnings": 0 ms, launches = their number)
-int pf_profile_count(pf_ctx* c) { return c ? (int)c->prof_names.size() + (c->warn_count > 0 ? 1 : 0) : 0; }
+// (kernel families only: warnings are reported by pf_last_warning / pf_warning_count, not as a pseudo-entry of this list -- round 5 had one)
+int pf_profile_count(pf_ctx* c) { return c ? (int)c->prof_names.size() : 0; }
 int pf_profile_get(pf_ctx* c, int idx, char* name, int cap, double* ms, int* launches) {
-  if (c && c->warn_count > 0 && idx == (int)c->prof_names.size()) {
-    if (name && cap > 0) { strncpy(name, "warnings", cap - 1); name[cap - 1] = 0; }
-    if (ms) *ms = 0.0;
-    if (launches) *launches = c->warn_count;
-    return 0;
-  }
   if (!c || idx < 0 || idx >= (int)c->prof_names.size()) return PF_ERR_ARG;
   if (name && cap > 0) { strncpy(name, c->prof_names[idx].c_str(), cap - 1); name[cap - 1] = 0; }
   if (ms) *ms = c->prof_tot[idx].ms;

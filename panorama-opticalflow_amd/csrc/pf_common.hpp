@@ -18,6 +18,16 @@ constexpr float kVerticalRegularizationCoef = 0.01f;
 constexpr float kHorizontalRegularizationCoef = 0.01f;
 constexpr float kGradientStepSize = 0.5f;
 constexpr float kDownscaleFactor = 0.5f;
+// The reference's PixFlow takes these as constructor arguments (CPU/PixFlow.hpp:46-68); its factory only ever passes the values above
+// (:459-497).  The sweep kernels take them as scalar kernel arguments (round 6, pf_set_solver_params): a multiply by a coefficient costs
+// the same from an SGPR as from a literal.  `step`: the fast step folds `flow - step * g` into ONE fused multiply-add, which is the
+// reference's two roundings only when the product is exact, i.e. when step is a power of two; for any other step size the host sets
+// `guard_min` above every exponent, so that the range guard sends EVERY step of an updated pixel through the IEEE sequence
+// (select_step<false>, which multiplies and subtracts): no second kernel variant, bit-exact, slower.
+struct SolverCoef {
+  float smooth = kSmoothnessCoef, vreg = kVerticalRegularizationCoef, hreg = kHorizontalRegularizationCoef, step = kGradientStepSize;
+  int guard_min = -94;   // an operand whose frexp exponent lies below this (and is not zero) leaves the exact forms' range; INT_MAX = always
+};
 
 // sentinel for "boundary flow not published yet" (a NaN payload arithmetic cannot produce)
 constexpr unsigned long long kNotReady = 0x7FFFDEAD7FFFDEADull;
@@ -147,6 +157,7 @@ struct SweepArgs {
   int wide_threshold_wgs = 512;   // wide = -1: "oversubscribed" means more latency-form workgroups x concurrent_sweeps than this
   int wide_tr = 0;                // wide = -1: transposed sweeps (bands along y) may take the throughput form too (its window loads do not coalesce there)
   int concurrent_sweeps = 2;      // sweeps that run on the chip at the same time as this launch's (this launch's pairs x 2 directions x lanes)
+  SolverCoef cf;                  // the energy's coefficients and the gradient step size (defaults = the reference factory's presets)
 };
 size_t sweep_boundary_elems(int W, int H);   // hand-off granules needed per sweep launch (covers every sweep kernel of this build)
 size_t sweep1_boundary_elems(int W, int H);                     // lab build only (-DPF_EXPERIMENTS)

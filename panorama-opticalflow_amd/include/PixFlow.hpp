@@ -29,11 +29,10 @@ struct PixFlow : public OpticalFlowInterface {
       : pyrScaleFactor(pyrScaleFactor), smoothnessCoef(smoothnessCoef), verticalRegularizationCoef(verticalRegularizationCoef),
         horizontalRegularizationCoef(horizontalRegularizationCoef), gradientStepSize(gradientStepSize), downscaleFactor(downscaleFactor),
         directionalRegularizationCoef(directionalRegularizationCoef) {
-    // The device kernels are specialised for the only parameter set the reference's factory ever passes
-    // (PixFlow.hpp:461-497: both presets share it); anything else is rejected instead of silently ignored.
-    if (pyrScaleFactor != 0.9f || smoothnessCoef != 0.001f || verticalRegularizationCoef != 0.01f || horizontalRegularizationCoef != 0.01f ||
-        gradientStepSize != 0.5f || downscaleFactor != 0.5f)
-      throw VrCamException("PixFlow: only the pixflow_low / pixflow_search_20 parameter set is supported");
+    // Round 6: the coefficients are run-time arguments of the device kernels (pf_set_solver_params, include/panoflow.h), as they are
+    // constructor arguments in the reference (CPU/PixFlow.hpp:54-68).  The one exception is downscaleFactor: the 8-bit half-resolution
+    // front end exists for 0.5 only -- rejected here instead of silently ignored; the other ranges are checked by the library at solve time.
+    if (downscaleFactor != 0.5f) throw VrCamException("PixFlow: downscaleFactor must be 0.5 (the reference factory's value, CPU/PixFlow.hpp:466)");
   }
   ~PixFlow() {}
 
@@ -42,8 +41,16 @@ struct PixFlow : public OpticalFlowInterface {
         rgba0byte.step != rgba1byte.step)
       throw VrCamException("computeOpticalFlow: inputs must be two CV_8UC4 images of equal size");
     Mat out(rgba0byte.rows, rgba0byte.cols, CV_32FC2);
-    pano::check(pf_flow(pano::context(), rgba0byte.data, rgba1byte.data, rgba0byte.cols, rgba0byte.rows, rgba0byte.step, MaxPercentage, int(hint),
-                        out.ptr<float>(), out.step));
+    // this object's parameters for this solve; the shared per-thread context then returns to the factory's presets, which the other classes
+    // (NovelViewGeneratorAsymmetricFlow, Stitchtools: they only know algorithm NAMES, CPU/OpticalFlow.cpp:128) rely on
+    pf_ctx* ctx = pano::context();
+    const pf_solver_params sp = {pyrScaleFactor, smoothnessCoef, verticalRegularizationCoef, horizontalRegularizationCoef, gradientStepSize, downscaleFactor,
+                                 directionalRegularizationCoef};
+    pano::check(pf_set_solver_params(ctx, &sp));
+    const int rc = pf_flow(ctx, rgba0byte.data, rgba1byte.data, rgba0byte.cols, rgba0byte.rows, rgba0byte.step, MaxPercentage, int(hint), out.ptr<float>(), out.step);
+    const std::string msg = rc ? pf_last_error(ctx) : "";
+    pf_set_solver_params(ctx, nullptr);
+    if (rc) throw VrCamException("panoflow: " + msg);
     flow = out;
   }
 };

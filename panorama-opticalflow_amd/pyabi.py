@@ -39,6 +39,13 @@ class Config(C.Structure):
                 ("full_width_batch_gradients", C.c_int), ("sweep_impl", C.c_int), ("record_path", C.c_int)]
 
 
+class SolverParams(C.Structure):
+    """pf_solver_params (include/panoflow.h): the constructor arguments of the reference's PixFlow<P> (CPU/PixFlow.hpp:46-68)"""
+    _fields_ = [("pyr_scale_factor", C.c_float), ("smoothness_coef", C.c_float), ("vertical_regularization_coef", C.c_float),
+                ("horizontal_regularization_coef", C.c_float), ("gradient_step_size", C.c_float), ("downscale_factor", C.c_float),
+                ("directional_regularization_coef", C.c_float)]
+
+
 def lib(exp=False):
     """exp=False: the product library.  exp=True: the lab build with the cross-check sweeps (tests / diagnostics only)."""
     _lib = _libs.get(bool(exp))
@@ -84,6 +91,7 @@ def lib(exp=False):
 
 EXPORTS = [
     "pf_device_count", "pf_create", "pf_config_init", "pf_create_cfg", "pf_destroy", "pf_last_error", "pf_last_warning", "pf_warning_count", "pf_version", "pf_max_percentage_by_name",
+    "pf_solver_params_init", "pf_set_solver_params", "pf_get_solver_params",
     "pf_flow", "pf_flow_bidir", "pf_blend", "pf_novel_view", "pf_stitch_prepare", "pf_stitch_match", "pf_stitch_generate_blend", "pf_stitch_raw_blend", "pf_stitch_gather", "pf_stitch_step", "pf_stitch_prefetch",
     "pf_dev_alloc", "pf_dev_free", "pf_host_alloc", "pf_host_free", "pf_upload", "pf_download", "pf_sync", "pf_checksum_dev", "pf_selftest_packed_chains",
     "pf_flow_bidir_dev", "pf_blend_dev", "pf_novel_view_dev", "pf_novel_view_batch_dev",
@@ -426,6 +434,22 @@ class Context:
         b = _f32(blend).copy(); rows, cols = b.shape
         self._chk(self.l.pf_stage_blend_smooth(self.h, _p(b), _p(_f32(md)), cols, rows))
         return b
+
+    def set_solver_params(self, **kw):
+        """PixFlow's constructor arguments for every later solve on this context (pf_set_solver_params); no arguments = the factory's presets.
+        Keys: pyr_scale_factor, smoothness_coef, vertical_regularization_coef, horizontal_regularization_coef, gradient_step_size, downscale_factor."""
+        p = SolverParams()
+        self.l.pf_solver_params_init(C.byref(p))
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise PanoflowError("unknown solver parameter %r" % k)
+            setattr(p, k, v)
+        self._chk(self.l.pf_set_solver_params(self.h, C.byref(p)))
+
+    def solver_params(self):
+        p = SolverParams()
+        self._chk(self.l.pf_get_solver_params(self.h, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in SolverParams._fields_}
 
     def last_swept_steps(self):
         """dependent wavefront steps of one direction of the last solve (windows of gated pixels)"""
