@@ -80,6 +80,59 @@ pat("ds_write_b64 + ds_write_b32 among 8 independent v_add", ["ds_write_b64 v40,
 pat("independent v_add x4 ; s_cbranch_vccnz (not taken)", [fill(0), fill(1), fill(2), fill(3), "s_cbranch_vccnz 2f"], 20)
 pat("independent v_add x4 ; s_waitcnt lgkmcnt(0) (nothing pending)", [fill(0), fill(1), fill(2), fill(3), "s_waitcnt lgkmcnt(0)"], 20)
 
+# ---- incremental cost of ONE instruction of a kind inside a stream of 24 independent v_add (results waited for at the end of the unit) ----
+BASE24 = [fill(j) for j in range(24)]
+def incr(name, ins, tail=None):
+    pat("24 v_add + " + name, BASE24[:12] + ins + BASE24[12:] + (tail or []), 4, 24)
+pat("24 v_add (baseline of the incremental costs)", BASE24, 4, 24)
+incr("s_waitcnt lgkmcnt(0) at the end only", [], ["s_waitcnt lgkmcnt(0)"])
+for w in ("ds_write_b32 v40, v1", "ds_write_b64 v40, v[0:1]", "ds_write_b96 v40, v[0:2]", "ds_write_b128 v40, v[0:3]"):
+    incr(w.split()[0], [w], ["s_waitcnt lgkmcnt(0)"])
+incr("ds_write_b64 + ds_write_b32 (the step's publish)", ["ds_write_b64 v40, v[0:1]", "ds_write_b32 v40, v1 offset:1024"], ["s_waitcnt lgkmcnt(0)"])
+for r in ("ds_read_b32 v44, v40", "ds_read_b64 v[44:45], v40", "ds_read_b96 v[44:46], v40", "ds_read_b128 v[44:47], v40", "ds_read2_b64 v[44:47], v40 offset1:1", "ds_read2_b32 v[44:45], v40 offset1:1"):
+    incr(r.split()[0], [r], ["s_waitcnt lgkmcnt(0)"])
+incr("ds_read_b128 x3 (48-byte lane stride, as the records)", ["ds_read_b128 v[44:47], v41", "ds_read_b128 v[48:51], v41 offset:16", "ds_read_b128 v[52:55], v41 offset:32"], ["s_waitcnt lgkmcnt(0)"])
+incr("ds_read_b128 x2 (32-byte lane stride)", ["ds_read_b128 v[44:47], v42", "ds_read_b128 v[48:51], v42 offset:16"], ["s_waitcnt lgkmcnt(0)"])
+incr("v_rsq_f32", ["v_rsq_f32 v44, v45"])
+incr("v_rsq_f32 x2", ["v_rsq_f32 v44, v45", "v_rsq_f32 v46, v47"])
+incr("s_cbranch_vccnz (not taken)", ["s_cbranch_vccnz 2f"])
+incr("s_cbranch_scc1 (not taken)", ["s_cmp_eq_u32 s24, -1", "s_cbranch_scc1 2f"])
+incr("s_nop 0", ["s_nop 0"])
+incr("s_nop 1", ["s_nop 1"])
+incr("v_readfirstlane_b32", ["v_readfirstlane_b32 s26, v45"])
+incr("v_cmp_lt_f32 vcc", ["v_cmp_lt_f32 vcc, v44, v45"])
+incr("v_cmp_lt_f32 sgpr pair", ["v_cmp_lt_f32 s[30:31], v44, v45"])
+incr("v_cndmask_b32 (sgpr pair mask)", ["v_cndmask_b32 v44, v45, v46, s[30:31]"])
+incr("v_pk_fma_f32", ["v_pk_fma_f32 v[44:45], v[46:47], v[48:49], v[50:51]"])
+incr("v_pk_add_f32", ["v_pk_add_f32 v[44:45], v[46:47], v[48:49]"])
+incr("v_fma_f32", ["v_fma_f32 v44, v45, v46, v47"])
+incr("v_med3_f32", ["v_med3_f32 v44, v45, v46, v47"])
+incr("v_min3_i32", ["v_min3_i32 v44, v45, v46, v47"])
+incr("v_mad_u32_u24", ["v_mad_u32_u24 v44, v45, v46, v47"])
+incr("v_mov_b32_dpp row_newbcast", ["v_mov_b32_dpp v44, v45 row_newbcast:0 row_mask:0xf bank_mask:0x9"])
+incr("v_mov_b64_dpp row_newbcast", ["v_mov_b64_dpp v[44:45], v[46:47] row_newbcast:0 row_mask:0xf bank_mask:0x9"])
+incr("v_mov_b32_dpp row_bcast:15", ["v_mov_b32_dpp v44, v45 row_bcast:15 row_mask:0xe bank_mask:0x2"])
+incr("s_or_b64 + s_and_b64", ["s_or_b64 s[30:31], s[30:31], vcc", "s_and_b64 vcc, s[30:31], vcc"])
+incr("v_cmp_eq_u64", ["v_cmp_eq_u64 vcc, v[44:45], v[46:47]"])
+incr("v_frexp_exp_i32_f32", ["v_frexp_exp_i32_f32 v44, v45"])
+
+# ---- issue cost of LDS instructions with their latency hidden: the instruction(s) first, then 44 independent v_add, then the wait ----
+BASE44 = [fill(j) for j in range(44)]
+def incr_lds(name, ins):
+    pat("LDS-hidden: " + name + " ; 44 v_add ; wait", ins + BASE44 + ["s_waitcnt lgkmcnt(0)"], 3, 44)
+incr_lds("(nothing: baseline)", [])
+for w in ("ds_write_b32 v40, v1", "ds_write_b64 v40, v[0:1]", "ds_write_b96 v41, v[0:2]", "ds_write_b128 v41, v[0:3]", "ds_write_b64 v41, v[0:1]", "ds_write_b128 v43, v[0:3]"):
+    incr_lds(w.split(",")[0], [w])
+incr_lds("ds_write_b64 + ds_write_b32 (the step's publish)", ["ds_write_b64 v40, v[0:1]", "ds_write_b32 v40, v1 offset:1024"])
+for r in ("ds_read_b32 v44, v40", "ds_read_b64 v[44:45], v40", "ds_read_b96 v[44:46], v41", "ds_read_b128 v[44:47], v41", "ds_read_b128 v[44:47], v43", "ds_read2_b64 v[44:47], v40 offset1:1", "ds_read2_b64 v[44:47], v40 offset0:67 offset1:68"):
+    incr_lds(r.split(",")[0] + (" " + r.split()[-2] + r.split()[-1] if "offset" in r else ""), [r])
+incr_lds("ds_read_b128 x3 (48-byte lane stride, as the records)", ["ds_read_b128 v[44:47], v41", "ds_read_b128 v[48:51], v41 offset:16", "ds_read_b128 v[52:55], v41 offset:32"])
+incr_lds("ds_read_b128 x2 (32-byte lane stride)", ["ds_read_b128 v[44:47], v42", "ds_read_b128 v[48:51], v42 offset:16"])
+incr_lds("ds_read2_b64 x2 (the texels)", ["ds_read2_b64 v[44:47], v40 offset1:1", "ds_read2_b64 v[48:51], v40 offset0:67 offset1:68"])
+incr_lds("ds_read_b32 + ds_read_b64 (counter + top value)", ["ds_read_b32 v44, v40", "ds_read_b64 v[46:47], v40 offset:2048"])
+incr_lds("all nine LDS instructions of a step", ["ds_read2_b64 v[44:47], v40 offset1:1", "ds_read2_b64 v[48:51], v40 offset0:67 offset1:68", "ds_read_b128 v[52:55], v41", "ds_read_b128 v[56:59], v41 offset:16", "ds_read_b128 v[60:63], v41 offset:32",
+          "ds_read_b32 v4, v40", "ds_read_b64 v[6:7], v40 offset:2048", "ds_write_b64 v40, v[0:1] offset:4096", "ds_write_b32 v40, v1 offset:5120"])
+
 
 def gen():
     out = ["// generated by tests/micro/slot_model.py -- do not edit", "#include <hip/hip_runtime.h>", "#include <cstdio>", "#include <vector>", ""]
@@ -88,12 +141,12 @@ def gen():
         body = "\\n\\t".join(unit * reps)
         out.append("__global__ void k%d(unsigned long long* rec, float* o, int iters) {" % n)
         out.append("  __shared__ float lds[8192]; for (int i = threadIdx.x; i < 8192; i += 64) lds[i] = 1.0f + i * 1e-6f; __syncthreads();")
-        out.append("  unsigned long long t0, t1; float r; const unsigned la = (unsigned)(size_t)lds + threadIdx.x * 8;")
-        init = "\\n\\t".join(["v_mov_b32 v%d, 1.0" % i for i in range(64) if i != 40] + ["v_mov_b32 v1, 0x3f800001", "v_mov_b32 v32, 0x3f800001", "v_mov_b32 v33, 0x3f800001", "v_mov_b32 v40, %3",
+        out.append("  unsigned long long t0, t1; float r; const unsigned la = (unsigned)(size_t)lds + threadIdx.x * 8, lb = (unsigned)(size_t)lds + threadIdx.x * 48, lc = (unsigned)(size_t)lds + threadIdx.x * 32, ld = (unsigned)(size_t)lds + threadIdx.x * 16;")
+        init = "\\n\\t".join(["v_mov_b32 v%d, 1.0" % i for i in range(64) if i not in (40, 41, 42, 43)] + ["v_mov_b32 v1, 0x3f800001", "v_mov_b32 v32, 0x3f800001", "v_mov_b32 v33, 0x3f800001", "v_mov_b32 v40, %3", "v_mov_b32 v41, %5", "v_mov_b32 v42, %6", "v_mov_b32 v43, %7",
                               "s_mov_b32 s24, 0", "s_mov_b32 s25, 0", "s_mov_b32 s26, 0", "s_mov_b32 s27, 0", "s_mov_b64 vcc, 0", "s_mov_b32 s20, %4"])
         out.append('  asm volatile("%s\\n\\ts_waitcnt vmcnt(0) lgkmcnt(0)\\n\\ts_memtime %%0\\n\\ts_waitcnt lgkmcnt(0)\\n1:\\n\\t%s\\n\\ts_sub_u32 s20, s20, 1\\n\\ts_cmp_lg_u32 s20, 0\\n\\ts_cbranch_scc1 1b\\n2:\\n\\ts_waitcnt lgkmcnt(0)\\n\\ts_memtime %%1\\n\\ts_waitcnt lgkmcnt(0)\\n\\tv_add_f32 %%2, v0, v2"'
                    % (init, body))
-        out.append('               : "=&s"(t0), "=&s"(t1), "=v"(r) : "v"(la), "s"(iters) : %s);' % clob)
+        out.append('               : "=&s"(t0), "=&s"(t1), "=v"(r) : "v"(la), "s"(iters), "v"(lb), "v"(lc), "v"(ld) : %s);' % clob)
         out.append("  o[blockIdx.x * 64 + threadIdx.x] = r + lds[threadIdx.x]; if (threadIdx.x == 0) rec[blockIdx.x] = t1 - t0;")
         out.append("}")
     out.append("struct T { const char* name; void (*k)(unsigned long long*, float*, int); int per_body, nunit; };")
