@@ -102,6 +102,15 @@ constexpr int kWCp = kWC + PF_WCP_EXTRA; // row stride of the window: ring colum
 // the launch: 2 s + 1000x the expected duration) sits in LDS and is only looked at every 1024 polls.  A band that is merely
 // slow -- several contexts oversubscribing the GPU, a predecessor workgroup not scheduled yet -- therefore never raises
 // PF_ERR_TIMEOUT; a genuinely stuck one still does instead of hanging the GPU.
+#ifndef PF_DPP_FUSE
+#define PF_DPP_FUSE 1    // the selection's DPP moves folded into its compares / selects (A/B switch of round 6)
+#endif
+#ifndef PF_ABS_TORUS
+#define PF_ABS_TORUS 1   // the latency form's gather window addressed by image coordinates (A/B switch of round 6)
+#endif
+#ifndef PF_DPP64
+#define PF_DPP64 1   // the proposals' distribution with 64-bit DPP moves (A/B switch of round 6)
+#endif
 #ifndef PF_SWEEP_UNROLL
 #define PF_SWEEP_UNROLL 8
 #endif
@@ -287,14 +296,18 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   // The 2x2 footprint in sweep order is (v0, v0 + sg) x (u0, u0 + sg), sg = +1 forward / -1 backward.  Addressed from its LOWER
   // corner (vlo, ulo) it is two adjacent slots in two adjacent window rows -- the slot after ring column 63 holds column 0 again
   // (kWCp) -- so one ring wrap and one address serve all four texels (immediate offsets 0, 1, kWCp, kWCp + 1).
-  const int cxl = FWD ? x0 : W - 2 - x0, cyl = FWD ? y0 : H - 2 - y0;
+  // FOLLOW == 1 (the product's latency form, round 6): the torus is addressed by the texel's IMAGE coordinates instead -- the footprint's lower corner
+  // is (x0, y0) whatever the sweep's direction, so neither the mirror subtractions of a backward sweep nor the window-origin subtraction stand
+  // on the address chain (1 instruction per step forward, 2 backward), and the +1 neighbours are the next slots in both directions.
+  constexpr bool kAbs = PF_ABS_TORUS && FOLLOW == 1;
+  const int cxl = (FWD || kAbs) ? x0 : W - 2 - x0, cyl = (FWD || kAbs) ? y0 : H - 2 - y0;
   const int ulo = TR ? cyl : cxl, vlo = TR ? cxl : cyl;
   // out-of-window lanes are clamped to a valid window row (they read garbage that the HBM path below overwrites)
   int alo;   // ring / window row of texel row vlo (always a valid slot)
   if (FOLLOW == 2) { const unsigned a = unsigned(vlo - ob); alo = int(min(min(a, a - unsigned(kWA)), unsigned(kWA))); }   // a in [0, 2 * 52) -> a mod 52; anything else (a lane outside the window): row 52
-  else if (FOLLOW == 1) alo = (vlo - ob) & (kWRing - 1);
+  else if (FOLLOW == 1) alo = (kAbs ? vlo : vlo - ob) & (kWRing - 1);
   else alo = min(max(vlo - ob, 0), kWA - 2);
-  auto q = [&](int dr, int dc) { return (FWD ? dr : 1 - dr) * (WCP + (SKEW ? 1 : 0)) + (FWD ? dc : 1 - dc); };   // texel (v0 + sg*dr, u0 + sg*dc), relative to the corner
+  auto q = [&](int dr, int dc) { return ((FWD || kAbs) ? dr : 1 - dr) * (WCP + (SKEW ? 1 : 0)) + ((FWD || kAbs) ? dc : 1 - dc); };   // texel (v0 + sg*dr, u0 + sg*dc), relative to the corner
   const int o00 = q(0, 0);                            // texel (x0, y0)
   const int o10 = TR ? q(1, 0) : q(0, 1);             // texel (x0+1, y0)
   const int o01 = TR ? q(0, 1) : q(1, 0);             // texel (x0, y0+1)
@@ -400,17 +413,43 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
 // (Before: gather all six energies in lane 0, select (E, E+dx, E+dy, flow) in two stages of five v_cndmask, then one gradient
 // step: two DPP moves and five v_cndmask more per step, all on the dependency chain.)
 // FAST uses div_core and extends the running range guard; !FAST is the IEEE sequence.
-template <bool FAST, bool TR>
+// CROSS (round 6): the cross-lane neighbour exists for every lane (any band but a sweep's first), i.e. the comparison that reads the across
+// proposal needs no mask.  Then the three DPP moves that fetch the across proposal's energy and result (lane + 4) and the selects that use them are
+// ONE instruction each: a VOP2 instruction takes a DPP source itself -- v_cndmask_b32_dpp D = vcc ? own : across -- 6 issue slots instead of 8
+// (the compiler cannot form them: its selects carry their mask in an SGPR pair, the DPP encoding reads VCC; gfx950 has no DPP form of VOPC, so the
+// across energy still takes its own move).  Same comparisons, same operands: same bits (the lab build keeps the plain form; every product-vs-lab
+// test holds the two to each other).  The block's DPP reads stand >= 2 slots behind the writers of their sources by construction (rp is written
+// before the block and first read through DPP in its fourth slot; tools/asm_sched.py knows the instructions and re-checks).
+#define PF_DPP4 " row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+template <bool FAST, bool TR, bool CROSS = false>
 __device__ __forceinline__ float2 select_step(float e, float eC, float eCL, float2 rC, float2 cnd, bool okL, bool okT, float rEps, float step, int& emin, float& vmax) {
-  const float g1 = dpp_shl0<1>(e), g2 = dpp_shl0<2>(e);   // row_shl:n reads lane+n
+  constexpr bool kFuse = FAST && CROSS && PF_PK_ASM && PF_DPP_FUSE;
   float2 rp;                                               // this lane's proposal after its gradient step (meaningful in lanes 0 and 4)
   if (FAST) {
-    // packed fp32 (a step is issue-bound: one v_pk_* per pair of operations): (E+dx, E+dy) - E, / eps, flow - 0.5 * g
-    const f2p dg = f2p{g1, g2} - f2p{e, e};
-    const float ax = fabsf(dg.x), ay = fabsf(dg.y);
+    // (E+dx, E+dy) - E as two scalar subtractions whose first operand comes through DPP (row_shl:n reads lane+n): v_sub_f32_dpp, no separate move
+    f2p dg;
+    float amax;   // max(|dg.x|, |dg.y|)
+#if PF_PK_ASM
+    if (kFuse) {
+      // (E+dx, E+dy) - E as two subtractions whose first operand comes through DPP (row_shl:n reads lane+n): v_sub_f32_dpp, no separate moves + packed
+      // subtraction; the maximum of the magnitudes rides in the block (on values out of an asm statement the compiler would canonicalise each first)
+      float dx_, dy_;
+      // (s_nop 1: the DPP source is the energy's last addition, one slot up, and the compiler does not see a DPP read inside an asm statement --
+      // 2 wait states; tools/asm_sched.py re-derives them and fills them with independent instructions)
+      asm("s_nop 1\n\tv_sub_f32_dpp %0, %3, %3 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_sub_f32_dpp %1, %3, %3 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_max_f32_e64 %2, |%0|, |%1|" : "=&v"(dx_), "=&v"(dy_), "=&v"(amax) : "v"(e));
+      dg = f2p{dx_, dy_};
+    } else
+#endif
+    {
+      const float g1 = dpp_shl0<1>(e), g2 = dpp_shl0<2>(e);   // row_shl:n reads lane+n
+      dg = f2p{g1, g2} - f2p{e, e};
+      amax = __builtin_fmaxf(fabsf(dg.x), fabsf(dg.y));
+    }
+    // packed fp32 (a step is issue-bound: one v_pk_* per pair of operations): / eps, flow - 0.5 * g
     const f2p gq = div_core2(dg, kGradEpsilon, rEps);
-    emin = min(emin, min(__builtin_amdgcn_frexp_expf(ax), __builtin_amdgcn_frexp_expf(ay)));
-    vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(ax, ay));
+    emin = min(emin, min(__builtin_amdgcn_frexp_expf(dg.x), __builtin_amdgcn_frexp_expf(dg.y)));   // (the exponent does not see the sign)
+    vmax = __builtin_fmaxf(vmax, amax);
     // flow - step * g as ONE fused multiply-add: the product with a power of two is exact (|g| >= 2^-84 or 0 inside the guard's
     // range, so no underflow for step >= 2^-16), hence the single rounding of the FMA is the rounding of the reference's subtraction -- bit for
     // bit, signs of zero included (g = +0: f + (-0) = f) -- and one instruction less on the step's dependency chain.
@@ -419,9 +458,40 @@ __device__ __forceinline__ float2 select_step(float e, float eC, float eCL, floa
     const f2p r = __builtin_elementwise_fma(gq, f2p{-step, -step}, f2p{cnd.x, cnd.y});
     rp = make_float2(r.x, r.y);
   } else {
+    const float g1 = dpp_shl0<1>(e), g2 = dpp_shl0<2>(e);   // row_shl:n reads lane+n
     const float gx = (g1 - e) / kGradEpsilon, gy = (g2 - e) / kGradEpsilon;
     rp = make_float2(cnd.x - step * gx, cnd.y - step * gy);
   }
+#if PF_PK_ASM
+  if (kFuse && !TR) {
+    // L = the along proposal (own lane), T = the across proposal (lane + 4); okL and okT are true here
+    const bool pickL = e < eCL;
+    const float cur = pickL ? e : eC;
+    const float eT = dpp_shl0<4>(e);
+    const unsigned long long mL = __builtin_amdgcn_ballot_w64(pickL);
+    float fx, fy;
+    asm("v_cmp_nlt_f32_e32 vcc, %4, %5\n\t"                      // vcc = !(E(T) < cur)
+        "v_cndmask_b32_e64 %0, %6, %2, %8\n\t"                   // (pickL ? rL : rC).x
+        "v_cndmask_b32_e64 %1, %7, %3, %8\n\t"
+        "v_cndmask_b32_dpp %0, %2, %0, vcc" PF_DPP4 "\n\t"       // vcc ? that : rT.x  (rT = rp of lane + 4)
+        "v_cndmask_b32_dpp %1, %3, %1, vcc" PF_DPP4
+        : "=&v"(fx), "=&v"(fy) : "v"(rp.x), "v"(rp.y), "v"(eT), "v"(cur), "v"(rC.x), "v"(rC.y), "s"(mL) : "vcc");
+    return make_float2(fx, fy);
+  }
+  if (kFuse && TR) {
+    // transposed: L = the across proposal (lane + 4; okL is true here), T = the along proposal (own lane; okT per lane)
+    const float eL = dpp_shl0<4>(e);
+    float fx = rC.x, fy = rC.y, cur;
+    asm("v_cmp_nlt_f32_e32 vcc, %3, %7\n\t"                      // vcc = !(E(L) < E(C) as L sees it)
+        "s_nop 1\n\t"                                            // (VALU write of VCC -> VALU read: 2 wait states; asm_sched.py fills them)
+        "v_cndmask_b32_e32 %2, %3, %6, vcc\n\t"                  // cur = vcc ? E(C) : E(L)
+        "v_cndmask_b32_dpp %0, %4, %0, vcc" PF_DPP4 "\n\t"       // vcc ? rC : rL  (rL = rp of lane + 4)
+        "v_cndmask_b32_dpp %1, %5, %1, vcc" PF_DPP4
+        : "+v"(fx), "+v"(fy), "=&v"(cur) : "v"(eL), "v"(rp.x), "v"(rp.y), "v"(eC), "v"(eCL) : "vcc");
+    const bool pickT = okT && (e < cur);
+    return make_float2(pickT ? rp.x : fx, pickT ? rp.y : fy);
+  }
+#endif
   // lane 0: the across proposal's energy and result from lane 4; L is the along-axis proposal unless the sweep is transposed
   const float eX = dpp_shl0<4>(e);
   const float2 rX = make_float2(dpp_shl0<4>(rp.x), dpp_shl0<4>(rp.y));
@@ -447,6 +517,7 @@ template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
 __device__ __forceinline__ float dpp(float old, float src) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, BANK_MASK, false));
 }
+typedef float f2d __attribute__((ext_vector_type(2)));
 template <class G>
 struct SmemT {
   float4 rec[G::kWaves][G::kRS][kRows][G::kRQ];
@@ -676,6 +747,26 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
       }
       // Every move reads prev itself (one DPP hop from the lane that computed it; only the hop into the next row of 16 lanes
       // needs a second one): the chain prev -> proposal is 1-2 dependent DPP moves, not 4 and a select.
+#if PF_DPP64
+      // Both components of a flow move in ONE 64-bit DPP instruction (row_newbcast only: the two row_bcast:15 moves stay 32-bit): 5 issue slots
+      // instead of 8.  t15 first -- its readers, the two row_bcast:15 moves, then stand two slots behind it (the scheduling barrier ties the order down).
+      long p64 = __builtin_bit_cast(long, f2d{prev.x, prev.y}), c64 = __builtin_bit_cast(long, f2d{cnd.x, cnd.y});
+      // row_newbcast:8 -> lane 15 (lanes 12-15; the other lanes are not used): the odd group's result, for the next row of 16
+      long t64 = __builtin_amdgcn_mov_dpp(p64, 0x158, 0xF, 0x8, true);
+      __builtin_amdgcn_sched_barrier(0);
+      if (TOP != 0) {
+        c64 = __builtin_amdgcn_update_dpp(c64, p64, 0x150, 0xF, 0x9, false);   // row_newbcast:0 -> lanes 0-3 (own) and 12-15 (the row above of the odd group)
+      } else {
+        // first band: no ring value.  Lanes 4-7 of row 0 take the row's own last result as well (masked out of the selection, but
+        // evaluated: prev is only meaningful in lane 0 of a group, a wild value would send the wave through the out-of-window path
+        // in every step); with every lane written by one of the moves there is no previous value to set up.
+        c64 = __builtin_amdgcn_mov_dpp(p64, 0x150, 0xF, 0xB, false);
+      }
+      c64 = __builtin_amdgcn_update_dpp(c64, p64, 0x158, 0xF, 0x4, false);     // row_newbcast:8 -> lanes 8-11 (own, odd group)
+      const f2d c2 = __builtin_bit_cast(f2d, c64), t2 = __builtin_bit_cast(f2d, t64);
+      cnd = make_float2(c2.x, c2.y);
+      const float2 t15 = make_float2(t2.x, t2.y);
+#else
       if (TOP != 0) {
         cnd.x = dpp<0x150, 0xF, 0x9>(cnd.x, prev.x);         // row_newbcast:0 -> lanes 0-3 (own) and 12-15 (the row above of the odd group)
         cnd.y = dpp<0x150, 0xF, 0x9>(cnd.y, prev.y);
@@ -692,6 +783,7 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
       t15.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(prev.y), 0x158, 0xF, 0x8, true));
       cnd.x = dpp<0x158, 0xF, 0x4>(cnd.x, prev.x);           // row_newbcast:8 -> lanes 8-11 (own, odd group)
       cnd.y = dpp<0x158, 0xF, 0x4>(cnd.y, prev.y);
+#endif
       cnd.x = dpp<0x142, 0xE, 0x2>(cnd.x, t15.x);            // row_bcast:15 -> lanes 4-7 of rows 1..3 (lane 15 of the row of 16 above)
       cnd.y = dpp<0x142, 0xE, 0x2>(cnd.y, t15.y);
       // ---- the six proposal evaluations, one per lane ----
@@ -736,7 +828,7 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
         if (transposed) { const f3v q1 = *(__attribute__((address_space(3))) const f3v*)(rpn + 1); nb = make_float4(q1.x, q1.y, q1.z, 0.f); }
         else { const f4v q1 = rpn[1]; nb = make_float4(q1.x, q1.y, q1.z, q1.w); } }
       if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-      fin = select_step<true, TR>(e, eC, eCL, rC, cnd, okL, okT, rEps, cf.step, emin, vmax);
+      fin = select_step<true, TR, TOP != 0>(e, eC, eCL, rC, cnd, okL, okT, rEps, cf.step, emin, vmax);
       asm volatile("" : "+v"(fin.x), "+v"(fin.y));   // finish the fast result before the branch: the range test then runs beside the division, not before it
       // Only pixels that will be updated count: the lanes of a pixel without data (gate <= 0) still run the arithmetic, and
       // there the inputs are blur tails of black borders (operands ~1e-40) -- their result is discarded two lines below.
@@ -1208,8 +1300,13 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
       const int x = FWD ? cxc : W - 1 - cxc, y = FWD ? cyc : H - 1 - cyc;
       return g1 + (y * W + x);
     };
+    // ring slot of texel (u, v) (sweep order): by its IMAGE coordinates along the step axis / across the bands (d_error_fast<FOLLOW = 1>, kAbs)
+    auto ring_rc = [&](int u, int v, int& rr, int& cc) {
+      if (PF_ABS_TORUS) { rr = (FWD ? v : LB - 1 - v) & (kWRing - 1); cc = (FWD ? u : LS - 1 - u) & (kWC - 1); }
+      else { rr = (v - ob) & (kWRing - 1); cc = u & (kWC - 1); }
+    };
     auto win_store = [&](int u, int v, float2 val) {
-      const int rr = (v - ob) & (kWRing - 1), cc = u & (kWC - 1);
+      int rr, cc; ring_rc(u, v, rr, cc);
       float2* q = winw + rr * kWCp + cc;
       q[0] = val;
       if (cc == 0) q[kWC] = val;
@@ -1218,7 +1315,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
     // the same for the block of new columns, whose duplicates are rare per texel (1 in 64 / 1 in 32): wave-uniform guards around them
     // (dupc: the block's columns contain ring column 0; dupr: its rows contain ring row 0) keep the usual store at two address instructions + one write
     auto win_store_block = [&](int u, int v, float2 val, bool dupc, bool dupr) {
-      const int rr = (v - ob) & (kWRing - 1), cc = u & (kWC - 1);
+      int rr, cc; ring_rc(u, v, rr, cc);
       float2* q = winw + rr * kWCp + cc;
       q[0] = val;
       if (dupc) { if (cc == 0) q[kWC] = val; }
@@ -1398,8 +1495,12 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
               if (wok[c][k]) wv[c][k] = *q;
             }
           }
-          cdupc[c] = ((front & (kWC - 1)) + 8 > kWC) || (front & (kWC - 1)) == 0;
-          cdupr[c] = ((row0 - ob) & (kWRing - 1)) + kRectRows > kWRing || ((row0 - ob) & (kWRing - 1)) == 0;
+          {   // does the block (columns [front, front + 8), rows [row0, row0 + 24)) contain ring column 0 / ring row 0?  (lowest ring coordinate of the block)
+            const int clo = (PF_ABS_TORUS ? (FWD ? front : LS - 8 - front) : front) & (kWC - 1);
+            const int rlo = (PF_ABS_TORUS ? (FWD ? row0 : LB - kRectRows - row0) : row0 - ob) & (kWRing - 1);
+            cdupc[c] = clo + 8 > kWC || clo == 0;
+            cdupr[c] = rlo + kRectRows > kWRing || rlo == 0;
+          }
           if (n > 8) {   // the ninth column (wave-uniform: the offset along the step axis grew)
             wu[c][3] = front + 8; wvv[c][3] = row0 + lane;
             const float2* q = lane < kRectRows ? tex_ptr(wu[c][3], wvv[c][3]) : nullptr;

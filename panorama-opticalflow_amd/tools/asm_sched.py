@@ -22,7 +22,8 @@ instructions, every register dependency (RAW / WAR / WAW, incl. SCC / VCC / EXEC
 
 Hazard table (wait states = instructions or s_nop states between producer and consumer), gfx950; lower bounds taken from LLVM's
 GCNHazardRecognizer and cross-checked against the minimum distances hipcc itself leaves anywhere in the 200k-line listing of this file:
-  VALU (any: also packed, transcendental, DPP) writes a VGPR  -> DPP instruction reads it (source or the old value of its destination): 2
+  VALU (any: also packed, transcendental, DPP) writes a VGPR  -> DPP instruction reads it as its SOURCE: 2
+                                                              -> DPP move keeps it as the OLD value of the lanes its masks leave out: --dpp-old-wait (2 = LLVM's rule)
   transcendental (v_rsq / v_sqrt / v_rcp ...) writes a VGPR   -> any VALU instruction reads it: 1
   VALU writes an SGPR / VCC (v_cmp, v_readfirstlane, ...)     -> VALU instruction reads it (mask or operand): 2
   VALU writes a VGPR                                          -> v_readfirstlane / v_readlane reads it: 1;  v_permlane* reads it: 2
@@ -85,7 +86,7 @@ def split_ops(s):
 
 
 class Ins:
-    __slots__ = ("text", "mn", "defs", "uses", "kind", "known", "dpp_reads", "nop_states", "orig", "lds", "sgpr_by_valu", "is_branch")
+    __slots__ = ("text", "mn", "defs", "uses", "kind", "known", "dpp_reads", "dpp_old", "nop_states", "orig", "lds", "sgpr_by_valu", "is_branch")
 
     def __repr__(self):
         return self.text
@@ -94,7 +95,7 @@ class Ins:
 def parse(text):
     """text: one instruction (no comment).  Returns an Ins; .known = False if this pass must not move anything around it."""
     i = Ins()
-    i.text = text; i.known = True; i.dpp_reads = set(); i.nop_states = 0; i.lds = False; i.sgpr_by_valu = False; i.is_branch = False
+    i.text = text; i.known = True; i.dpp_reads = set(); i.dpp_old = set(); i.nop_states = 0; i.lds = False; i.sgpr_by_valu = False; i.is_branch = False
     parts = text.split(None, 1)
     mn = i.mn = parts[0]
     rest = parts[1] if len(parts) > 1 else ""
@@ -151,8 +152,10 @@ def parse(text):
         if mn.startswith(("v_fmac_", "v_mac_", "v_pk_fmac")): uses |= d
         if "dpp" in mn:
             i.kind = "dpp"
+            src = set(r for r in uses if r[0] == "v")   # read through the cross-lane network: the DPP hazard proper
             uses |= d                                   # lanes a DPP move does not write keep the old value (bank / row masks, no bound_ctrl)
-            i.dpp_reads = set(r for r in uses if r[0] == "v")
+            i.dpp_reads = src
+            i.dpp_old = set(r for r in d if r[0] == "v") - src
         if mn.startswith(("v_cmp_", "v_readfirstlane", "v_readlane")): i.sgpr_by_valu = True
         if mn.startswith(("v_add_co", "v_sub_co", "v_subrev_co", "v_addc_co", "v_subb_co", "v_mad_u64", "v_mad_i64", "v_div_")): i.known = False   # second (scalar) destination: not modelled
         if "exec" in defs: i.known = False
@@ -173,6 +176,7 @@ def hazard_need(prod, cons, reg, pk_wait):
     if reg[0] == "v":
         if prod.kind in ("valu", "trans", "dpp"):
             if reg in cons.dpp_reads: need = max(need, 2)
+            if reg in cons.dpp_old: need = max(need, DPP_OLD_WAIT)
             if cons.mn.startswith(("v_readfirstlane", "v_readlane")): need = max(need, 1)
             if cons.mn.startswith("v_permlane"): need = max(need, 2)
         if prod.kind == "trans" and cons.kind in ("valu", "trans", "dpp"): need = max(need, 1)
@@ -184,6 +188,7 @@ def hazard_need(prod, cons, reg, pk_wait):
     return need
 
 
+DPP_OLD_WAIT = 2   # --dpp-old-wait: wait states between a VALU write of a register and a DPP move that only keeps it as the OLD value of masked-off lanes
 HAZ_READ_MAX = 2   # the largest entry of the table: what a value entering the block may still need
 
 
@@ -214,6 +219,7 @@ def schedule_block(ins_with_nops, ldsregs, pk_wait, allow_move):
     for k, i in enumerate(seq):
         hz = set()
         if i.dpp_reads: hz |= i.dpp_reads
+        if i.dpp_old and DPP_OLD_WAIT: hz |= i.dpp_old
         if i.kind in ("valu", "trans", "dpp"): hz |= set(r for r in i.uses if r[0] in "vs" or r == "vcc")
         if "_lds_" in i.mn: hz.add("m0")
         if any(r not in first_writer for r in hz): entry_min[k] = min(i.orig, HAZ_READ_MAX)
@@ -246,6 +252,61 @@ def schedule_block(ins_with_nops, ldsregs, pk_wait, allow_move):
         i = seq[pick]; done[pick] = True; remaining -= 1
         slot_of[pick] = slot; order.append(pick); out.append(i); slot += 1
         for r in i.defs: last_writer[r] = pick
+    # ---- second pass: fill the wait states that are left by SINKING an earlier instruction into them ----
+    # The list scheduler above only pulls instructions UP.  A wait state in front of a consumer late in the block (the DPP reads of the step's
+    # energy, one slot behind the v_cmp that follows its last addition) has nothing below it to pull up -- but an instruction further up whose
+    # result is not needed until later (an exponent for the range guard, a compare whose mask is combined at the end) can be issued THERE
+    # instead: the slot it leaves closes up, the wait state disappears.  Greedy, every candidate move is checked with the full re-check below
+    # (dependencies in their old order, every hazard, every entry distance) before it is taken; LDS instructions, waits and branches never move.
+    # (Sinking an instruction that merely READS or writes a register some LDS read loads to BEHIND an s_waitcnt is safe -- a wait only makes more
+    # values valid; the rule "never across a wait" protects the other direction.  So the sink pass drops that one ordering: instruction -> later wait
+    # through the LDSREGS pseudo register alone.  Real register dependencies -- e.g. on the ds_read that next loads the register -- stay.)
+    def depends_sink(a, b):
+        if b.kind == "wait" and a.kind != "wait":
+            au = a.uses - {"LDSREGS"}
+            return bool(a.defs & (b.uses | b.defs)) or bool(au & b.defs)
+        return depends(a, b)
+    preds_sink = [[a for a in preds[b] if depends_sink(seq[a], seq[b])] for b in range(n)]
+    index_of = {id(i): k for k, i in enumerate(seq)}
+    def valid(lst):
+        pos_of, sl, lw = {}, 0, {}
+        for x in lst:
+            if x.kind != "nop": pos_of[index_of[id(x)]] = sl
+            sl += 1
+        for b in range(n):
+            for a in preds_sink[b]:
+                if pos_of[a] >= pos_of[b]: return False
+        for x in lst:
+            if x.kind == "nop": continue
+            k = index_of[id(x)]
+            if pos_of[k] < entry_min[k]: return False
+            for r in x.uses:
+                if r in lw:
+                    need = hazard_need(seq[lw[r]], x, r, pk_wait)
+                    if need and pos_of[k] - pos_of[lw[r]] - 1 < need: return False
+            for r in x.defs: lw[r] = k
+        return True
+    sunk = 0
+    if allow_move and nops_new:
+        again = True
+        while again:
+            again = False
+            for pos, x in enumerate(out):
+                if x.kind != "nop": continue
+                for cp in range(pos - 1, -1, -1):
+                    c = out[cp]
+                    if c.kind not in ("valu", "salu", "trans"): continue
+                    cand = out[:cp] + out[cp + 1:pos] + [c] + out[pos + 1:]
+                    if valid(cand):
+                        out = cand; again = True; sunk += 1; nops_new -= 1; slot -= 1
+                        break
+                if again: break
+        if sunk:   # positions changed: rebuild the bookkeeping the checks below use
+            order, sl = [], 0
+            for x in out:
+                if x.kind != "nop":
+                    k = index_of[id(x)]; order.append(k); slot_of[k] = sl
+                sl += 1
     # values that LEAVE the block: the next block was scheduled by hipcc in the belief that every producer here sits at least as far from the
     # block's end as it did; with the wait states gone (or instructions pulled up in front of it) a producer may have come closer -- pad the
     # end until every producer keeps min(its old distance, the table's maximum)
@@ -265,7 +326,7 @@ def schedule_block(ins_with_nops, ldsregs, pk_wait, allow_move):
     # ---- re-check: dependencies in their old order, hazards satisfied ----
     newpos = {k: p for p, k in enumerate(order)}
     for b in range(n):
-        for a in preds[b]:
+        for a in (preds_sink[b] if sunk else preds[b]):
             assert newpos[a] < newpos[b], "dependency broken: %s -> %s" % (seq[a].text, seq[b].text)
     lw = {}
     for k in order:
@@ -352,7 +413,10 @@ def main():
     ap.add_argument("--pk-wait", type=int, default=0)
     ap.add_argument("--no-move", action="store_true", help="only drop the wait states the table does not ask for; never reorder")
     ap.add_argument("--report")
+    ap.add_argument("--dpp-old-wait", type=int, default=2, help="wait states behind the writer of a partial DPP move's OLD value (LLVM: 2, like the source; tests/micro/dpp_old_probe.hip: the hardware needs none)")
     a = ap.parse_args()
+    global DPP_OLD_WAIT
+    DPP_OLD_WAIT = a.dpp_old_wait
     lines = open(a.inp).read().split("\n")
     out, total, _ = process(lines, a.kernels, a.pk_wait, not a.no_move, a.report)
     open(a.out, "w").write("\n".join(out))

@@ -282,7 +282,10 @@ def main():
     k1 = next(n for n in range(k0 + 1, len(lines)) if lines[n].strip().startswith("s_endpgm"))
     body = lines[k0:k1]
     marks = [n for n, l in enumerate(body) if "row_newbcast:0" in l]
-    marks = marks[::2]                       # two moves (x, y) per step
+    if any("v_mov_b64_dpp" in body[n] for n in marks):
+        marks = [n for n in marks if "v_mov_b64_dpp" in body[n]]   # round 6: ONE 64-bit move per step
+    else:
+        marks = marks[::2]                   # two moves (x, y) per step
     loops = [marks[i:i + 8] for i in range(0, len(marks) - 7, 8)]
     lone = analyse(body, loops, lat, issue, a.clock_ghz)
     guide = analyse(body, loops, LAT_GUIDE, ISSUE_GUIDE, a.clock_ghz)
