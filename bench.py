@@ -238,7 +238,9 @@ def main():
 
     # a context drives 4 HIP streams (front end, two flow directions, blend ramp) next to torch's and RCCL's: with the
     # runtime's default of 4 hardware queues two of them could share a queue and serialise
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24" if not args.no_extras else str(min(24, max(8, 4 * args.concurrent))))
+    # (the config5_strong leg -- 8 pairs in flight on two batch lanes beside the main context -- needs them with or without the extras: with 8 queues
+    # it ran at 1,650 instead of 2,454 Mpix/s in round 5's driver-command line, profiles/r05_bench_driver_cmd_line.json)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24" if (not args.no_extras or args.pairs_total > 0) else str(min(24, max(8, 4 * args.concurrent))))
     import numpy as np
     import torch  # first: the HIP runtime it loads is the one libpanoflow.so then binds to
     import torch.distributed as dist
@@ -405,9 +407,9 @@ def main():
         # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is
         # READ FROM A COMMITTED FILE -- the rocprofv3 --pmc passes of this same command (profiles/, see its note) -- and labelled so.
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r05_pmc_bench.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r06_pmc_bench.json")
         if not os.path.exists(pmc_path):
-            pmc_path = os.path.join(ROOT, "profiles", "r04_pmc_bench.json")
+            pmc_path = os.path.join(ROOT, "profiles", "r05_pmc_bench.json")
         if (cols, rows, args.alg) == (9000, 4000, "pixflow_low") and os.path.exists(pmc_path):
             try:
                 pl = json.load(open(pmc_path))["sweep_per_launch"]
@@ -441,24 +443,27 @@ def main():
 
         if world == 1 and not args.no_extras and args.concurrent <= 1:
             # ---- the honest bound of the sweeps: a dependency chain of `swept` steps per direction x the time of one step
-            # of a lone band (measured live); hw_floor_us = the same chain priced with the guide's instruction latencies
-            # (profiles/r04_sweep_step_isa.txt) ----
+            # of a lone band (measured live); isa_model_us = the product's step as one wave in order, priced with the lone-wave slot
+            # measurements (profiles/r06_sweep_step_isa.txt) ----
             t_step = measure_t_step(pf, ctx, np)
             if sweep_ms_per_dir:
                 bound_ms = swept * t_step * 1e-3
                 lb = {"swept_steps": swept, "t_step_us": round(t_step, 4), "bound_ms": round(bound_ms, 3),
                       "measured_sweep_ms_per_direction": round(sweep_ms_per_dir, 3), "frac_of_bound": round(bound_ms / sweep_ms_per_dir, 4),
                       "note": "bound = swept_steps x t_step of ONE lone band (8 rows x 4096, HIP events); the two directions run concurrently"}
-                isa = os.path.join(ROOT, "profiles", "r05_sweep_step_isa.json")
-                if not os.path.exists(isa):
-                    isa = os.path.join(ROOT, "profiles", "r04_sweep_step_isa.json")
+                isa = os.path.join(ROOT, "profiles", "r06_sweep_step_isa.json")
                 if os.path.exists(isa):
                     try:
                         hw = json.load(open(isa))
-                        lb["hw_floor_us"] = hw["hw_floor_us"]
-                        lb["hw_floor_ms"] = round(swept * hw["hw_floor_us"] * 1e-3, 3)
-                        lb["frac_of_hw_floor"] = round(swept * hw["hw_floor_us"] * 1e-3 / sweep_ms_per_dir, 4)
-                        lb["hw_floor_source"] = "from_file: profiles/" + os.path.basename(isa).replace(".json", ".txt") + " (loop-carried dependency chain of one step of compute_band<1,...>, priced with MI355X_MICROARCH.md latencies)"
+                        # the issue-slot model of ONE wave in order (tests/micro/isa_chain.py on the product's assembly, priced with the lone-wave slot
+                        # measurements of profiles/r06_slot_model.txt): a floor of the step only while it stays below the measured t_step -- said so here
+                        lb["isa_model_us"] = hw["isa_model_us"]
+                        lb["isa_model_issue_slots_per_step"] = hw.get("issue_slots_per_step")
+                        lb["isa_model_ms"] = round(swept * hw["isa_model_us"] * 1e-3, 3)
+                        lb["t_step_vs_isa_model"] = round(t_step / hw["isa_model_us"], 4)
+                        lb["isa_model_is_below_measured_step"] = bool(hw["isa_model_us"] <= t_step)
+                        lb["frac_of_isa_model"] = round(swept * hw["isa_model_us"] * 1e-3 / sweep_ms_per_dir, 4)
+                        lb["isa_model_source"] = "from_file: profiles/r06_sweep_step_isa.txt (one wave issuing the product's step in order, one slot per ~4.46 cycles: profiles/r06_slot_model.txt)"
                     except Exception:
                         pass
                 res["roofline"]["latency_bound"] = lb
@@ -526,7 +531,9 @@ def main():
                                    "one_thread": {"value": round(smp / t1, 4), "unit": "Mpix/s", "cores": 1, "seconds": round(t1, 2)},
                                    "pairs_in_parallel": ({"value": round((1 + len(more)) * smp / t3, 4), "unit": "Mpix/s", "cores": 2 * (1 + len(more)), "pairs": 1 + len(more), "seconds": round(t3, 2),
                                                           "note": "SURVEY 8(d) leg (iii), config 5: the same sub-strip of the 8 pairs (seeds 1234..1241) at the same time, two threads each"} if t3 else None),
-                                   "host_threads_available": os.cpu_count()}
+                                   "host_threads_available": os.cpu_count(),
+                                   "which_is_the_configurations": "`value` here = the bounded SAMPLE (a 2000-column sub-strip of the configuration's pair, measured by this run); the figure for the "
+                                                                  "configuration itself -- the whole 9000x4000 pair -- is `full_pair` (read from a committed file, measured once on a GPU box's host)"}
             fp = os.path.join(ROOT, "profiles", "r05_cpu_full_pair.json")
             if (cols, rows, args.alg) == (9000, 4000, "pixflow_low") and os.path.exists(fp):
                 try:   # the WHOLE pair once on a GPU box's host (tests/micro/cpu_full_pair.py); read from the committed file, not run here (minutes)

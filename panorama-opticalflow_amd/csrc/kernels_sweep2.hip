@@ -84,16 +84,8 @@ struct SwGeom {
 };
 using SwLatency = SwGeom<4, 1>;
 using SwWide = SwGeom<8, 2>;
-#ifndef PF_PRIO_C
-#define PF_PRIO_C 3   // s_setprio of the compute waves / of the helper waves (above another kernel's waves on the same CU)
-#endif
-#ifndef PF_PRIO_H
-#define PF_PRIO_H 1
-#endif
-#ifndef PF_WCP_EXTRA
-#define PF_WCP_EXTRA 3
-#endif
-constexpr int kWCp = kWC + PF_WCP_EXTRA; // row stride of the window: ring column 0 is stored a second time behind column 63, so that the
+constexpr int kPrioCompute = 3, kPrioHelper = 1;   // s_setprio of the compute waves / of the helper waves (above another kernel's waves on the same CU)
+constexpr int kWCp = kWC + 3; // row stride of the window: ring column 0 is stored a second time behind column 63, so that the
                               // right-hand texel of a bilinear footprint is always the NEXT slot (no second ring wrap on the address chain).
                               // 67, not 65: row r of a band sits at column s - r, so with a stride of 65 float2 the gathers of all 8 rows of a
                               // step (equal flows) fall on the SAME LDS banks (64 r float2 apart); 67 puts them 4 banks apart (a texel pair is
@@ -102,60 +94,33 @@ constexpr int kWCp = kWC + PF_WCP_EXTRA; // row stride of the window: ring colum
 // the launch: 2 s + 1000x the expected duration) sits in LDS and is only looked at every 1024 polls.  A band that is merely
 // slow -- several contexts oversubscribing the GPU, a predecessor workgroup not scheduled yet -- therefore never raises
 // PF_ERR_TIMEOUT; a genuinely stuck one still does instead of hanging the GPU.
-#ifndef PF_DPP_FUSE
-#define PF_DPP_FUSE 1    // the selection's DPP moves folded into its compares / selects (A/B switch of round 6)
-#endif
-#ifndef PF_ABS_TORUS
-#define PF_ABS_TORUS 1   // the latency form's gather window addressed by image coordinates (A/B switch of round 6)
-#endif
-#ifndef PF_DPP64
-#define PF_DPP64 1   // the proposals' distribution with 64-bit DPP moves (A/B switch of round 6)
-#endif
-#ifndef PF_SWEEP_UNROLL
-#define PF_SWEEP_UNROLL 8
-#endif
-#ifndef PF_MARGIN
-#ifndef PF_MARGIN_X
-#define PF_MARGIN_X 0
-#endif
-#ifndef PF_MARGIN_TX
-#define PF_MARGIN_TX 1   // the throughput form's margin across workgroups
-#endif
-#ifndef PF_MARGIN_IN
-#define PF_MARGIN_IN 0
-#endif
-#define PF_MARGIN(top) ((top) == 2 ? PF_MARGIN_X : PF_MARGIN_IN)   // extra columns to fall behind after catching up with the producer (measured: 0 inside a workgroup; across
-                                                                  // workgroups 1 until round 4, 0 since the window follows the flow: dense pair 46.75 -> 46.4 ms, strip 22.13 -> 22.02)
-#define PF_MARGIN_T(top) ((top) == 2 ? PF_MARGIN_TX : PF_MARGIN_IN)
-#endif
-#ifndef PF_LOADER_IDLE
-#define PF_LOADER_IDLE 8  // > 0: the loader's ring-full iteration is a short s_sleep of this length instead of a pass through its predicated-off body
-#endif
-#ifndef PF_DRAIN_CHUNK
-#define PF_DRAIN_CHUNK 1  // 1: the drainer writes whole 8-step chunks instead of whatever has been produced
-#endif
-#ifndef PF_TF_ADDR_ASM
-#define PF_TF_ADDR_ASM 0   // throughput form: the window address as one three-instruction block (latency form: always)
-#endif
-#ifndef PF_TF_SUMSQ_ASM
-#define PF_TF_SUMSQ_ASM 0  // throughput form: the two sum-of-squares chains as single blocks (latency form: always)
-#endif
-#ifndef PF_SELF_PUBLISH
-#define PF_SELF_PUBLISH 0 // 1: the last compute wave of a workgroup stores its hand-off granules itself (experiment: measured, slower, see compute_band)
-#endif
-#ifndef PF_DRAIN_SLEEP
-#define PF_DRAIN_SLEEP 8  // drainer: s_sleep between two looks at the bands' step counters when no chunk was complete
-#endif
-#ifndef PF_PUB_SLEEP
-#define PF_PUB_SLEEP 1    // publisher wave: s_sleep between two looks at the last band's step counter
-#endif
-#ifndef PF_POLL_SLEEP
-#define PF_POLL_SLEEP 1   // poller wave: s_sleep between two polls of the previous workgroup's granules
-#endif
+// Hand-off parameters (each swept on the hardware, profiles/r04_sweep_helpers_ab.txt, r05 same-box A/Bs; the rejected alternatives -- a last band that
+// stores its granules itself, asm address / sum-of-squares blocks in the throughput form, other priorities / sleeps / window strides -- are kept as
+// profiles/r06_removed_experiment_macros.patch, not as macros in the product source):
+constexpr int kMarginAcross = 0;    // extra columns a latency-form band falls behind after it has waited for a granule ACROSS workgroups (1 until round 4)
+constexpr int kMarginAcrossT = 1;   // ... the throughput form's
+constexpr int kLoaderIdleSleep = 8; // a loader whose ring is full sleeps this long instead of walking its predicated-off body
+constexpr int kDrainSleep = 8;      // drainer: s_sleep between two looks at the bands' step counters when no chunk was complete
+constexpr int kPubSleep = 1;        // publisher wave: s_sleep between two looks at the last band's step counter
+constexpr int kPollSleep = 1;       // poller wave: s_sleep between two polls of the previous workgroup's granules
 #define PF_STR2(x) #x
 #define PF_STR(x) PF_STR2(x)   // ~0.2 s of polling: a stuck band raises ctrl[1] instead of hanging the GPU
 
 struct F2x2 { float a, b, c, d; } __attribute__((aligned(8)));
+#ifdef PF_EXPERIMENTS
+// lab build only (PANOFLOW_POISON_LDS=1, tests/test_gpu_hygiene.py): every sweep workgroup fills its gather windows with NaN / inf / +-1e38 before the
+// loaders start -- a result that depends on a window slot its loader never wrote (or on what a pixel that is not updated reads there) then differs
+// from the oracle instead of depending on what the previous kernel happened to leave in LDS
+__device__ int g_poison_lds;
+__device__ __forceinline__ void poison_window(float2* win, int n) {
+  if (g_poison_lds == 0) return;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int k = i & 3;
+    const float v = k == 0 ? __builtin_nanf("") : (k == 1 ? __builtin_inff() : (k == 2 ? 1.0e38f : -1.0e38f));
+    win[i] = make_float2(v, (i & 4) ? -v : v);
+  }
+}
+#endif
 #ifdef PF_SWEEP_STATS
 // diagnostics build only (var_libs/lib_stats.so): [0] wave-steps of the latency form, [1] its gather rounds (one per step) in which >= 1 lane of a
 // pixel that is updated left the LDS gather window (the whole wave then takes the HBM path), [2] / [3] the same for the throughput form (two
@@ -299,12 +264,12 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   // FOLLOW == 1 (the product's latency form, round 6): the torus is addressed by the texel's IMAGE coordinates instead -- the footprint's lower corner
   // is (x0, y0) whatever the sweep's direction, so neither the mirror subtractions of a backward sweep nor the window-origin subtraction stand
   // on the address chain (1 instruction per step forward, 2 backward), and the +1 neighbours are the next slots in both directions.
-  constexpr bool kAbs = PF_ABS_TORUS && FOLLOW == 1;
+  constexpr bool kAbs = FOLLOW == 1;
   const int cxl = (FWD || kAbs) ? x0 : W - 2 - x0, cyl = (FWD || kAbs) ? y0 : H - 2 - y0;
   const int ulo = TR ? cyl : cxl, vlo = TR ? cxl : cyl;
   // out-of-window lanes are clamped to a valid window row (they read garbage that the HBM path below overwrites)
   int alo;   // ring / window row of texel row vlo (always a valid slot)
-  if (FOLLOW == 2) { const unsigned a = unsigned(vlo - ob); alo = int(min(min(a, a - unsigned(kWA)), unsigned(kWA))); }   // a in [0, 2 * 52) -> a mod 52; anything else (a lane outside the window): row 52
+  if (FOLLOW == 2) { const unsigned a = unsigned(vlo - ob); alo = int(min(min(a, a - unsigned(kWA)), unsigned(kWA - 1))); }   // a in [0, 2 * 48) -> a mod 48; anything else (a lane outside the window, overwritten by the HBM path): row 47, so that its footprint stays inside this band's own window rows
   else if (FOLLOW == 1) alo = (kAbs ? vlo : vlo - ob) & (kWRing - 1);
   else alo = min(max(vlo - ob, 0), kWA - 2);
   auto q = [&](int dr, int dc) { return ((FWD || kAbs) ? dr : 1 - dr) * (WCP + (SKEW ? 1 : 0)) + ((FWD || kAbs) ? dc : 1 - dc); };   // texel (v0 + sg*dr, u0 + sg*dc), relative to the corner
@@ -323,7 +288,7 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   // statement whose result the next instruction reads (4 cycles for a lone wave: as much as the instruction saved).
   const unsigned colSum = unsigned(SKEW ? ulo + (FOLLOW == 2 ? vlo : alo) : ulo);
   unsigned cornerAddr;
-  if (!SKEW || PF_TF_ADDR_ASM) {
+  if (!SKEW) {
     asm("v_and_b32 %0, %5, %1\n\tv_lshl_add_u32 %0, %0, 3, %2\n\tv_mad_u32_u24 %0, %3, %4, %0"
         : "=&v"(cornerAddr) : "v"(colSum), "s"((unsigned)(size_t)win), "v"(alo), "s"(unsigned(WCP * sizeof(float2))), "n"(kWC - 1));
   } else {
@@ -339,7 +304,7 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
   // ---- B ----
   const float xR = __builtin_amdgcn_fractf(cx), yR = __builtin_amdgcn_fractf(cy);   // cx, cy >= 0: exactly cx - float(int(cx))
   float s2;
-  if (PF_PK_ASM && (!SKEW || PF_TF_SUMSQ_ASM)) s2 = sumsq_diff2(f2p{bx, by}, fd);   // |blurred - flow|^2: one block (exact_forms.hpp)
+  if (PF_PK_ASM && !SKEW) s2 = sumsq_diff2(f2p{bx, by}, fd);   // |blurred - flow|^2: one block (exact_forms.hpp)
   else {
     const f2p df = f2p{bx, by} - fd;
     const f2p df2 = df * df;
@@ -385,7 +350,7 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
     py = a1 + a2 * xR + a3 * yR; ly = a4 * xR * yR;
   }
   float d2;
-  if (PF_PK_ASM && (!SKEW || PF_TF_SUMSQ_ASM)) d2 = sumsq_diff2_sum(f2p{i0x, i0y}, f2p{px, py}, f2p{lx, ly});
+  if (PF_PK_ASM && !SKEW) d2 = sumsq_diff2_sum(f2p{i0x, i0y}, f2p{px, py}, f2p{lx, ly});
   else {
     const float i1x = px + lx, i1y = py + ly;
     f2p di, di2;   // (i0 - i1)^2 per channel: one asm block, see exact_forms.hpp
@@ -423,33 +388,34 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
 #define PF_DPP4 " row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1"
 template <bool FAST, bool TR, bool CROSS = false>
 __device__ __forceinline__ float2 select_step(float e, float eC, float eCL, float2 rC, float2 cnd, bool okL, bool okT, float rEps, float step, int& emin, float& vmax) {
-  constexpr bool kFuse = FAST && CROSS && PF_PK_ASM && PF_DPP_FUSE;
+  [[maybe_unused]] constexpr bool kFuse = FAST && CROSS && PF_PK_ASM;
   float2 rp;                                               // this lane's proposal after its gradient step (meaningful in lanes 0 and 4)
   if (FAST) {
     // (E+dx, E+dy) - E as two scalar subtractions whose first operand comes through DPP (row_shl:n reads lane+n): v_sub_f32_dpp, no separate move
+    // Range guard of the division by eps, taken on the ENERGIES (round 6) instead of on their differences: every lane holds an energy (lanes 1, 2
+    // / 5, 6 the ones at +dx, +dy), the guard is wave-wide, and two energies that are each zero or of magnitude in [2^-71, 2^99] differ by zero or by
+    // at least an ulp of 2^-71 = 2^-94 and by at most 2^100 -- inside div_core's proven range [2^-95, 2^100].  One exponent (biased by 24 so that it
+    // shares the guard's threshold: exponent >= -94 <=> value >= 2^-95) and one operand of the max3 instead of two exponents, a minimum and a maximum.
+    emin = min(emin, __builtin_amdgcn_frexp_expf(e) - 24);
+    vmax = __builtin_fmaxf(vmax, fabsf(e));
     f2p dg;
-    float amax;   // max(|dg.x|, |dg.y|)
 #if PF_PK_ASM
     if (kFuse) {
       // (E+dx, E+dy) - E as two subtractions whose first operand comes through DPP (row_shl:n reads lane+n): v_sub_f32_dpp, no separate moves + packed
-      // subtraction; the maximum of the magnitudes rides in the block (on values out of an asm statement the compiler would canonicalise each first)
+      // subtraction.  (s_nop 1: the DPP source is the energy's last addition, one slot up, and the compiler does not see a DPP read inside an asm
+      // statement -- 2 wait states; tools/asm_sched.py re-derives them and fills them with independent instructions)
       float dx_, dy_;
-      // (s_nop 1: the DPP source is the energy's last addition, one slot up, and the compiler does not see a DPP read inside an asm statement --
-      // 2 wait states; tools/asm_sched.py re-derives them and fills them with independent instructions)
-      asm("s_nop 1\n\tv_sub_f32_dpp %0, %3, %3 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_sub_f32_dpp %1, %3, %3 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-          "v_max_f32_e64 %2, |%0|, |%1|" : "=&v"(dx_), "=&v"(dy_), "=&v"(amax) : "v"(e));
+      asm("s_nop 1\n\tv_sub_f32_dpp %0, %2, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_sub_f32_dpp %1, %2, %2 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+          : "=&v"(dx_), "=&v"(dy_) : "v"(e));
       dg = f2p{dx_, dy_};
     } else
 #endif
     {
       const float g1 = dpp_shl0<1>(e), g2 = dpp_shl0<2>(e);   // row_shl:n reads lane+n
       dg = f2p{g1, g2} - f2p{e, e};
-      amax = __builtin_fmaxf(fabsf(dg.x), fabsf(dg.y));
     }
     // packed fp32 (a step is issue-bound: one v_pk_* per pair of operations): / eps, flow - 0.5 * g
     const f2p gq = div_core2(dg, kGradEpsilon, rEps);
-    emin = min(emin, min(__builtin_amdgcn_frexp_expf(dg.x), __builtin_amdgcn_frexp_expf(dg.y)));   // (the exponent does not see the sign)
-    vmax = __builtin_fmaxf(vmax, amax);
     // flow - step * g as ONE fused multiply-add: the product with a power of two is exact (|g| >= 2^-84 or 0 inside the guard's
     // range, so no underflow for step >= 2^-16), hence the single rounding of the FMA is the rounding of the reference's subtraction -- bit for
     // bit, signs of zero included (g = +0: f + (-0) = f) -- and one instruction less on the step's dependency chain.
@@ -566,7 +532,7 @@ __device__ __forceinline__ void st_cnt(int* p, int v) {
 // wave-uniform, so the per-step "is my top neighbour there" test is two scalar instructions.
 template <class G, int TOP, bool TR, bool FWD, bool SPARSE>
 __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restrict__ g1, int W, int H, int nsteps, int w, int band,
-                                             int nact, bool publishes, float rW, float rEps, const SolverCoef cf, int uLo, int LSv, unsigned long long* bnd_out = nullptr) {
+                                             int nact, bool publishes, float rW, float rEps, const SolverCoef cf, int uLo, int LSv) {
   constexpr int kWaves = G::kWaves, kRS = G::kRS, kOS = G::kOS, kWA = G::kWA;
   constexpr int transposed = TR ? 1 : 0, forward = FWD ? 1 : 0;
   const int lane = threadIdx.x & 63;
@@ -590,15 +556,7 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
   // that computed it (lane 0 of a group), no select.
   const int kk = k & 3;
   const float addx = (kk == 1) ? kGradEpsilon : 0.0f, addy = (kk == 2) ? kGradEpsilon : 0.0f;
-#if PF_SELF_PUBLISH
-  // EXPERIMENT (round-4 review, next #3; profiles/r05_handoff_ab.txt): the workgroup's last band stores its granules itself -- no publisher
-  // wave in the relay -- at the price of an exec-masked 8-byte global store per step on a wave that is on the sweep's dependency chain
-  const bool selfPub = publishes && (w == kWaves - 1);
-  const bool lastPub = false;
-  const bool pubLane = (threadIdx.x & 63) == 8 * (kRows - 1);
-#else
   const bool lastPub = publishes && (w == kWaves - 1);
-#endif
   const bool hasNext = (w + 1 < nact);
   // where row 0's top neighbour of column c lives, and the counter that says how many columns are there
   const int wp = (w > 0) ? w - 1 : 0;
@@ -710,7 +668,7 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
     lds_u64* topNext = (lds_u64*)top_slot(s0 + kChunk);                     // ... of the next chunk's first column
     asm volatile("" : "+v"(recChunk), "+v"(recNext), "+v"(outChunk));
     if (TOP != 0) asm volatile("" : "+v"(topChunk), "+v"(topNext));
-#pragma unroll PF_SWEEP_UNROLL
+#pragma unroll
     for (int j = 0; j < kChunk; ++j) {
       const int s = s0 + j;
       // ---- this lane's proposal: lanes 0-3 of a group <- the group's own last result (its lane 0), lanes 4-7 <- the result of
@@ -723,7 +681,7 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
             // at the edge of the producer: wait for this column (across workgroups: and the next one, i.e. fall one more
             // column behind, so that the following steps find their top value already read despite the HBM hop's jitter).
             // No early exit from the hot loop: a timeout only marks the band dead (checked once per chunk).
-            const int need = (s + 1 + PF_MARGIN(TOP) < LSv) ? s + 1 + PF_MARGIN(TOP) : LSv;
+            const int need = (s + 1 + (TOP == 2 ? kMarginAcross : 0) < LSv) ? s + 1 + (TOP == 2 ? kMarginAcross : 0) : LSv;
             int spins = 0;
 #ifdef PF_SWEEP_STATS
             ++statHits;
@@ -747,7 +705,6 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
       }
       // Every move reads prev itself (one DPP hop from the lane that computed it; only the hop into the next row of 16 lanes
       // needs a second one): the chain prev -> proposal is 1-2 dependent DPP moves, not 4 and a select.
-#if PF_DPP64
       // Both components of a flow move in ONE 64-bit DPP instruction (row_newbcast only: the two row_bcast:15 moves stay 32-bit): 5 issue slots
       // instead of 8.  t15 first -- its readers, the two row_bcast:15 moves, then stand two slots behind it (the scheduling barrier ties the order down).
       long p64 = __builtin_bit_cast(long, f2d{prev.x, prev.y}), c64 = __builtin_bit_cast(long, f2d{cnd.x, cnd.y});
@@ -766,24 +723,6 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
       const f2d c2 = __builtin_bit_cast(f2d, c64), t2 = __builtin_bit_cast(f2d, t64);
       cnd = make_float2(c2.x, c2.y);
       const float2 t15 = make_float2(t2.x, t2.y);
-#else
-      if (TOP != 0) {
-        cnd.x = dpp<0x150, 0xF, 0x9>(cnd.x, prev.x);         // row_newbcast:0 -> lanes 0-3 (own) and 12-15 (the row above of the odd group)
-        cnd.y = dpp<0x150, 0xF, 0x9>(cnd.y, prev.y);
-      } else {
-        // first band: no ring value.  Lanes 4-7 of row 0 take the row's own last result as well (masked out of the selection, but
-        // evaluated: prev is only meaningful in lane 0 of a group, a wild value would send the wave through the out-of-window path
-        // in every step); with every lane written by one of the moves there is no previous value to set up.
-        cnd.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(prev.x), 0x150, 0xF, 0xB, false));
-        cnd.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(prev.y), 0x150, 0xF, 0xB, false));
-      }
-      float2 t15;
-      // row_newbcast:8 -> lane 15 (lanes 12-15; the other lanes are not used): the odd group's result, for the next row of 16
-      t15.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(prev.x), 0x158, 0xF, 0x8, true));
-      t15.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(prev.y), 0x158, 0xF, 0x8, true));
-      cnd.x = dpp<0x158, 0xF, 0x4>(cnd.x, prev.x);           // row_newbcast:8 -> lanes 8-11 (own, odd group)
-      cnd.y = dpp<0x158, 0xF, 0x4>(cnd.y, prev.y);
-#endif
       cnd.x = dpp<0x142, 0xE, 0x2>(cnd.x, t15.x);            // row_bcast:15 -> lanes 4-7 of rows 1..3 (lane 15 of the row of 16 above)
       cnd.y = dpp<0x142, 0xE, 0x2>(cnd.y, t15.y);
       // ---- the six proposal evaluations, one per lane ----
@@ -832,7 +771,7 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
       asm volatile("" : "+v"(fin.x), "+v"(fin.y));   // finish the fast result before the branch: the range test then runs beside the division, not before it
       // Only pixels that will be updated count: the lanes of a pixel without data (gate <= 0) still run the arithmetic, and
       // there the inputs are blur tails of black borders (operands ~1e-40) -- their result is discarded two lines below.
-      if (__builtin_expect(__any((emin < cf.guard_min || !(vmax <= 0x1p100f)) && gated), 0)) {
+      if (__builtin_expect(__any((emin < cf.guard_min || !(vmax <= 0x1p99f)) && gated), 0)) {
 #ifdef PF_SWEEP_STATS
         ++statRedo;
 #endif
@@ -861,12 +800,6 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
         asm volatile("" : "+v"(tvN));   // the register PAIR as one operand: two 32-bit operands cost two v_mov per step to split and rejoin it
         tv = tvN;
       }
-#if PF_SELF_PUBLISH
-      if (selfPub) {
-        const int cx = s - (kRows - 1);
-        if (pubLane && cx >= 0 && cx < LSv) __hip_atomic_store(bnd_out + cx, pack2(fin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-#endif
       prev = fin;   // valid in lane 0 of each group.  "no pixel" steps hand on their zero record: never used as a neighbour (masked / outside the image)
       // ---- publish: result ring (lane 0 of a group stores to the slot, the other lanes to a scratch slot of their own), then the step counter ----
       outChunk[j * kRows] = f2w{fin.x, fin.y};
@@ -1179,7 +1112,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
     PF_BOFF(rec, bo); PF_BOFF(g1, bo); PF_BOFF(flow, bo); PF_BOFF(boundary, bo); PF_BOFF(ctrl, bo); PF_BOFF(g0, bo); PF_BOFF(blurred, bo); PF_BOFF(gate, bo);
     if (prepcnt != nullptr) PF_BOFF(prepcnt, bo);
   }
-  constexpr int kWaves = G::kWaves, kRS = G::kRS, kOS = G::kOS, kWA = G::kWA, kLoadAhead = G::kLoadAhead, kLoaders = G::kLoaders;
+  constexpr int kWaves = G::kWaves, kRS = G::kRS, kOS = G::kOS, kLoadAhead = G::kLoadAhead, kLoaders = G::kLoaders;
   static_assert(MODE == 0 || G::kBPW == 1, "the experimental record paths exist in the latency form only");
   using Smem = SmemT<G>;
   if (MODE == 2 && int(blockIdx.x) >= nwgSweep) {
@@ -1234,6 +1167,9 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
     sm.deadline = (long long)wall_clock64() + budgetTicks;
   }
   if (tid < kWaves) { sm.recHead[tid] = 0; sm.outHead[tid] = 0; sm.outTail[tid] = 0; }
+#ifdef PF_EXPERIMENTS
+  poison_window(&sm.win[0][0][0], int(sizeof(sm.win) / sizeof(float2)));
+#endif
   __syncthreads();
   const int wg = sm.wg;
   const int LS = transposed ? H : W, LB = transposed ? W : H;   // extent along the step axis / across the bands
@@ -1246,16 +1182,16 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
   if (wave < kWaves) {
     // ======================= compute wave: band of 8 rows =======================
     if (wave >= nact) return;
-    __builtin_amdgcn_s_setprio(PF_PRIO_C);   // the helper waves share SIMDs with compute waves: compute wins issue arbitration
+    __builtin_amdgcn_s_setprio(kPrioCompute);   // the helper waves share SIMDs with compute waves: compute wins issue arbitration
 #ifdef PF_SWEEP_STATS
     sm.statEntry = tEntry;
 #endif
     const int top = (wave > 0) ? 1 : ((wg > 0 || staticTop) ? 2 : 0);   // where row 0's top neighbour comes from
     const int band = bandLo + band0 + wave;                               // absolute band index
     bool ok;
-    if (top == 1) ok = compute_band<G, 1, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, cf, uLo, LSv, boundary + size_t(wg + 1) * LSv);
-    else if (top == 2) ok = compute_band<G, 2, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, cf, uLo, LSv, boundary + size_t(wg + 1) * LSv);
-    else ok = compute_band<G, 0, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, cf, uLo, LSv, boundary + size_t(wg + 1) * LSv);
+    if (top == 1) ok = compute_band<G, 1, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, cf, uLo, LSv);
+    else if (top == 2) ok = compute_band<G, 2, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, cf, uLo, LSv);
+    else ok = compute_band<G, 0, TR, FWD, SPARSE>(sm, g1, W, H, nsteps, wave, band, nact, publishes, rW, rEps, cf, uLo, LSv);
     if (!ok) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #ifdef PF_SWEEP_STATS_PRINT   // (stage entry only: ctrl[2..3] belong to the next sweep in a whole solve)
     if (lane == 0) { atomicAdd(&ctrl[2], atomicExch(&sm.statHits, 0)); atomicAdd(&ctrl[3], atomicExch(&sm.statSpins, 0)); }
@@ -1265,7 +1201,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
 
   // helper waves: below the compute waves (3), above another kernel's waves that share this CU -- since the two directions run
   // out of phase, the other direction's Gaussians / medians / prepass sit on the sweep's SIMDs (strip -0.12 ms, 9000x4000 pair -0.4 ms)
-  __builtin_amdgcn_s_setprio(PF_PRIO_H);
+  __builtin_amdgcn_s_setprio(kPrioHelper);
   if constexpr (G::kBPW == 2) {
     if (wave >= kWaves && wave < kWaves + kLoaders) {
       sweep_loader_pair<G, TR, FWD>(sm, rec, g1, ctrl, W, H, nsteps, nstepsPad, wave - kWaves, nact, band0, bandLo, uLo, LSv);
@@ -1279,7 +1215,8 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
     // pair 46 -> 68 ms).  Now the window of chunk j (steps 8j .. 8j + 7) is centred on pixel + o(j), o(j) = the blurred flow at the chunk's
     // centre pixel rounded to integers (the flow is median-filtered and diffused at every level: inside 8 rows x 15 columns it stays
     // within a pixel or two of that), moving by at most one texel per chunk and axis:
-    //   * the LDS window is a TORUS addressed by the texel's absolute sweep-order coordinates: slot = ((v - ob) & 31) * stride + (u & 63)
+    //   * the LDS window is a TORUS addressed by the texel's IMAGE coordinates (round 6; until then: sweep-order coordinates relative to the band):
+    //     slot = ((image coordinate across the bands) & 31) * stride + ((image coordinate along the step axis) & 63)
     //     (ring row 0 again behind row 31, ring column 0 again behind column 63: a 2 x 2 footprint never wraps);
     //   * chunk j needs columns [uLo + 8j - 15 + ou, uLo + 8j + 15 + ou] x rows [vb - 8 + ov, vb + 15 + ov] ((ou, ov) = o(j) in sweep order):
     //     the loader keeps a column front and loads the 7 / 8 / 9 new columns of the chunk's 24 rows (8 + the change of ou), and, when ov
@@ -1293,7 +1230,6 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
     if (w >= nact) return;
     float2* winw = &sm.win[w][0][0];
     const int vb = (bandLo + band0 + w) * kRows;   // the band's first row (column, transposed) in sweep order
-    const int ob = vb - kRad;                      // origin of the ring rows (compute_band's `ob`)
     auto tex_ptr = [&](int u, int v) -> const float2* {   // texel (u, v) in sweep order; nullptr outside the image (never sampled: samples are clamped)
       if (u < 0 || u >= LS || v < 0 || v >= LB) return nullptr;
       const int cxc = TR ? v : u, cyc = TR ? u : v;
@@ -1302,8 +1238,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
     };
     // ring slot of texel (u, v) (sweep order): by its IMAGE coordinates along the step axis / across the bands (d_error_fast<FOLLOW = 1>, kAbs)
     auto ring_rc = [&](int u, int v, int& rr, int& cc) {
-      if (PF_ABS_TORUS) { rr = (FWD ? v : LB - 1 - v) & (kWRing - 1); cc = (FWD ? u : LS - 1 - u) & (kWC - 1); }
-      else { rr = (v - ob) & (kWRing - 1); cc = u & (kWC - 1); }
+      rr = (FWD ? v : LB - 1 - v) & (kWRing - 1); cc = (FWD ? u : LS - 1 - u) & (kWC - 1);
     };
     auto win_store = [&](int u, int v, float2 val) {
       int rr, cc; ring_rc(u, v, rr, cc);
@@ -1414,15 +1349,13 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
     bool first = true;
     for (;;) {
       const int oh = first ? 0 : ld_cnt(&sm.outHead[w]);
-#if PF_LOADER_IDLE
       // ring full (the usual state: the loader runs kRS steps ahead): a SHORT idle iteration -- the body below costs a few hundred
       // predicated-off instructions per pass, issued on the compute wave's own SIMD
       if (!first && rh + kChunk - oh > kRS) {
-        __builtin_amdgcn_s_sleep(PF_LOADER_IDLE);
+        __builtin_amdgcn_s_sleep(kLoaderIdleSleep);
         if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         continue;
       }
-#endif
       first = false;
       float4 va[kLoadAhead], vb4[kLoadAhead], vc[kLoadAhead];
       bool ld[kLoadAhead];
@@ -1496,8 +1429,8 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
             }
           }
           {   // does the block (columns [front, front + 8), rows [row0, row0 + 24)) contain ring column 0 / ring row 0?  (lowest ring coordinate of the block)
-            const int clo = (PF_ABS_TORUS ? (FWD ? front : LS - 8 - front) : front) & (kWC - 1);
-            const int rlo = (PF_ABS_TORUS ? (FWD ? row0 : LB - kRectRows - row0) : row0 - ob) & (kWRing - 1);
+            const int clo = (FWD ? front : LS - 8 - front) & (kWC - 1);
+            const int rlo = (FWD ? row0 : LB - kRectRows - row0) & (kWRing - 1);
             cdupc[c] = clo + 8 > kWC || clo == 0;
             cdupr[c] = rlo + kRectRows > kWRing || rlo == 0;
           }
@@ -1583,11 +1516,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
           int ot = sm.outTail[w];
           const int oh = ld_cnt(&sm.outHead[w]);
           int n = oh - ot; n = n > 8 ? 8 : n;
-#if PF_DRAIN_CHUNK
           if (n == 8 || (n > 0 && oh >= nsteps)) {   // whole chunks only (one full-wave store per band and chunk; the result ring holds four)
-#else
-          if (n > 0) {
-#endif
             const int j = lane >> 3, r = lane & 7, t = ot + j;
             if (j < n) {
               const float2 val = sm.out[w][t % kOS][r];
@@ -1609,7 +1538,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
       if (done) break;
       if (progress) idle = 0;
       else {
-        __builtin_amdgcn_s_sleep(PF_DRAIN_SLEEP);
+        __builtin_amdgcn_s_sleep(kDrainSleep);
         if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
     }
@@ -1618,7 +1547,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
 
   if (wave == kWaves + kLoaders) {
     // ======================= publisher: last row of the workgroup -> granules in HBM (tight loop, never waits on HBM) =======================
-    if (!publishes || PF_SELF_PUBLISH) return;
+    if (!publishes) return;
     unsigned long long* bnd_out = boundary + size_t(wg + 1) * LSv;   // granule row 0 belongs to the static row above the window
     const int wl = kWaves - 1;
     int pt = 0, idle = 0;
@@ -1637,7 +1566,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
         st_cnt(&sm.pubTail, pt);
         idle = 0;
       } else {
-        __builtin_amdgcn_s_sleep(PF_PUB_SLEEP);
+        __builtin_amdgcn_s_sleep(kPubSleep);
         if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { sm.abort = 1; __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
     }
@@ -1675,7 +1604,7 @@ __global__ __launch_bounds__(G::kThreads) void k_sweep2(const float4* __restrict
           idle = 0;
           continue;
         }
-        __builtin_amdgcn_s_sleep(PF_POLL_SLEEP);
+        __builtin_amdgcn_s_sleep(kPollSleep);
       } else {
         __builtin_amdgcn_s_sleep(8);
       }
@@ -1722,6 +1651,39 @@ __global__ __launch_bounds__(1024) void k_pk_probe(int rounds, unsigned* __restr
   }
   if (diff) atomicAdd(bad, 1u);
 }
+// The second hardware assumption of the product's sweep TU (round 6; tools/asm_sched.py --dpp-old-wait 0): a DPP move whose masks leave lanes
+// unwritten may DIRECTLY follow the instruction that wrote its destination -- those lanes keep the old value, nothing reads it through the
+// cross-lane network.  The step's own sequence (VALU producer of the pair, 64-bit row_newbcast moves, 32-bit row_bcast:15 moves) back to back
+// against the same with wait states, on changing data; a single differing bit refuses the device like the packed chains above
+// (tests/micro/dpp_old_probe.hip is the long form).
+#define PF_DPP_OLD_SEQ(N)                                                                                        \
+  "v_mov_b32 v12, %2\n v_mov_b32 v13, %3\n v_mov_b32 v16, %4\n v_mov_b32 v17, %5\n v_mov_b32 v18, %6\n v_mov_b32 v19, %7\n s_nop 4\n" \
+  "v_mov_b64_dpp v[14:15], v[12:13] row_newbcast:8 row_mask:0xf bank_mask:0x8 bound_ctrl:1\n s_nop 4\n"       \
+  "v_pk_add_f32 v[10:11], v[16:17], v[18:19]\n" N                                                               \
+  "v_mov_b64_dpp v[10:11], v[12:13] row_newbcast:0 row_mask:0xf bank_mask:0x9\n" N                              \
+  "v_mov_b64_dpp v[10:11], v[12:13] row_newbcast:8 row_mask:0xf bank_mask:0x4\n" N                              \
+  "v_mov_b32_dpp v10, v14 row_bcast:15 row_mask:0xe bank_mask:0x2\n" N                                          \
+  "v_mov_b32_dpp v11, v15 row_bcast:15 row_mask:0xe bank_mask:0x2\n s_nop 4\n"                                \
+  "v_mov_b32 %0, v10\n v_mov_b32 %1, v11\n"
+__global__ __launch_bounds__(1024) void k_dpp_old_probe(int rounds, unsigned* __restrict__ bad) {
+#if defined(__gfx950__)
+  unsigned s = (blockIdx.x * blockDim.x + threadIdx.x) * 2246822519u + 777u;
+  auto val = [&]() { s = s * 1664525u + 1013904223u; return float(int(s >> 8) % 20001 - 10000) / 256.0f; };
+  float p0 = val(), p1 = val(), a0 = val(), a1 = val(), b0 = val(), b1 = val();
+  unsigned diff = 0;
+  for (int r = 0; r < rounds; ++r) {
+    float x, y, xs, ys;
+    asm volatile(PF_DPP_OLD_SEQ("") : "=&v"(x), "=&v"(y) : "v"(p0), "v"(p1), "v"(a0), "v"(a1), "v"(b0), "v"(b1)
+                 : "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19");
+    asm volatile(PF_DPP_OLD_SEQ("s_nop 4\n") : "=&v"(xs), "=&v"(ys) : "v"(p0), "v"(p1), "v"(a0), "v"(a1), "v"(b0), "v"(b1)
+                 : "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19");
+    diff |= (__float_as_uint(x) ^ __float_as_uint(xs)) | (__float_as_uint(y) ^ __float_as_uint(ys));
+    const float fx = float(int(__float_as_uint(x) >> 9) % 4001 - 2000) / 64.0f, fy = float(int(__float_as_uint(y) >> 9) % 4001 - 2000) / 64.0f;
+    p0 = a1 + fx; p1 = b0 - fy; a0 = fy + float(r & 7); a1 = fx * 0.5f + 1.0f; b0 = p0 * 0.25f + 2.0f; b1 = fabsf(fy) + 0.5f;
+  }
+  if (diff) atomicAdd(bad, 1u);
+#endif
+}
 // 0 = the asm-block forms and the compiler-scheduled forms agree bit for bit on this device (or the build has no asm blocks); bad = scratch word on the device
 int sweep_pk_probe(hipStream_t st, unsigned* bad) {
 #if defined(PF_SAFE_PK)
@@ -1731,6 +1693,8 @@ int sweep_pk_probe(hipStream_t st, unsigned* bad) {
   if (hipMemsetAsync(bad, 0, 4, st) != hipSuccess) return -1;
   hipLaunchKernelGGL(k_pk_probe, dim3(256), dim3(64), 0, st, 256, bad);          // one wave per CU
   hipLaunchKernelGGL(k_pk_probe, dim3(256 * 4), dim3(1024), 0, st, 24, bad);      // 16 waves per SIMD
+  hipLaunchKernelGGL(k_dpp_old_probe, dim3(256), dim3(64), 0, st, 128, bad);
+  hipLaunchKernelGGL(k_dpp_old_probe, dim3(256 * 4), dim3(1024), 0, st, 16, bad);
   unsigned h = 1;
   if (hipMemcpyAsync(&h, bad, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
   return int(h);
@@ -1837,6 +1801,10 @@ static bool launch_sweep2_form(hipStream_t st, const SweepArgs& a, float* rec) {
 // hold at once -- a batch of pairs at the large levels -- and the latency form otherwise (a.wide: 0 / 1 forced, -1 = by size).
 // `concurrent` = sweep launches that run beside this one (the other direction's): the host's estimate, 2 for a bidirectional solve.
 bool launch_sweep2(hipStream_t st, const SweepArgs& a, float* rec) {
+#ifdef PF_EXPERIMENTS
+  static const int poison = [] { const int v = getenv("PANOFLOW_POISON_LDS") ? 1 : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_poison_lds), &v, sizeof(int)); return v; }();
+  (void)poison;
+#endif
   int wide = a.wide;
   if (wide < 0) {
     // oversubscribed launches of a batch: the throughput form where it exists (dense, bands stepping along x), else the latency form

@@ -216,7 +216,7 @@ __device__ __forceinline__ bool compute_band_t(SmemTF& sm, const float2* __restr
       if (TOP != 0) {
         if (__builtin_expect(waitTop, 0)) {
           if (!dead && s < LSv) {
-            const int need = (s + 1 + PF_MARGIN_T(TOP) < LSv) ? s + 1 + PF_MARGIN_T(TOP) : LSv;
+            const int need = (s + 1 + (TOP == 2 ? kMarginAcrossT : 0) < LSv) ? s + 1 + (TOP == 2 ? kMarginAcrossT : 0) : LSv;
             int spins = 0;
             for (;;) {
               const int avail = __builtin_amdgcn_readfirstlane(ld_cnt(topHead)) - kBias;
@@ -309,6 +309,9 @@ __global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__
     sm.deadline = (long long)wall_clock64() + budgetTicks;
   }
   if (tid < tWaves) { sm.recHead[tid] = 0; sm.outHead[tid] = 0; sm.outTail[tid] = 0; }
+#ifdef PF_EXPERIMENTS
+  poison_window(&sm.win[0][0][0], int(sizeof(sm.win) / sizeof(float2)));
+#endif
   __syncthreads();
   const int wg = sm.wg;
   const int LS = transposed ? H : W, LB = transposed ? W : H;
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__
       const int oh = first ? 0 : ld_cnt(&sm.outHead[w]);
       const bool ld = rh < nsteps && (rh + kChunk - oh <= kChunk * (tAhead + 1));
       if (!ld) {   // ring full (the usual state): a short idle iteration
-        __builtin_amdgcn_s_sleep(PF_LOADER_IDLE ? PF_LOADER_IDLE : 4);
+        __builtin_amdgcn_s_sleep(kLoaderIdleSleep);
         if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { give_up(); break; }
         continue;
       }
@@ -530,11 +533,7 @@ __global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__
           int ot = sm.outTail[w];
           const int oh = ld_cnt(&sm.outHead[w]);
           int n = oh - ot; n = n > 8 ? 8 : n;
-#if PF_DRAIN_CHUNK
           if (n == 8 || (n > 0 && oh >= nsteps)) {   // whole chunks: all 64 lanes of the four stores at work, an eighth of the passes
-#else
-          if (n > 0) {
-#endif
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int i = lane + 64 * u, j = i & 7, r = i >> 3, t = ot + j;   // a store covers 8 rows x 8 consecutive columns (64-byte runs)
@@ -559,7 +558,7 @@ __global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__
       if (done) break;
       if (progress) idle = 0;
       else {
-        __builtin_amdgcn_s_sleep(PF_DRAIN_SLEEP);
+        __builtin_amdgcn_s_sleep(kDrainSleep);
         if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { give_up(); break; }
       }
     }
@@ -586,7 +585,7 @@ __global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__
         st_cnt(&sm.pubTail, pt);
         idle = 0;
       } else {
-        __builtin_amdgcn_s_sleep(PF_PUB_SLEEP);
+        __builtin_amdgcn_s_sleep(kPubSleep);
         if (spin_expired(idle, sm) || ld_cnt(&sm.abort)) { give_up(); break; }
       }
     }
@@ -614,7 +613,7 @@ __global__ __launch_bounds__(tThreads) void k_sweep_t(const float4* __restrict__
           idle = 0;
           continue;
         }
-        __builtin_amdgcn_s_sleep(PF_POLL_SLEEP);
+        __builtin_amdgcn_s_sleep(kPollSleep);
       } else {
         __builtin_amdgcn_s_sleep(8);
       }

@@ -34,32 +34,37 @@ KERNEL = os.environ.get("ISA_KERNEL") or "_ZN2pf8k_sweep2INS_12_GLOBAL__N_16SwGe
 # instruction depends on the previous one -- the guide's 2-cycle wave64 VALU rate needs at least two waves per SIMD, and the sweep's
 # dependency chain lives in ONE wave per band.  "guide": MI355X_MICROARCH.md's throughput-side numbers (2-cycle issue, ~4-cycle
 # dependent VALU, ~50-cycle ds_read), i.e. the same stream on an ideal single-wave pipeline; reported beside it.
-LAT_LONE = {         # result latency: issue -> a dependent instruction may issue (cycles), lone wave, lat_probe.hip
-    "valu": 7,       # dependent chains: v_mul/v_add alternating 5.5, v_add 8.5, v_fract 8.5, v_lshl_add 8.6, v_med3 10.2 per link
-    "pk": 9,         # v_pk_add / v_pk_mul 9.0, v_pk_fma 8.5
-    "trans": 11,     # v_sqrt_f32 chain 12.5 per link; v_sqrt + v_add pair 16.5
-    "dpp": 14,       # v_mov_b32_dpp chain (with its s_nop 1) 16.5 per link
-    "cmp": 6.6,      # v_cmp -> v_cndmask pair 13.25
-    "ds_read": 50,   # + DS cycles of the instruction: ds_read_b32 52.5, b64 / b128 68.4, read2st64_b64 84.4 per dependent link
-    "salu": 4,
-    "readlane": 7,   # v_readfirstlane -> v_mov from the SGPR pair 13.25
-}
-ISSUE_LONE = {"valu": 5.5, "pk": 6.75, "trans": 8, "dpp": 7.5, "cmp": 5.5, "salu": 4, "readlane": 5.5, "nop": 4, "branch": 2, "wait": 1}   # 4 independent chains: per instruction; s_nop 0: 4 cycles (tests/micro/nop_cost.hip, round 5)
+# Round 6 (tests/micro/slot_model.py, profiles/r06_slot_model.txt): ONE wave alone on its SIMD issues one instruction per ~4.46 cycles WHATEVER it is --
+# dependent or not, scalar, vector, DPP or an s_nop state (v_add chains 4.34-4.46 with 0..4 independent instructions between the links; "a dependent
+# instruction costs 8.25" of round 5 was hipcc's own s_nop between two asm statements).  What costs more than a slot: consecutive packed fp32
+# (5.3-5.5 each), v_rsq (+4), an LDS instruction (+6 on average among the step's nine: 249 instead of 195 cycles for 44 v_add + all nine), a
+# not-taken branch (+4..+8).  Results are there for the next slot (no extra dependent latency) except: v_rsq -> reader one slot later (the
+# assembly carries that wait state), LDS reads (ds_read2_b64 x2 -> first use 94 cycles, ds_read_b64 / b32 61, b128 ~70).
+LAT_LONE = {"valu": 4.46, "pk": 5.0, "trans": 8.6, "dpp": 4.46, "cmp": 4.46, "ds_read": 52, "salu": 4.46, "readlane": 4.46}
+ISSUE_LONE = {"valu": 4.46, "pk": 5.0, "trans": 8.0, "dpp": 4.46, "cmp": 4.46, "salu": 4.46, "readlane": 4.46, "nop": 4.46, "branch": 8.0, "wait": 1}
+LDS_ISSUE_EXTRA = 6.0   # cycles an LDS instruction holds the wave's issue beyond a slot (lone-wave pricing only)
 LAT_GUIDE = {"valu": 4, "pk": 4, "trans": 16, "dpp": 11, "cmp": 7, "ds_read": 50, "salu": 4, "readlane": 8}
 ISSUE_GUIDE = {"valu": 2, "pk": 2, "trans": 8, "dpp": 2, "cmp": 2, "salu": 2, "readlane": 2, "nop": 1, "branch": 2, "wait": 1}
 LAT = dict(LAT_LONE)
 ISSUE = dict(ISSUE_LONE)
+DS_CYC_LONE = {"ds_read_b32": 9, "ds_read_b64": 9, "ds_read_b128": 18, "ds_read2_b64": 38, "ds_read2_b32": 9}   # + LAT["ds_read"] = issue -> first use, lone wave (slot_model)
 DS_CYC = {"ds_read_b32": 2, "ds_read_b64": 2, "ds_read_b128": 4, "ds_read2st64_b64": 8, "ds_read2_b64": 8, "ds_read2_b32": 4,
           "ds_write_b32": 4, "ds_write_b64": 6, "ds_write_b128": 13}   # guide, LDS table: cycles per wave-instruction
 
 
 def compile_asm():
-    out = "/tmp/isa_chain_sweep2.s"
-    # the flags of the Makefile (FLAGS + FLAGS_kernels_sweep2); ISA_FLAGS="..." replaces the scheduler flags for what-if runs
-    sched = os.environ.get("ISA_FLAGS", "-mllvm -amdgpu-sched-strategy=max-ilp").split()
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"] + sched +
-                          ["-S", "--cuda-device-only", SRC, "-o", out], stderr=subprocess.DEVNULL)
-    return out
+    """the assembly that ships: hipcc -S with the Makefile's flags, then tools/asm_sched.py with the Makefile's SCHED_FLAGS"""
+    out, sched_out = "/tmp/isa_chain_sweep2.s", "/tmp/isa_chain_sweep2.sched.s"
+    pkg = os.path.join(ROOT, "panorama-opticalflow_amd")
+    mk = open(os.path.join(pkg, "Makefile")).read()
+    var = lambda name: re.search(r"^%s\s*\??=\s*(.*)$" % re.escape(name), mk, re.M).group(1).strip()
+    # ISA_FLAGS="..." replaces the scheduler flags for what-if runs
+    sched = os.environ.get("ISA_FLAGS", var("FLAGS_kernels_sweep2")).split()
+    subprocess.check_call([var("HIPCC")] + var("FLAGS").replace("$(ARCH)", var("ARCH")).split() + sched + ["-S", "--cuda-device-only", SRC, "-o", out], stderr=subprocess.DEVNULL)
+    if os.environ.get("ISA_NO_SCHED"):
+        return out
+    subprocess.check_call([sys.executable, os.path.join(pkg, "tools", "asm_sched.py"), out, sched_out] + var("SCHED_FLAGS").split(), stderr=subprocess.DEVNULL)
+    return sched_out
 
 
 REG = re.compile(r"\b([vsa])(\d+)\b|\b([vsa])\[(\d+):(\d+)\]")
@@ -167,10 +172,14 @@ def classify(line):
 def price(i, lat, issue):
     if i.kind == "ds_read":
         base = i.mn.split()[0]
-        i.issue = issue["valu"]; i.lat = lat["ds_read"] + DS_CYC.get(base, 2)       # an LDS instruction takes the wave's issue slot like any other
+        lone = issue is not ISSUE_GUIDE
+        i.issue = issue["valu"] + (LDS_ISSUE_EXTRA if lone else 0); i.lat = lat["ds_read"] + (DS_CYC_LONE if lone else DS_CYC).get(base, 2)
     elif i.kind == "ds_write":
-        i.issue = max(issue["valu"], DS_CYC.get(i.mn, 4)); i.lat = 0
-    elif i.kind in ("wait", "nop", "branch"):
+        lone = issue is not ISSUE_GUIDE
+        i.issue = (issue["valu"] + LDS_ISSUE_EXTRA) if lone else max(issue["valu"], DS_CYC.get(i.mn, 4)); i.lat = 0
+    elif i.kind == "nop":
+        i.issue = issue["nop"] * (int(i.text.split()[1], 0) + 1); i.lat = 0     # s_nop N = N + 1 wait states
+    elif i.kind in ("wait", "branch"):
         i.issue = issue[i.kind]; i.lat = 0
     else:
         i.issue = issue[i.kind]; i.lat = lat[i.kind]
@@ -257,6 +266,7 @@ def analyse(body, loops, lat, issue, clock):
         e = {"loop": li, "instructions_per_8_steps": len(ins),
              "per_step": {"instructions": round(len(ins) / 8, 1), "vector": round(nvalu / 8, 1), "lds": round(nlds / 8, 1), "scalar_and_control": round(nsalu / 8, 1)},
              "reads_top_neighbour_from_lds": bool(has_top),
+             "issue_slots_per_step": round(sum((int(i.text.split()[1], 0) + 1) if i.kind == "nop" else (0 if i.kind == "wait" else 1) for i in ins) / 8, 1),
              "issue_only_cycles_per_step": round(sum(i.issue for i in ins) / 8, 1), "recurrence_cycles_per_step": round((lp2 - lp1) / 8, 1),
              "in_order_cycles_per_step": round(per_chunk / 8, 1), "in_order_us_per_step": round(per_chunk / 8 / (clock * 1e3), 4)}
         out.append((e, ins, times))
@@ -269,7 +279,7 @@ def main():
     ap.add_argument("--lat", action="append", default=[], help="override a lone-wave latency: name=cycles (valu, pk, trans, dpp, cmp, ds_read, salu, readlane)")
     ap.add_argument("--issue", action="append", default=[], help="override a lone-wave issue cost: name=cycles (valu, pk, trans, dpp, cmp, salu, readlane)")
     ap.add_argument("--clock-ghz", type=float, default=2.4)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_sweep_step_isa"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_sweep_step_isa"))
     a = ap.parse_args()
     lat, issue = dict(LAT_LONE), dict(ISSUE_LONE)
     for kv in a.lat:
@@ -291,11 +301,12 @@ def main():
     guide = analyse(body, loops, LAT_GUIDE, ISSUE_GUIDE, a.clock_ghz)
     pick = lambda rs, key: max((e[key] for e, _, _ in rs if e["reads_top_neighbour_from_lds"]), default=max(e[key] for e, _, _ in rs))
     result = {"kernel": "pf::k_sweep2<false, true, false, 0> (normal orientation, forward, dense, records from k_sweep_prep)", "clock_ghz": a.clock_ghz,
-              "lone_wave": {"latencies_cycles": lat, "issue_cycles": issue, "source": "tests/micro/lat_probe.hip on MI355X (profiles/r03_lat_probe.txt)", "loops": [e for e, _, _ in lone]},
+              "lone_wave": {"latencies_cycles": lat, "issue_cycles": issue, "lds_issue_extra_cycles": LDS_ISSUE_EXTRA, "source": "tests/micro/slot_model.py on MI355X (profiles/r06_slot_model.txt)", "loops": [e for e, _, _ in lone]},
               "guide_pipeline": {"latencies_cycles": LAT_GUIDE, "issue_cycles": ISSUE_GUIDE, "source": "MI355X_MICROARCH.md (2-cycle wave64 VALU, ~4-cycle dependent VALU, ~50-cycle ds_read; DPP / cmp / sqrt from tests/micro/issue_rate.hip)",
                                  "loops": [e for e, _, _ in guide]},
               "ds_cycles": DS_CYC,
-              "hw_floor_us": pick(lone, "in_order_us_per_step"), "hw_floor_cycles": pick(lone, "in_order_cycles_per_step"),
+              "isa_model_us": pick(lone, "in_order_us_per_step"), "isa_model_cycles": pick(lone, "in_order_cycles_per_step"),
+              "issue_slots_per_step": pick(lone, "issue_slots_per_step"),
               "recurrence_floor_cycles": pick(lone, "recurrence_cycles_per_step"),
               "guide_pipeline_floor_us": pick(guide, "in_order_us_per_step"), "guide_pipeline_floor_cycles": pick(guide, "in_order_cycles_per_step"),
               "how_to_recompute": "python tests/micro/isa_chain.py [--lat name=cycles ...] [--issue name=cycles ...]   (compiles csrc/kernels_sweep2.hip with the product's flags; no GPU needed)"}
@@ -305,11 +316,12 @@ def main():
                 "342-386, 427-456: gate, proposeFlowUpdate from L and T, errorGradient, flow -= 0.5 * grad; six errorFunction evaluations in six lanes).\n"
                 "Generated by tests/micro/isa_chain.py from `hipcc -S` of csrc/kernels_sweep2.hip with the product's flags; recompute with\n"
                 "`python tests/micro/isa_chain.py [--lat name=cycles] [--issue name=cycles]`.\n\n"
-                "WHAT BOUNDS A STEP.  The sweep's dependency chain lives in ONE wave per band of 8 rows, and on gfx950 one wave alone is offered an\n"
-                "issue slot only every ~5.5 cycles -- measured (tests/micro/lat_probe.hip, profiles/r03_lat_probe.txt): four independent v_add_f32\n"
-                "chains 5.5 cycles per instruction, a dependent chain 5.5-8.5, v_pk_* 6.75 / 9.0, DPP 7.5 / 16.5, ds_read_b64 68 dependent.  The\n"
-                "guide's 2-cycle wave64 VALU rate (MI355X_MICROARCH.md: SIMD-32) needs two or more waves per SIMD.  So a step costs its instruction\n"
-                "COUNT x the lone-wave issue interval; the loop-carried dependency cycle (`recurrence`) is about half of that and is not the limit.\n\n")
+                "WHAT BOUNDS A STEP.  The sweep's dependency chain lives in ONE wave per band of 8 rows, and on gfx950 one wave alone on its SIMD issues ONE\n"
+                "instruction per ~4.46 cycles whatever it is -- dependent or not, vector, scalar, DPP, or an s_nop state (tests/micro/slot_model.py,\n"
+                "profiles/r06_slot_model.txt; the guide's 2-cycle wave64 VALU rate needs two or more waves per SIMD).  So a step costs its issue SLOTS\n"
+                "(instructions + wait states) x that interval, plus what a few instruction kinds hold the issue longer (consecutive packed fp32, v_rsq,\n"
+                "LDS instructions, branches) and whatever LDS latency the stream does not cover; the loop-carried dependency cycle (`recurrence`) is\n"
+                "shorter and not the limit.  This is the PRODUCT's assembly: hipcc's output after tools/asm_sched.py (Makefile SCHED=1).\n\n")
         f.write("Three instances of the loop exist in the kernel (compute_band<TOP>: first band of a sweep / band inside a workgroup / first band of a\n"
                 "workgroup); each is the 8-step unrolled chunk (a step starts at its first `row_newbcast:0` DPP move).\n\n")
         for (e, _, _), (g, _, _) in zip(lone, guide):
@@ -320,16 +332,14 @@ def main():
                        ", row 0 takes its top neighbour from the LDS ring" if e["reads_top_neighbour_from_lds"] else ", no top neighbour (first band)",
                        e["issue_only_cycles_per_step"], e["recurrence_cycles_per_step"], e["in_order_cycles_per_step"], e["in_order_us_per_step"], a.clock_ghz,
                        g["issue_only_cycles_per_step"], g["recurrence_cycles_per_step"], g["in_order_cycles_per_step"], g["in_order_us_per_step"]))
-        f.write("\nhw_floor_us = %.4f  (lone-wave pricing, max over the loops that read a top neighbour; bench.py: roofline.latency_bound.hw_floor_us).\n"
-                "Measured on MI355X: 0.267 us per step for a lone band (bench.py t_step_us, HIP events; effective clock 2.41 GHz by GRBM_GUI_ACTIVE,\n"
-                "tests/micro/clock_probe.sh): the kernel runs AT this floor (the model is a few percent pessimistic: it prices every vector instruction\n"
-                "at the measured average interval).  On an ideal single-wave pipeline (guide numbers) the same stream would need %.4f us: the factor\n"
-                "between the two is the lone-wave issue interval, which no instruction placement changes -- only fewer instructions per step do\n"
-                "(round 1: 0.70 us -> round 2: 0.35 -> round 3: 0.275 -> round 5: 0.267 us by removing them; DESIGN.md 3.3), or a second wave that shares the step's work, which the\n"
-                "step's own dependency chain forbids (every hand-over between waves goes through LDS: >= 90 cycles per hop, lat_probe).\n"
-                "Round 4 measured the other side of the same coin: the SIMD's VALU pipe takes ~4 cycles per wave64 instruction, so ONE such wave already keeps it ~65 %% busy --\n"
-                "two compute waves per SIMD (the wide workgroup shape, same instruction stream) run at 0.43 us per step each, not 0.29 (profiles/r04_wide_sweep.txt).\n\n"
-                % (result["hw_floor_us"], result["guide_pipeline_floor_us"]))
+        f.write("\nisa_model_us = %.4f (%.1f issue slots per step; lone-wave pricing, max over the loops that read a top neighbour; bench.py:\n"
+                "roofline.latency_bound.isa_model_us).  It is a MODEL of one wave in order with this round's measured slot prices, to be read beside the\n"
+                "measured step of a lone band (bench.py t_step_us, HIP events around a whole 8 x 4096 launch, i.e. including the launch's start-up and the\n"
+                "loaders' first round trips): the measurement must not fall below it.  On an ideal single-wave pipeline (guide numbers: 2-cycle issue) the\n"
+                "same stream would need %.4f us: the factor between the two is the lone-wave issue interval, which no instruction placement changes --\n"
+                "only fewer slots per step do (round 1: 0.70 us -> 2: 0.35 -> 3: 0.275 -> 5: 0.267 -> 6: see bench; DESIGN.md 3.3), or a second wave that\n"
+                "shares the step's work, which the step's own dependency chain forbids (every hand-over between waves goes through LDS: >= 60 cycles per hop).\n\n"
+                % (result["isa_model_us"], result["issue_slots_per_step"], result["guide_pipeline_floor_us"]))
         # annotated listing of the slowest top-reading loop, lone-wave pricing
         e, ins, times = max((r for r in lone if r[0]["reads_top_neighbour_from_lds"]), key=lambda r: r[0]["in_order_cycles_per_step"], default=lone[0])
         n = len(ins)
@@ -357,7 +367,7 @@ def main():
         step_no = 0
         nstar = nwait = 0
         for k, i in enumerate(ins):
-            if "row_newbcast:0" in i.text and (k == 0 or "row_newbcast:0" not in ins[k - 1].text):
+            if "row_newbcast:0" in i.text and (i.mn == "v_mov_b64_dpp" or k == 0 or "row_newbcast:0" not in ins[k - 1].text):
                 step_no += 1
                 f.write("  ---- step %d of the chunk ----\n" % step_no)
             start, why = tl[(5, k)]
@@ -365,7 +375,7 @@ def main():
             flag = ("*" if (5, k) in crit else " ") + ("L" if why == "lds" else (">" if why is not None else " "))
             f.write("  %s %7.0f  %s\n" % (flag, start - base, i.text))
         f.write("\n%d of the chunk's %d instructions issued the moment their slot came (no operand wait); %d waited for an operand or the LDS queue.\n" % (n - nwait, n, nwait))
-    print(json.dumps({k: result[k] for k in ("hw_floor_us", "hw_floor_cycles", "recurrence_floor_cycles", "guide_pipeline_floor_us")}))
+    print(json.dumps({k: result[k] for k in ("isa_model_us", "isa_model_cycles", "issue_slots_per_step", "recurrence_floor_cycles", "guide_pipeline_floor_us")}))
 
 
 if __name__ == "__main__":

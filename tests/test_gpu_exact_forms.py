@@ -43,3 +43,20 @@ def test_packed_fp32_chains_need_no_wait_states():
     assert r.returncode == 0, r.stdout + r.stderr
     assert "identical with and without s_nop" in r.stdout
     assert "differing results 0" in r.stdout
+
+
+DPP_PROBE = os.path.join(HERE, "..", "panorama-opticalflow_amd", "tools", "dpp_old_probe")
+
+
+@pytest.mark.gpu
+def test_partial_dpp_writes_need_no_wait_states_behind_the_old_value():
+    """The product's sweep TU is scheduled by tools/asm_sched.py with --dpp-old-wait 0: a DPP move whose bank / row masks leave lanes unwritten
+    may directly follow the instruction that wrote its destination (LLVM counts the tied old operand like the DPP source: 2 wait states).  The
+    probe runs the step's own sequence -- VALU producer, 64-bit row_newbcast moves, 32-bit row_bcast:15 moves -- with and without wait states,
+    one wave alone up to 16 waves per SIMD, and must get identical bits."""
+    assert os.path.exists(DPP_PROBE), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    r = subprocess.run([DPP_PROBE], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical with and without wait states" in r.stdout
+    assert r.stdout.strip().splitlines()[-1] == "mismatches 0"

@@ -231,3 +231,56 @@ def test_missing_hardware_queues_raise_a_warning():
     assert "PROF None" in out, out
     out = run("16")
     assert [l for l in out.splitlines() if l.startswith("WARN")][0].split()[1] == "0", out
+
+
+_POISON_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/oracle")
+from tests.conftest import load_pkg_module
+import orc
+orc.build()
+pf = load_pkg_module("pyabi")
+bad = 0
+for form in (0, 2):
+    ctx = pf.Context(0, exp=True, sweep_wide=form)
+    for (w, h) in ((260, 150), (150, 260)):
+        r = np.random.default_rng(77 + w + form)
+        img0 = r.random((h, w)).astype(np.float32); img1 = np.roll(img0, 3, axis=1) + 0.05 * r.random((h, w)).astype(np.float32)
+        g0 = np.stack(orc.gradients(img0), -1); g1 = np.stack(orc.gradients(img1), -1)
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        flow = np.stack([9.0 * np.sin(xx / 40.0) + 0.5 * r.standard_normal((h, w)), 6.0 * np.cos(yy / 30.0) + 0.5 * r.standard_normal((h, w))], -1).astype(np.float32)
+        a0 = np.ones((h, w), np.float32); a1 = np.ones((h, w), np.float32)
+        # pixels that are NOT updated, next to pixels that are, carrying flows no window holds: huge, infinite, NaN
+        a0[h // 4: h // 4 + 11, w // 5: w // 2] = 0.3
+        a1[2 * h // 3:, ::3] = 0.0
+        off = (a0 <= 0.9) | (a1 <= 0.9)
+        wild = np.array([1.0e30, -3.0e38, np.inf, -np.inf, np.nan, 250.0, -777.0, 0.0], np.float32)
+        idx = np.argwhere(off)
+        flow[idx[:, 0], idx[:, 1], 0] = wild[(idx[:, 0] + 3 * idx[:, 1]) %% 8]
+        flow[idx[:, 0], idx[:, 1], 1] = wild[(5 * idx[:, 0] + idx[:, 1]) %% 8]
+        blurred = orc.gaussian_blur(np.nan_to_num(flow, nan=0.0, posinf=0.0, neginf=0.0).clip(-50, 50), 15, 8.0)
+        for fwd in (1, 0):
+            ref = orc.sweep(g0[..., 0], g0[..., 1], g1[..., 0], g1[..., 1], blurred, a0, a1, flow, fwd)
+            got = ctx.stage_sweep(g0, g1, blurred, a0, a1, flow, fwd)
+            same = (got.view(np.uint32) == ref.view(np.uint32)) | ((got == 0) & (ref == 0))
+            n = int((~same).sum())
+            print("form", form, w, h, "forward", fwd, "differing", n, "updated pixels changed", int(((ref != flow) & ~np.isnan(ref)).any(-1).sum()))
+            bad += n
+    ctx.close()
+print("POISON_RESULT", bad)
+"""
+
+
+def test_sweep_garbage_in_the_gather_window_never_reaches_a_result():
+    """Pixels that are not updated evaluate their (discarded) proposals on whatever their LDS window slot holds -- with the flow-following window
+    possibly a slot no loader wrote since the kernel started -- and pixels that are updated must only ever read texels their loader brought.
+    The lab build with PANOFLOW_POISON_LDS=1 fills every sweep workgroup's gather windows with NaN / inf / +-1e38 first; not-updated pixels
+    carry huge / infinite / NaN flows next to updated ones.  Both product sweep forms (latency, throughput; the lab build compiles the same
+    templates) must still equal the oracle bit for bit: garbage can neither beat the kept energy nor trigger a redo that changes a result."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PANOFLOW_POISON_LDS="1")
+    r = subprocess.run([sys.executable, "-c", _POISON_SCRIPT % {"root": root}], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    print(r.stdout[-3000:]); print(r.stderr[-2000:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "POISON_RESULT 0" in r.stdout
