@@ -49,7 +49,10 @@ for f, v in sorted(fam.items(), key=lambda kv: -kv[1]["ns"]):
 out.append("%-22s %10s %10.3f" % ("sum of kernel time", "", tot))
 txt = "\n".join(out); print(txt)
 open("gpurun_out/%s_batch_summary_%d.txt" % (R, cols), "w").write(txt + "\n")
-os.system("cp %s gpurun_out/%s_batch_kernel_stats_%d.csv" % (ks, R, cols))
+import csv as _csv   # (without the rows of torch's own kernels, which make the synthetic inputs)
+_rows = list(_csv.reader(open(ks)))
+_csv.writer(open("gpurun_out/%s_batch_kernel_stats_%d.csv" % (R, cols), "w", newline="")).writerows(
+    [_rows[0]] + [r for r in _rows[1:] if not any(t in r[0] for t in ("at::", "rocprim", "rocclr", "hipcub", "elementwise", "c10::"))])
 if have_pmc:
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) of ONE pf_novel_view_batch_dev call on 8 pairs %dx%d; bytes per PAIR; gfx950 counts wide reads at 1/2: true fetch in [raw, 2*raw]" % (cols, rows),
                "families": js}, open("gpurun_out/%s_batch_pmc_%d.json" % (R, cols), "w"), indent=1)

@@ -9,7 +9,15 @@ R=${1:-r01}
 rm -rf gpurun_out/prof_$R gpurun_out/pmcb_*
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$R -o bench -- python bench.py --no-cpu-baseline --no-extras --pairs-total 0 > gpurun_out/prof_$R.log 2>&1
 grep "^{\"metric\"" gpurun_out/prof_$R.log | tail -1 > gpurun_out/${R}_bench_line.json
-cp $(find gpurun_out/prof_$R -name '*kernel_stats.csv' | head -1) gpurun_out/${R}_bench_kernel_stats.csv
+# (the synthetic inputs are made with torch on the GPU: its at::native / rocprim kernels are not the product's -- filtered out, percentages left as reported)
+python - <<PY
+import csv, glob
+src = sorted(glob.glob('gpurun_out/prof_$R/**/*kernel_stats.csv', recursive=True))[0]
+rows = list(csv.reader(open(src)))
+keep = [rows[0]] + [r for r in rows[1:] if not any(t in r[0] for t in ('at::', 'rocprim', 'rocclr', 'hipcub', 'elementwise', 'c10::'))]
+csv.writer(open('gpurun_out/${R}_bench_kernel_stats.csv', 'w', newline='')).writerows(keep)
+print("kernel stats: kept %d of %d rows" % (len(keep) - 1, len(rows) - 1))
+PY
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 1200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcb_$c -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-profile --pairs-total 0 > gpurun_out/pmcb_$c.log 2>&1
   echo "$c rc=$?"
