@@ -21,15 +21,15 @@
 //     waves stream records and window texels HBM->LDS ahead of the wavefront, drain results LDS->HBM,
 //     publish the granules and poll the previous workgroup's granules, so the long-latency traffic sits in
 //     THEIR in-order memory queues, not in the compute waves'.
-//   * a lone wave issues one instruction every ~5 cycles here (independent 4.75, directly dependent 8.25, an s_nop 4.0:
-//     tests/micro/nop_cost.hip), so the step time is the instruction count (and, among equals, the length of the
-//     loop-carried chain): ~119 instructions per step (packed fp32 math, exact cheap forms of sqrt and division --
-//     exact_forms.hpp --, one range guard per step, no per-step address arithmetic that a loop-carried register or an
-//     immediate can replace, no LDS-order stalls, the serial packed chains and the window address as single instruction
-//     blocks without the compiler's wait states).  DESIGN.md 3.2-3.3 and docs/history.md have the history (154 -> 119),
-//     profiles/r05_sweep_step_isa.txt the listing.
+//   * a lone wave issues ONE instruction per ~4.46 cycles here whatever it is -- dependent or not, vector, scalar, DPP or an s_nop state
+//     (tests/micro/slot_model.py, profiles/r06_slot_model.txt) -- so the step time is its count of issue SLOTS: 103 per step since round 6
+//     (packed fp32 math, exact cheap forms of sqrt and division -- exact_forms.hpp --, one range guard per step, no per-step address arithmetic
+//     that a loop-carried register or an immediate can replace, 64-bit DPP moves for the proposals, the across proposal's moves folded into
+//     v_cndmask_b32_dpp / v_sub_f32_dpp, the gather torus addressed by image coordinates), and the product's assembly goes through
+//     tools/asm_sched.py, which re-derives the wait states and fills them with independent instructions (hipcc leaves 7-9 per step, the pass 0-1).
+//     DESIGN.md 3.2-3.3 and docs/history.md have the history (154 -> 103), profiles/r06_sweep_step_isa.txt the listing.
 //   * the gather window in LDS follows the flow (round 5): centred per chunk of 8 steps on pixel + the rounded blurred
-//     flow, a torus addressed by absolute texel coordinates (the loader of k_sweep2 below).
+//     flow, a torus addressed by the texel's image coordinates (the loader of k_sweep2 below).
 // Workgroups take their band index from an atomic ticket (a band only waits for bands already
 // running), every spin is bounded and raises ctrl[1] instead of hanging.
 #include <hip/hip_ext.h>
