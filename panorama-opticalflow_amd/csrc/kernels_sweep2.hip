@@ -386,8 +386,12 @@ __device__ __forceinline__ float d_error_fast(const float2* __restrict__ g1, __a
 // test holds the two to each other).  The block's DPP reads stand >= 2 slots behind the writers of their sources by construction (rp is written
 // before the block and first read through DPP in its fourth slot; tools/asm_sched.py knows the instructions and re-checks).
 #define PF_DPP4 " row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-template <bool FAST, bool TR, bool CROSS = false>
-__device__ __forceinline__ float2 select_step(float e, float eC, float eCL, float2 rC, float2 cnd, bool okL, bool okT, float rEps, float step, int& emin, float& vmax) {
+// MID: a hook of the caller's that is issued between the gradient step and the selection -- compute_band puts its read-ahead of the producer's
+// step counter and top value there (round 6): as late in the step as the LDS latency before the step's publishing wait allows, so that a band
+// follows the band above ~0.25 step closer (same-box: lone dense pair 43.70 -> 43.51 ms; profiles/r06_step_block_ab.txt)
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+template <bool FAST, bool TR, bool CROSS = false, class MID = NoMid>
+__device__ __forceinline__ float2 select_step(float e, float eC, float eCL, float2 rC, float2 cnd, bool okL, bool okT, float rEps, float step, int& emin, float& vmax, MID mid = MID()) {
   [[maybe_unused]] constexpr bool kFuse = FAST && CROSS && PF_PK_ASM;
   float2 rp;                                               // this lane's proposal after its gradient step (meaningful in lanes 0 and 4)
   if (FAST) {
@@ -428,6 +432,9 @@ __device__ __forceinline__ float2 select_step(float e, float eC, float eCL, floa
     const float gx = (g1 - e) / kGradEpsilon, gy = (g2 - e) / kGradEpsilon;
     rp = make_float2(cnd.x - step * gx, cnd.y - step * gy);
   }
+  __builtin_amdgcn_sched_barrier(0);   // (the barriers keep the compiler from hoisting the two independent LDS reads back up)
+  mid();
+  __builtin_amdgcn_sched_barrier(0);
 #if PF_PK_ASM
   if (kFuse && !TR) {
     // L = the along proposal (own lane), T = the across proposal (lane + 4); okL and okT are true here
@@ -687,14 +694,17 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
             ++statHits;
 #endif
             for (;;) {
-              const int avail = __builtin_amdgcn_readfirstlane(ld_cnt(topHead)) - kBias;   // columns [0, avail) of the row above are in the ring
+              // counter, then value, issued together (one wave's LDS operations execute in issue order: a counter that says "there" makes the
+              // value read behind it good) -- one LDS round trip per poll instead of two dependent ones at the exit
+              const int cnt = ld_cnt(topHead);
+              tv = __hip_atomic_load(top_slot(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              const int avail = __builtin_amdgcn_readfirstlane(cnt) - kBias;   // columns [0, avail) of the row above are in the ring
               if (avail >= need) break;
               if (spin_expired(spins, sm) || (((spins & 255) == 0) && ld_cnt(&sm.abort))) { dead = true; break; }
             }
 #ifdef PF_SWEEP_STATS
             statSpins += spins;
 #endif
-            tv = __hip_atomic_load(top_slot(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             // leave nothing in flight at the join with the fast path (the compiler would wait there on every step)
             unsigned tlo = unsigned(tv), thi = unsigned(tv >> 32);
             asm volatile("" : "+v"(tlo), "+v"(thi));
@@ -766,8 +776,9 @@ __device__ __forceinline__ bool compute_band(SmemT<G>& sm, const float2* __restr
         na = make_float4(q0.x, q0.y, q0.z, q0.w);
         if (transposed) { const f3v q1 = *(__attribute__((address_space(3))) const f3v*)(rpn + 1); nb = make_float4(q1.x, q1.y, q1.z, 0.f); }
         else { const f4v q1 = rpn[1]; nb = make_float4(q1.x, q1.y, q1.z, q1.w); } }
-      if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-      fin = select_step<true, TR, TOP != 0>(e, eC, eCL, rC, cnd, okL, okT, rEps, cf.step, emin, vmax);
+      // the producer's counter and the top value of the NEXT step, read inside select_step (MID): ~16 slots in front of the step's publishing wait
+      auto read_top_ahead = [&]() { if (TOP != 0) { hN = ld_cnt(topHead); tvN = __hip_atomic_load(tpn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } };
+      fin = select_step<true, TR, TOP != 0>(e, eC, eCL, rC, cnd, okL, okT, rEps, cf.step, emin, vmax, read_top_ahead);
       asm volatile("" : "+v"(fin.x), "+v"(fin.y));   // finish the fast result before the branch: the range test then runs beside the division, not before it
       // Only pixels that will be updated count: the lanes of a pixel without data (gate <= 0) still run the arithmetic, and
       // there the inputs are blur tails of black borders (operands ~1e-40) -- their result is discarded two lines below.
