@@ -82,8 +82,10 @@ typedef struct pf_config {
 } pf_config;
 void pf_config_init(pf_config* cfg);
 /* Self-test that pf_create already ran once for the context's device: the sweep's asm-block packed-fp32 chains against the
- * compiler-scheduled forms of the same arithmetic.  0 = identical bits (or a -DPF_SAFE_PK build, which has no such blocks);
- * > 0 = threads whose results differed (pf_create would have refused the device); < 0 = error code. */
+ * compiler-scheduled forms of the same arithmetic, and (round 6) the step's partial DPP writes issued back to back against the same
+ * sequence with wait states (the two hardware assumptions of the scheduled sweep TU).  0 = identical bits (or a
+ * -DPF_SAFE_PK build, which has no such blocks); > 0 = threads whose results differed (pf_create would have refused the device);
+ * < 0 = error code. */
 int pf_selftest_packed_chains(pf_ctx* ctx);
 pf_ctx* pf_create_cfg(const pf_config* cfg);
 void pf_destroy(pf_ctx* ctx);
